@@ -1,0 +1,169 @@
+"""ctypes front-end of the CPU oracle (oracle/ddm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package; bayesflow_nddms_amd never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_SRC = os.path.join(_HERE, "ddm_oracle.c")
+
+M_BASIC, M_SINGLE, M_ALT, M_ALPHA_NS, M_EXPLICIT = 0, 1, 2, 3, 4
+SUMMARY_K = 10
+
+_lib = None
+
+
+def build(force=False):
+    """gcc the oracle into oracle/liboracle.so (contraction off: every fma is spelled out)."""
+    if (not force and os.path.exists(_SO)
+            and (not os.path.exists(_SRC) or os.path.getmtime(_SO) >= os.path.getmtime(_SRC))):
+        return _SO
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-mfma", "-fno-math-errno", "-fopenmp", "-fPIC", "-shared",
+           "-o", _SO, _SRC, "-lm"]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.oracle_mt_seed.argtypes = [ctypes.c_uint32]
+        L.oracle_mt_double.restype = ctypes.c_double
+        L.oracle_mt_gauss.restype = ctypes.c_double
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.oracle_mt_basic.argtypes = [dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
+        L.oracle_mt_single.argtypes = [dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_int, dp]
+        L.oracle_mt_explicit.argtypes = [dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
+        L.oracle_mt_explicit.restype = ctypes.c_int
+        L.oracle_mt_ratcliff.argtypes = [ctypes.c_int] + [ctypes.c_double] * 8 + [dp]
+        L.oracle_model_nparams.argtypes = [ctypes.c_int]
+        L.oracle_model_nparams.restype = ctypes.c_int
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.oracle_philox_simulate.argtypes = [
+            ctypes.c_int, fp, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_uint64,
+            ctypes.c_uint64, ctypes.c_float, ctypes.c_int, fp, ctypes.POINTER(ctypes.c_int32), fp, fp,
+            ctypes.c_int]
+        L.oracle_philox_simulate.restype = ctypes.c_int
+        L.oracle_philox_normals4.argtypes = [ctypes.c_uint32] * 6 + [fp]
+        L.oracle_philox_block.argtypes = [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _fptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+# ----------------------------------------------------------------------------- MT19937 mode
+def mt_seed(seed):
+    """np.random.seed(int) equivalent for the oracle's global legacy stream."""
+    lib().oracle_mt_seed(int(seed) & 0xFFFFFFFF)
+
+
+def mt_gauss():
+    return lib().oracle_mt_gauss()
+
+
+def mt_double():
+    return lib().oracle_mt_double()
+
+
+def mt_basic(params, n_trials, dt=0.01, max_steps=400.0):
+    """basic_ddm_dc.py:114-125 simulate_trials on the NumPy legacy stream (float64)."""
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    out = np.empty((n_trials, 2), dtype=np.float64)
+    lib().oracle_mt_basic(_dptr(p), n_trials, dt, max_steps, _dptr(out))
+    return out
+
+
+def mt_single(params, n_trials, dt=0.01, max_steps=400.0, gamma=1.0, variant=0):
+    """single_trial_alpha_not_scaled.py:144-155 (variant 0; gamma for _scale/_scale2) / :963-974 (variant 1, _alt)."""
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    assert p.shape == (7,)
+    out = np.empty((n_trials, 2), dtype=np.float64)
+    lib().oracle_mt_single(_dptr(p), n_trials, dt, max_steps, gamma, variant, _dptr(out))
+    return out
+
+
+def mt_explicit(drift, bounds, beta, ter, dc, dt=0.01, max_steps=400.0):
+    """imputation_from_stahl_not_scaled.py:120-148 over a boundary vector."""
+    p = np.array([drift, beta, ter, dc], dtype=np.float64)
+    b = np.ascontiguousarray(bounds, dtype=np.float64)
+    out = np.empty(len(b), dtype=np.float64)
+    rc = lib().oracle_mt_explicit(_dptr(p), _dptr(b), len(b), dt, max_steps, _dptr(out))
+    if rc != 0:
+        raise ValueError("Trial-level boundary cannot be less than zero")
+    return out
+
+
+def mt_ratcliff(N=100, Alpha=1, Tau=.4, Nu=1, Beta=.5, rangeTau=0, rangeBeta=0, Eta=.3, Varsigma=1):
+    """pyhddmjagsutils.py:47-176 simulratcliff on the NumPy legacy stream."""
+    out = np.empty(N, dtype=np.float64)
+    lib().oracle_mt_ratcliff(N, Alpha, Tau, Nu, Beta, rangeTau, rangeBeta, Eta, Varsigma, _dptr(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- Philox mode
+def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, set_offset=0, bounds=None,
+                    ext_sigma=0.0, ext_mode=0, want_trials=True, want_k=False, want_summary=True,
+                    want_ext=False, threads=1):
+    """The device stream on the CPU: element-wise checker of the HIP kernels.
+
+    Returns dict(trials f32[B,N,2], k i32[B,N], summary f32[B,10], ext f32[B]) (requested keys only)."""
+    L = lib()
+    P = L.oracle_model_nparams(model)
+    p = np.ascontiguousarray(params, dtype=np.float32)
+    if p.ndim == 1:
+        p = p[None]
+    assert p.shape[1] == P, f"model {model} takes {P} parameters per set, got {p.shape}"
+    B = p.shape[0]
+    max_k = int(np.ceil(max_steps))
+    bnd = None
+    if model == M_EXPLICIT:
+        bnd = np.ascontiguousarray(bounds, dtype=np.float32).reshape(B, n_trials)
+    res = {}
+    trials = np.empty((B, n_trials, 2), np.float32) if want_trials else None
+    k = np.empty((B, n_trials), np.int32) if want_k else None
+    summ = np.empty((B, SUMMARY_K), np.float32) if want_summary else None
+    ext = np.empty((B,), np.float32) if want_ext else None
+    rc = L.oracle_philox_simulate(
+        model, _fptr(p), _fptr(bnd), B, n_trials, np.float32(dt), max_k, seed, set_offset,
+        np.float32(ext_sigma), ext_mode, _fptr(trials),
+        None if k is None else k.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _fptr(summ), _fptr(ext),
+        threads)
+    if rc != 0:
+        raise ValueError(f"oracle_philox_simulate rc={rc}")
+    if want_trials:
+        res["trials"] = trials
+    if want_k:
+        res["k"] = k
+    if want_summary:
+        res["summary"] = summ
+    if want_ext:
+        res["ext"] = ext
+    return res
+
+
+def philox_normals4(c0, c1, c2, c3, k0, k1):
+    z = np.empty(4, np.float32)
+    lib().oracle_philox_normals4(c0, c1, c2, c3, k0, k1, _fptr(z))
+    return z
+
+
+def philox_block(c0, c1, c2, c3, k0, k1):
+    x = np.empty(4, np.uint32)
+    lib().oracle_philox_block(c0, c1, c2, c3, k0, k1, x.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    return x
