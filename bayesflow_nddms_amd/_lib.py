@@ -1,0 +1,76 @@
+"""ctypes binding of libnddm_hip.so (include/nddm.h).  No CPU fallback exists: if the HIP
+library is missing or cannot be loaded, importing the simulators fails loudly."""
+import ctypes
+import os
+
+from .build import SO_PATH
+
+NDDM_OK, NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM, NDDM_ERR_HIP, NDDM_ERR_NO_DEVICE = range(6)
+GAUSS_EXACT, GAUSS_FAST = 0, 1
+ABI_VERSION = 1
+
+_lib = None
+
+
+class NddmLibraryError(ImportError):
+    pass
+
+
+def _declare(L):
+    c = ctypes
+    fp, vp = c.c_void_p, c.c_void_p      # device pointers travel as integers
+    L.nddm_abi_version.restype = c.c_int
+    L.nddm_last_error.restype = c.c_char_p
+    L.nddm_device_count.argtypes = [c.POINTER(c.c_int)]
+    L.nddm_set_device.argtypes = [c.c_int]
+    L.nddm_summary_k.restype = c.c_int
+    L.nddm_model_nparams.argtypes = [c.c_int]
+    L.nddm_set_tuning.argtypes = [c.c_int] * 4
+    common = [c.c_int64, c.c_int32, c.c_float, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32]
+    for name in ("nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate", "nddm_single_trial_alt_simulate"):
+        getattr(L, name).argtypes = [fp] + common + [fp, fp, vp]
+    L.nddm_alpha_not_scaled_simulate.argtypes = [fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
+    L.nddm_explicit_boundary_simulate.argtypes = [fp, fp] + common + [fp, fp, vp]
+    L.nddm_draw_prior.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, c.c_float, fp, vp]
+    L.nddm_debug_normals.argtypes = [fp, c.c_int64, c.c_uint32, c.c_uint32, c.c_uint32, fp, vp]
+    for name in EXPORTS:
+        if name != "nddm_last_error":
+            getattr(L, name).restype = c.c_int
+
+
+# every symbol include/nddm.h declares (+ the tuning aid); tests check they all resolve
+EXPORTS = [
+    "nddm_abi_version", "nddm_last_error", "nddm_device_count", "nddm_set_device", "nddm_summary_k",
+    "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
+    "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
+    "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning",
+]
+
+
+def lib():
+    """The loaded library; raises NddmLibraryError (an ImportError) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise NddmLibraryError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            L = ctypes.CDLL(SO_PATH)
+        except OSError as e:   # e.g. libamdhip64 not found
+            raise NddmLibraryError(f"cannot load {SO_PATH}: {e}") from e
+        _declare(L)
+        if L.nddm_abi_version() != ABI_VERSION:
+            raise NddmLibraryError(f"ABI mismatch: library {L.nddm_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Map an nddm_status to the reference's exception convention (ValueError for bad input)."""
+    if rc == NDDM_OK:
+        return
+    msg = lib().nddm_last_error().decode() or f"nddm status {rc}"
+    if rc in (NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

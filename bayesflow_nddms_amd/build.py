@@ -1,0 +1,45 @@
+"""Build the HIP library in-tree: bayesflow_nddms_amd/libnddm_hip.so (gfx950 only).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the built .so
+travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libnddm_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "nddm_kernels.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "nddm_rng.h"),
+           os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
+# -ffp-contract=off: the exact Gaussian transform spells out every fma; contraction would change roundings
+HIPCC_FLAGS = ["-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build_hip(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into libnddm_hip.so; returns the path."""
+    if not force and not is_stale():
+        return SO_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", SO_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

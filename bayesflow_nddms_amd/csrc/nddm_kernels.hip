@@ -1,0 +1,606 @@
+// nddm_kernels.hip -- Euler-Maruyama DDM trial simulators for MI355X (gfx950), and their C ABI.
+//
+// Replaces, behind include/nddm.h, the numba/NumPy simulators of the reference:
+//   basic_ddm_dc.py:85-125, single_trial_alpha_not_scaled.py:107-155 (+ :926-974, :1237-1285,
+//   :1471-1519, :1710-1722), imputation_from_stahl_not_scaled.py:120-148, and the
+//   alpha_not_scaled.py:52-128 generator recast as an Euler-Maruyama process.
+//
+// Execution design:
+//   * one 64-lane wavefront per workgroup; a wavefront owns a CHUNK of consecutive parameter
+//     sets whose raw parameters it stages in LDS once.
+//   * one lane = one trial at a time.  Trial length is heavy-tailed (median 107, p99 2243
+//     steps at dt=.001), so lanes are PERSISTENT: a lane whose trial has ended retires it and
+//     takes the next unassigned (set, trial) of the chunk in order (wave ballot + prefix
+//     count), instead of idling until the slowest trial of its set ends.
+//   * results are staged in an LDS ring of per-set slots as packed (step index | choice);
+//     when the last trial of a set retires the wave FLUSHES the slot: one coalesced float2
+//     store sweep to HBM plus the fused per-set summary reduction (integer sums reduced
+//     across the wave with shuffles, so summaries are bit-reproducible).
+//   * the Gaussian stream is counter-based (nddm_rng.h): no RNG state is loaded or stored.
+//
+// The path is VALU/transcendental-bound: 8 B are written per trial for ~246 Gaussian draws.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nddm.h"
+#include "nddm_rng.h"
+
+namespace nddm {
+
+constexpr int WAVE = 64;
+constexpr int MAX_REJECT = 64;   // cap of the per-trial latent's rejection loop (P(reject) <= 1/2 per draw)
+
+template <int MODEL> struct ModelTraits;
+template <> struct ModelTraits<NDDM_BASIC_DDM_DC>      { static constexpr int P = 5; static constexpr bool HAS_Z = false; static constexpr int TAU = 3; };
+template <> struct ModelTraits<NDDM_SINGLE_TRIAL>      { static constexpr int P = 8; static constexpr bool HAS_Z = true;  static constexpr int TAU = 3; };
+template <> struct ModelTraits<NDDM_SINGLE_TRIAL_ALT>  { static constexpr int P = 8; static constexpr bool HAS_Z = true;  static constexpr int TAU = 3; };
+template <> struct ModelTraits<NDDM_ALPHA_NOT_SCALED>  { static constexpr int P = 6; static constexpr bool HAS_Z = false; static constexpr int TAU = 3; };
+template <> struct ModelTraits<NDDM_EXPLICIT_BOUNDARY> { static constexpr int P = 4; static constexpr bool HAS_Z = true;  static constexpr int TAU = 2; };
+
+struct SimArgs {
+    const float *params;      // [B, P]
+    const float *bounds;      // [B, N] (explicit-boundary model) or null
+    float *out_trials;        // [B, N, 2] or null
+    float *out_summary;       // [B, K] or null
+    float *out_ext;           // [B] or null
+    long long B;
+    unsigned long long set_offset;
+    int n_trials;
+    int max_k;
+    float dt;
+    float sqrt_dt;
+    uint32_t k0, k1;
+    int sets_per_chunk;
+    int ring;                 // LDS ring slots (power of two)
+    float ext_sigma;
+    int ext_mode;
+    int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
+    int max_blocks;           // ... or after this many Philox blocks (4 steps each)
+};
+
+// auxiliary normal `a` of (set, trial): stream 1
+template <bool FAST>
+struct AuxStream {
+    uint32_t k0, k1, trial, set_lo, c3, blk;
+    float z[4];
+    __device__ __forceinline__ AuxStream(uint32_t k0_, uint32_t k1_, uint64_t set, uint32_t trial_)
+        : k0(k0_), k1(k1_), trial(trial_), set_lo((uint32_t)set),
+          c3(((uint32_t)(set >> 32) & 0x0fffffffu) | 0x10000000u), blk(0xffffffffu) {}
+    __device__ __forceinline__ float normal(uint32_t a)
+    {
+        const uint32_t b = a >> 2;
+        if (b != blk) { normals4<FAST>(b, trial, set_lo, c3, k0, k1, z); blk = b; }
+        const uint32_t j = a & 3u;
+        return j == 0 ? z[0] : (j == 1 ? z[1] : (j == 2 ? z[2] : z[3]));
+    }
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The fused epilogue of one parameter set: coalesced (col0, col1) stores + summary reduction.
+template <int MODEL, bool FAST>
+__device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long set_in_call, const float *pp,
+                                          const uint32_t *res, const float *zres)
+{
+    using T = ModelTraits<MODEL>;
+    const int N = A.n_trials;
+    const float tau = pp[T::TAU];
+    int n_up = 0, n_lo = 0, n_miss = 0;
+    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
+    long long sz = 0, szz = 0;
+    float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set_in_call * N : nullptr;
+    for (int j = lane; j < N; j += WAVE) {
+        const uint32_t v = res[j];
+        const uint32_t k = v & 0x3fffffffu;
+        const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
+        const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
+        const float rt = __builtin_fmaf((float)k, A.dt, tau);
+        float zval = 0.0f;
+        if constexpr (T::HAS_Z) zval = zres[j];
+        float2 o;
+        if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
+        else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
+        else { o.x = ch * rt; o.y = zval; }
+        if (code == 3u) o.x = __builtin_nanf("");
+        if (out) out[j] = o;
+        if (A.out_summary) {
+            const unsigned long long kk = (unsigned long long)k * k;
+            if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
+            else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
+            else n_miss++;
+            if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
+                double zd = (double)zval;
+                zd = zd > 1.0e6 ? 1.0e6 : zd;
+                zd = zd < -1.0e6 ? -1.0e6 : zd;
+                sz += (long long)(zd * 4294967296.0);
+                szz += (long long)((zd * zd) * 16777216.0);
+            }
+        }
+    }
+    if (A.out_summary) {
+        n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
+        sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
+        if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
+            sz = (long long)wave_sum((unsigned long long)sz);
+            szz = (long long)wave_sum((unsigned long long)szz);
+        }
+        if (lane == 0) {
+            float *o = A.out_summary + set_in_call * NDDM_SUMMARY_K;
+            const double dtd = (double)A.dt, taud = (double)tau;
+            const double n_resp = (double)(n_up + n_lo);
+            o[0] = (float)n_up; o[1] = (float)n_lo; o[2] = (float)n_miss;
+            if (n_resp > 0) {
+                const double mk = (double)sk / n_resp;
+                const double vk = (double)sk2 / n_resp - mk * mk;
+                o[3] = (float)(taud + dtd * mk);
+                o[4] = (float)(dtd * dtd * vk);
+            } else { o[3] = __builtin_nanf(""); o[4] = __builtin_nanf(""); }
+            if (n_up > 0) {
+                const double nu = (double)n_up;
+                const double mk = (double)sk_up / nu;
+                const double vk = (double)sk2_up / nu - mk * mk;
+                o[5] = (float)(taud + dtd * mk);
+                o[6] = (float)(dtd * dtd * vk);
+            } else { o[5] = __builtin_nanf(""); o[6] = __builtin_nanf(""); }
+            const double Nd = (double)N;
+            const double mz = ((double)sz / 4294967296.0) / Nd;
+            const double vz = ((double)szz / 16777216.0) / Nd - mz * mz;
+            o[7] = (float)mz;
+            o[8] = (float)vz;
+            o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
+        }
+    }
+    if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
+        if (A.out_ext && lane == 0) {
+            AuxStream<FAST> aux(A.k0, A.k1, A.set_offset + (unsigned long long)set_in_call, 0xffffffffu);
+            const float loc = (A.ext_mode == 0) ? pp[1] : 1.0f;
+            A.out_ext[set_in_call] = __builtin_fmaf(A.ext_sigma, aux.normal(0), loc);
+        }
+    }
+}
+
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
+{
+    using T = ModelTraits<MODEL>;
+    constexpr int P = T::P;
+    extern __shared__ uint32_t lds_raw[];
+
+    const int lane = threadIdx.x;
+    const int N = A.n_trials;
+    const long long set0 = (long long)blockIdx.x * A.sets_per_chunk;      // first set of this wave's chunk (in-call index)
+    const long long rem_sets = A.B - set0;
+    const int nsets = (int)(rem_sets < A.sets_per_chunk ? rem_sets : A.sets_per_chunk);
+    const uint32_t G = (uint32_t)nsets * (uint32_t)N;                    // trials of the chunk
+    const int ring = A.ring, ring_mask = A.ring - 1;
+
+    // LDS carve-up: raw parameter rows | per-slot retire counters | packed results | z column
+    float *lp = reinterpret_cast<float *>(lds_raw);
+    int *cnt = reinterpret_cast<int *>(lp + A.sets_per_chunk * P);
+    uint32_t *res = reinterpret_cast<uint32_t *>(cnt + ring);
+    float *zres = reinterpret_cast<float *>(res + (size_t)ring * N);
+
+    for (int i = lane; i < nsets * P; i += WAVE) lp[i] = A.params[set0 * P + i];
+    for (int i = lane; i < ring; i += WAVE) cnt[i] = 0;
+    __syncthreads();
+
+    // per-lane trial state
+    float x = 0.0f, a = 0.0f, mu_dt = 0.0f, sig = 0.0f, zout = 0.0f;
+    int k = 0;
+    uint32_t trial = 0, tile = 0, set_lo = 0, c3 = 0;
+    bool has = false, active = false, invalid = false;
+
+    uint32_t next_g = 0;     // wave-uniform: next unassigned trial of the chunk
+    int flushed = 0;         // wave-uniform: sets already flushed (flushes are in order)
+
+    while (true) {
+        // ------------------------------------------------------------ retire finished trials
+        const bool fin = has && !active;
+        if (fin) {
+            const uint32_t code = invalid ? 3u : (x >= a ? 1u : (x <= 0.0f ? 2u : 0u));
+            const int slot = (int)tile & ring_mask;
+            res[(size_t)slot * N + trial] = (uint32_t)k | (code << 30);
+            if constexpr (T::HAS_Z) zres[(size_t)slot * N + trial] = zout;
+            atomicAdd(&cnt[slot], 1);
+            has = false;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ flush complete sets, in order
+        while (flushed < nsets) {
+            const int slot = flushed & ring_mask;
+            const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
+            if (c != N) break;
+            flush_set<MODEL, FAST>(A, lane, set0 + flushed, lp + flushed * P, res + (size_t)slot * N,
+                                   zres + (size_t)slot * N);
+            __syncthreads();
+            if (lane == 0) cnt[slot] = 0;
+            flushed++;
+        }
+        if (flushed == nsets) break;
+        __syncthreads();
+        // ------------------------------------------------------------ hand out new trials
+        {
+            const unsigned long long want_mask = __ballot(!has);
+            const uint32_t g = next_g + lane_rank(want_mask);
+            const uint32_t tl = g / (uint32_t)N;
+            const bool ok = !has && g < G && (int)tl < flushed + ring;
+            const unsigned long long ok_mask = __ballot(ok);
+            next_g += (uint32_t)__popcll(ok_mask);
+            if (ok) {
+                tile = tl;
+                trial = g - tl * (uint32_t)N;
+                const float *pp = lp + tl * P;
+                const unsigned long long gset = A.set_offset + (unsigned long long)(set0 + tl);
+                set_lo = (uint32_t)gset;
+                c3 = (uint32_t)(gset >> 32) & 0x0fffffffu;
+                float drift, beta, sig_c;
+                invalid = false;
+                zout = 0.0f;
+                if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
+                    drift = pp[0]; a = pp[1]; beta = pp[2]; sig_c = pp[4];
+                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
+                    drift = pp[0]; beta = pp[2]; sig_c = pp[5];
+                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    uint32_t ai = 1;
+                    do { a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]); ai++; } while (!(a > 0.0f) && ai <= MAX_REJECT);
+                    if (!(a > 0.0f)) a = fabsf(a);
+                    zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * a);
+                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
+                    drift = pp[0]; a = pp[1]; beta = pp[2];
+                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    uint32_t ai = 1;
+                    do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
+                    if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
+                    zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
+                } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
+                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    drift = __builtin_fmaf(pp[4], aux.normal(0), pp[0]);
+                    a = pp[1]; beta = pp[2]; sig_c = pp[5];
+                } else {   // NDDM_EXPLICIT_BOUNDARY
+                    drift = pp[0]; beta = pp[1]; sig_c = pp[3];
+                    a = A.bounds[(set0 + tl) * N + trial];
+                    zout = a;
+                    invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
+                }
+                mu_dt = drift * A.dt;
+                sig = A.sqrt_dt * sig_c;
+                x = a * beta;
+                k = 0;
+                has = true;
+                active = !invalid && (x > 0.0f) && (x < a) && (k < A.max_k);
+            }
+        }
+        // ------------------------------------------------------------ step phase
+        for (int it = 0; it < A.max_blocks; ++it) {
+            float z[4];
+            normals4<FAST>((uint32_t)k >> 2, trial, set_lo, c3, A.k0, A.k1, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (active) {
+                    x = x + __builtin_fmaf(sig, z[j], mu_dt);
+                    k++;
+                    active = (x > 0.0f) && (x < a) && (k < A.max_k);
+                }
+            }
+            const unsigned long long act_mask = __ballot(active);
+            const unsigned long long fin_mask = __ballot(has && !active);
+            if (act_mask == 0ull || __popcll(fin_mask) >= A.refill_thresh) break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// debugging kernel for the parity tests: 4 normals per counter
+template <bool FAST>
+__global__ void debug_normals_kernel(const uint32_t *ctr, long long n, uint32_t k0, uint32_t k1, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float z[4];
+    normals4<FAST>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, z);
+    out[4 * i] = z[0]; out[4 * i + 1] = z[1]; out[4 * i + 2] = z[2]; out[4 * i + 3] = z[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-device draw_prior(): basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 (+ _alt :889-913,
+// _scale :1205-1232 share the marginals).  Stream 2 of the row; one thread per row.
+struct PriorStream {
+    uint32_t k0, k1, row_lo, c3, draw;
+    float z[4];
+    uint32_t u[4];
+    int nz, nu;
+    __device__ PriorStream(uint32_t k0_, uint32_t k1_, uint64_t row)
+        : k0(k0_), k1(k1_), row_lo((uint32_t)row), c3(((uint32_t)(row >> 32) & 0x0fffffffu) | 0x20000000u),
+          draw(0), nz(0), nu(0) {}
+    __device__ float normal()
+    {
+        if (nz == 0) { normals4<false>(draw++, 0u, row_lo, c3, k0, k1, z); nz = 4; }
+        const int j = 4 - nz; nz--;
+        return j == 0 ? z[0] : (j == 1 ? z[1] : (j == 2 ? z[2] : z[3]));
+    }
+    __device__ float uniform()
+    {
+        if (nu == 0) { const u32x4 x = philox4x32_10(draw++, 1u, row_lo, c3, k0, k1); u[0] = x.x; u[1] = x.y; u[2] = x.z; u[3] = x.w; nu = 4; }
+        const int j = 4 - nu; nu--;
+        return uniform01(j == 0 ? u[0] : (j == 1 ? u[1] : (j == 2 ? u[2] : u[3])));
+    }
+    // N(mean, sd) truncated to [low, upp] by rejection (truncnorm_better, basic_ddm_dc.py:55-57)
+    __device__ float truncnorm(float mean, float sd, float low, float upp)
+    {
+        float v = mean;
+        for (int i = 0; i < 256; ++i) {
+            v = __builtin_fmaf(sd, normal(), mean);
+            if (v >= low && v <= upp) break;
+        }
+        return fminf(fmaxf(v, low), upp);
+    }
+    // Beta(2,2) = the median of three uniforms (order statistic U_(2:3))
+    __device__ float beta22()
+    {
+        const float a = uniform(), b = uniform(), c = uniform();
+        return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+    }
+};
+
+__global__ void prior_kernel(int model, long long B, uint32_t k0, uint32_t k1, unsigned long long set_offset,
+                             float gamma, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    PriorStream s(k0, k1, set_offset + (unsigned long long)i);
+    if (model == NDDM_BASIC_DDM_DC) {
+        float *o = out + i * 5;
+        o[0] = 2.0f * s.normal();                       // drift ~ N(0, 2)          basic_ddm_dc.py:65
+        o[1] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // alpha ~ TN(1,.5; 0,10)    :68
+        o[2] = s.beta22();                              // beta ~ Beta(2,2)          :71
+        o[3] = s.truncnorm(0.5f, 0.25f, 0.0f, 1.5f);    // ter ~ TN(.5,.25; 0,1.5)   :74
+        o[4] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // dc ~ TN(1,.5; 0,10)       :77
+    } else {   // single-trial family: same marginals for base / _alt / _scale
+        float *o = out + i * 8;
+        o[0] = 2.0f * s.normal();                       // single_trial_alpha_not_scaled.py:81
+        o[1] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // mu_alpha                  :84
+        o[2] = s.beta22();                              //                           :87
+        o[3] = s.truncnorm(0.5f, 0.25f, 0.0f, 1.5f);    //                           :90
+        o[4] = s.truncnorm(1.0f, 0.5f, 0.0f, 3.0f);     // std_alpha ~ TN(1,.5; 0,3) :93
+        o[5] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // dc                        :96
+        o[6] = 5.0f * s.uniform();                      // sigma1 ~ U(0,5)           :99
+        o[7] = gamma >= 0.0f ? gamma : 2.0f * s.uniform();   // gamma ~ U(0,2) (:1229) when gamma < 0 is passed
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+
+static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <int MODEL>
+static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, hipStream_t st)
+{
+    if (fast) hipLaunchKernelGGL((sim_kernel<MODEL, true>), dim3(n_chunks), dim3(WAVE), lds_bytes, st, A);
+    else      hipLaunchKernelGGL((sim_kernel<MODEL, false>), dim3(n_chunks), dim3(WAVE), lds_bytes, st, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return NDDM_OK;
+}
+
+struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks; };
+static Tuning g_tuning = {0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+
+static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
+                    int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
+                    int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream)
+{
+    g_err[0] = 0;
+    int P;
+    bool has_z;
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: P = 5; has_z = false; break;
+    case NDDM_SINGLE_TRIAL: P = 8; has_z = true; break;
+    case NDDM_SINGLE_TRIAL_ALT: P = 8; has_z = true; break;
+    case NDDM_ALPHA_NOT_SCALED: P = 6; has_z = false; break;
+    case NDDM_EXPLICIT_BOUNDARY: P = 4; has_z = true; break;
+    default: return fail(NDDM_ERR_PARAM, "unknown model%s");
+    }
+    if (B < 0 || n_trials <= 0 || max_steps < 0) return fail(NDDM_ERR_SHAPE, "B < 0, n_trials <= 0 or max_steps < 0%s");
+    if (max_steps >= (1 << 30)) return fail(NDDM_ERR_SHAPE, "max_steps must be < 2^30%s");
+    if (!(dt > 0.0f) || !isfinite(dt)) return fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
+    if (flags > 1u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
+    if (B == 0) return NDDM_OK;
+    if (!params) return fail(NDDM_ERR_NULL, "params is NULL%s");
+    if (model == NDDM_EXPLICIT_BOUNDARY && !bounds) return fail(NDDM_ERR_NULL, "bounds is NULL%s");
+    if (!out_trials && !out_summary && !out_ext) return fail(NDDM_ERR_NULL, "no output buffer given%s");
+
+    SimArgs A;
+    memset(&A, 0, sizeof A);
+    A.params = params; A.bounds = bounds; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_ext;
+    A.B = B; A.set_offset = set_offset; A.n_trials = n_trials; A.max_k = max_steps; A.dt = dt; A.sqrt_dt = sqrtf(dt);
+    A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
+    A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
+
+    // geometry: ring slots so that >= ~4 wavefronts' worth of trials can be in flight per wave window
+    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((256 + n_trials - 1) / n_trials);
+    if (ring < 4) ring = 4;
+    if (ring > 64) ring = 64;
+    const size_t per_trial = has_z ? 8 : 4;
+    while (ring > 2 && (size_t)ring * n_trials * per_trial > 40 * 1024) ring >>= 1;
+    if ((size_t)ring * n_trials * per_trial > 60 * 1024)
+        return fail(NDDM_ERR_SHAPE, "n_trials too large for one launch (LDS ring); split the call%s");
+    // chunk: enough trials per wave to amortise the tail, but many more chunks than resident waves
+    int spc = g_tuning.sets_per_chunk;
+    if (!spc) {
+        long long want = (9600 + n_trials - 1) / n_trials;          // ~150 trials per lane
+        long long cap = B / 8192 > 0 ? B / 8192 : 1;                 // keep >= 8192 chunks when B allows
+        spc = (int)(want < cap ? want : cap);
+        if (spc < 1) spc = 1;
+        if (spc > 64) spc = 64;
+    }
+    if ((long long)spc * n_trials >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "chunk too large%s");
+    A.sets_per_chunk = spc; A.ring = ring;
+    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : 8;
+    A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
+    const long long n_chunks = (B + spc - 1) / spc;
+    if (n_chunks > 0x7fffffffll) return fail(NDDM_ERR_SHAPE, "too many chunks for one launch%s");
+    const size_t lds = (size_t)spc * P * 4 + (size_t)ring * 4 + (size_t)ring * n_trials * per_trial;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: return launch_model<NDDM_BASIC_DDM_DC>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_SINGLE_TRIAL: return launch_model<NDDM_SINGLE_TRIAL>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_SINGLE_TRIAL_ALT: return launch_model<NDDM_SINGLE_TRIAL_ALT>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_ALPHA_NOT_SCALED: return launch_model<NDDM_ALPHA_NOT_SCALED>(A, fast, lds, (int)n_chunks, st);
+    default: return launch_model<NDDM_EXPLICIT_BOUNDARY>(A, fast, lds, (int)n_chunks, st);
+    }
+}
+
+}  // namespace nddm
+
+// ================================================================================================
+extern "C" {
+
+int nddm_abi_version(void) { return NDDM_ABI_VERSION; }
+const char *nddm_last_error(void) { return nddm::g_err; }
+int nddm_summary_k(void) { return NDDM_SUMMARY_K; }
+
+int nddm_model_nparams(int model)
+{
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: return 5;
+    case NDDM_SINGLE_TRIAL: return 8;
+    case NDDM_SINGLE_TRIAL_ALT: return 8;
+    case NDDM_ALPHA_NOT_SCALED: return 6;
+    case NDDM_EXPLICIT_BOUNDARY: return 4;
+    }
+    return -1;
+}
+
+int nddm_device_count(int *count)
+{
+    if (!count) return nddm::fail(NDDM_ERR_NULL, "count is NULL%s");
+    const hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return nddm::fail(NDDM_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return NDDM_OK;
+}
+
+int nddm_set_device(int device)
+{
+    const hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return nddm::fail(NDDM_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return NDDM_OK;
+}
+
+/* benchmarking aid (not part of the drop-in surface): 0 = automatic */
+int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks)
+{
+    if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
+    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks};
+    return NDDM_OK;
+}
+
+int nddm_basic_ddm_dc_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                               uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                               float *out_summary, void *stream)
+{
+    return nddm::simulate(NDDM_BASIC_DDM_DC, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, flags,
+                          0.0f, 0, out_trials, out_summary, nullptr, stream);
+}
+
+int nddm_single_trial_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                               uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                               float *out_summary, void *stream)
+{
+    return nddm::simulate(NDDM_SINGLE_TRIAL, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, flags,
+                          0.0f, 0, out_trials, out_summary, nullptr, stream);
+}
+
+int nddm_single_trial_alt_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                                   uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                                   float *out_summary, void *stream)
+{
+    return nddm::simulate(NDDM_SINGLE_TRIAL_ALT, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset,
+                          flags, 0.0f, 0, out_trials, out_summary, nullptr, stream);
+}
+
+int nddm_alpha_not_scaled_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                                   uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
+                                   int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
+                                   void *stream)
+{
+    return nddm::simulate(NDDM_ALPHA_NOT_SCALED, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset,
+                          flags, ext_sigma, ext_mode, out_trials, out_summary, out_extdata, stream);
+}
+
+int nddm_explicit_boundary_simulate(const float *params, const float *bounds, int64_t B, int32_t n_trials,
+                                    float dt, int32_t max_steps, uint64_t seed, uint64_t set_offset,
+                                    uint32_t flags, float *out_trials, float *out_summary, void *stream)
+{
+    return nddm::simulate(NDDM_EXPLICIT_BOUNDARY, params, bounds, B, n_trials, dt, max_steps, seed, set_offset,
+                          flags, 0.0f, 0, out_trials, out_summary, nullptr, stream);
+}
+
+int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
+                    void *stream)
+{
+    nddm::g_err[0] = 0;
+    if (model != NDDM_BASIC_DDM_DC && model != NDDM_SINGLE_TRIAL && model != NDDM_SINGLE_TRIAL_ALT)
+        return nddm::fail(NDDM_ERR_PARAM, "draw_prior: model has no reference prior%s");
+    if (B < 0) return nddm::fail(NDDM_ERR_SHAPE, "B < 0%s");
+    if (B == 0) return NDDM_OK;
+    if (!out_params) return nddm::fail(NDDM_ERR_NULL, "out_params is NULL%s");
+    const int threads = 256;
+    const long long blocks = (B + threads - 1) / threads;
+    hipLaunchKernelGGL(nddm::prior_kernel, dim3((unsigned)blocks), dim3(threads), 0,
+                       reinterpret_cast<hipStream_t>(stream), (int)model, (long long)B, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (unsigned long long)set_offset, gamma, out_params);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nddm::fail(NDDM_ERR_HIP, "prior kernel launch failed: %s", hipGetErrorString(e));
+    return NDDM_OK;
+}
+
+int nddm_debug_normals(const uint32_t *counters, int64_t n, uint32_t k0, uint32_t k1, uint32_t flags, float *out,
+                       void *stream)
+{
+    nddm::g_err[0] = 0;
+    if (n < 0) return nddm::fail(NDDM_ERR_SHAPE, "n < 0%s");
+    if (n == 0) return NDDM_OK;
+    if (!counters || !out) return nddm::fail(NDDM_ERR_NULL, "null pointer%s");
+    const int threads = 256;
+    const long long blocks = (n + threads - 1) / threads;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & NDDM_GAUSS_FAST)
+        hipLaunchKernelGGL(nddm::debug_normals_kernel<true>, dim3((unsigned)blocks), dim3(threads), 0, st, counters,
+                           (long long)n, k0, k1, out);
+    else
+        hipLaunchKernelGGL(nddm::debug_normals_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0, st, counters,
+                           (long long)n, k0, k1, out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nddm::fail(NDDM_ERR_HIP, "debug kernel launch failed: %s", hipGetErrorString(e));
+    return NDDM_OK;
+}
+
+}  // extern "C"

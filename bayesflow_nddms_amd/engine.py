@@ -1,0 +1,220 @@
+"""Batched device entry of the DDM trial simulators: Python adapter over the C ABI (include/nddm.h).
+
+PyTorch is plumbing here (device memory and streams); all arithmetic happens in the HIP kernels.
+There is no CPU path: calls raise if no ROCm device / HIP library is available.
+"""
+import math
+import threading
+
+import numpy as np
+
+from . import _lib
+
+BASIC_DDM_DC, SINGLE_TRIAL, SINGLE_TRIAL_ALT, ALPHA_NOT_SCALED, EXPLICIT_BOUNDARY = range(5)
+SUMMARY_K = 10
+SUMMARY_COLS = ("n_upper", "n_lower", "n_missing", "mean_rt", "var_rt", "mean_rt_upper", "var_rt_upper",
+                "mean_z", "var_z", "choice_mean")
+NPARAMS = {BASIC_DDM_DC: 5, SINGLE_TRIAL: 8, SINGLE_TRIAL_ALT: 8, ALPHA_NOT_SCALED: 6, EXPLICIT_BOUNDARY: 4}
+# columns that must be > 0 for the process to be defined (boundary / diffusion coefficient), per model
+_POSITIVE_COLS = {BASIC_DDM_DC: (1, 4), SINGLE_TRIAL: (5,), SINGLE_TRIAL_ALT: (1,), ALPHA_NOT_SCALED: (1, 5),
+                  EXPLICIT_BOUNDARY: (3,)}
+
+# default Gaussian transform of the product path; tests pin the exact one against the oracle bit for bit
+DEFAULT_FAST = True
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_device():
+    """Fail loudly when the HIP path cannot run (no silent CPU fallback)."""
+    torch = _torch()
+    _lib.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("bayesflow_nddms_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    return torch
+
+
+class StreamState:
+    """Functional RNG position: (seed, next set index).  The simulators are stateless apart from this pair, so a
+    resumed run continues the stream by restoring it (checkpoint/resume)."""
+
+    def __init__(self, seed=0, offset=0):
+        self._lock = threading.Lock()
+        self.seed = int(seed)
+        self.offset = int(offset)
+
+    def take(self, n_sets):
+        with self._lock:
+            off = self.offset
+            self.offset += int(n_sets)
+            return self.seed, off
+
+    def get_state(self):
+        return {"seed": self.seed, "offset": self.offset}
+
+    def set_state(self, state):
+        with self._lock:
+            self.seed, self.offset = int(state["seed"]), int(state["offset"])
+
+
+GLOBAL_STREAM = StreamState(seed=0)
+
+
+def seed(s):
+    """Reset the package-level stream (the analogue of np.random.seed for the device simulators)."""
+    GLOBAL_STREAM.set_state({"seed": int(s), "offset": 0})
+
+
+def max_k_of(max_steps):
+    """The reference loops `while ... n_steps < max_steps` with a float cap (basic_ddm_dc.py:87, 95): the largest
+    step count reached is ceil(max_steps)."""
+    return int(math.ceil(float(max_steps)))
+
+
+def validate_params_host(model, params):
+    """Host-side validation (only possible when parameters arrive on the host): the reference's error
+    convention is ValueError (imputation_from_stahl_not_scaled.py:124-125)."""
+    p = np.asarray(params)
+    if not np.all(np.isfinite(p)):
+        raise ValueError("parameters must be finite")
+    for c in _POSITIVE_COLS[model]:
+        if np.any(p[..., c] <= 0):
+            raise ValueError(f"parameter column {c} (boundary / diffusion coefficient) must be > 0")
+    if model in (SINGLE_TRIAL, SINGLE_TRIAL_ALT):
+        lat = p[..., 1] if model == SINGLE_TRIAL else p[..., 5]
+        if np.any(lat + 8.0 * np.abs(p[..., 4]) <= 0):
+            raise ValueError("per-trial latent N(mean, std) > 0 is (numerically) never satisfied")
+
+
+def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
+             bounds=None, ext_sigma=0.0, ext_mode=0, want_trials=True, want_summary=True, want_ext=False,
+             out_trials=None, out_summary=None, stream_state=None, device=None):
+    """Run one batched simulation on the current ROCm device.
+
+    params: array-like or torch tensor [B, P] (or [P]) in the reference's parameter order.
+    Returns a dict of torch tensors on the device: 'trials' f32 [B, n_trials, 2], 'summary' f32 [B, 10],
+    'ext' f32 [B] (alpha_not_scaled only), plus 'seed' / 'set_offset' actually used.
+    """
+    torch = require_device()
+    L = _lib.lib()
+    P = NPARAMS[model]
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    on_host = not (isinstance(params, torch.Tensor) and params.is_cuda)
+    if on_host:
+        p_np = np.ascontiguousarray(params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else params,
+                                    dtype=np.float64)
+        if p_np.ndim == 1:
+            p_np = p_np[None]
+        if p_np.ndim != 2 or p_np.shape[1] != P:
+            raise ValueError(f"params must have shape [B, {P}] for this model, got {p_np.shape}")
+        validate_params_host(model, p_np)
+        p_dev = torch.as_tensor(p_np, dtype=torch.float32).contiguous().to(dev)
+    else:
+        p_dev = params
+        if p_dev.ndim == 1:
+            p_dev = p_dev[None]
+        if p_dev.ndim != 2 or p_dev.shape[1] != P:
+            raise ValueError(f"params must have shape [B, {P}] for this model, got {tuple(p_dev.shape)}")
+        p_dev = p_dev.to(dtype=torch.float32).contiguous()
+    B = int(p_dev.shape[0])
+    n_trials = int(n_trials)
+    if n_trials <= 0:
+        raise ValueError("n_trials must be positive")
+    if not (dt > 0 and math.isfinite(dt)):
+        raise ValueError("dt must be finite and > 0")
+    max_k = max_k_of(max_steps)
+    if max_k < 0:
+        raise ValueError("max_steps must be >= 0")
+
+    b_dev = None
+    if model == EXPLICIT_BOUNDARY:
+        if bounds is None:
+            raise ValueError("explicit-boundary model needs `bounds`")
+        if not (isinstance(bounds, torch.Tensor) and bounds.is_cuda):
+            b_np = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(B, n_trials))
+            if np.any(b_np < 0) or not np.all(np.isfinite(b_np)):
+                raise ValueError("Trial-level boundary cannot be less than zero")
+            b_dev = torch.as_tensor(b_np, dtype=torch.float32).contiguous().to(dev)
+        else:
+            b_dev = bounds.to(dtype=torch.float32).reshape(B, n_trials).contiguous()
+
+    if seed is None or set_offset is None:
+        s_seed, s_off = (stream_state or GLOBAL_STREAM).take(B)
+        seed = s_seed if seed is None else seed
+        set_offset = s_off if set_offset is None else set_offset
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    set_offset = int(set_offset) & 0xFFFFFFFFFFFFFFFF
+    fast = DEFAULT_FAST if fast is None else bool(fast)
+    flags = _lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT
+
+    with torch.cuda.device(dev):
+        if want_trials and out_trials is None:
+            out_trials = torch.empty((B, n_trials, 2), dtype=torch.float32, device=dev)
+        if want_summary and out_summary is None:
+            out_summary = torch.empty((B, SUMMARY_K), dtype=torch.float32, device=dev)
+        out_ext = torch.empty((B,), dtype=torch.float32, device=dev) if (want_ext and model == ALPHA_NOT_SCALED) else None
+        for t, shape in ((out_trials, (B, n_trials, 2)), (out_summary, (B, SUMMARY_K))):
+            if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous()
+                                  or not t.is_cuda):
+                raise ValueError(f"output buffer must be a contiguous float32 device tensor of shape {shape}")
+        st = torch.cuda.current_stream(dev).cuda_stream
+        pt = lambda t: None if t is None else t.data_ptr()
+        if B > 0:
+            common = (B, n_trials, float(dt), max_k, seed, set_offset, flags)
+            if model == BASIC_DDM_DC:
+                rc = L.nddm_basic_ddm_dc_simulate(pt(p_dev), *common, pt(out_trials), pt(out_summary), st)
+            elif model == SINGLE_TRIAL:
+                rc = L.nddm_single_trial_simulate(pt(p_dev), *common, pt(out_trials), pt(out_summary), st)
+            elif model == SINGLE_TRIAL_ALT:
+                rc = L.nddm_single_trial_alt_simulate(pt(p_dev), *common, pt(out_trials), pt(out_summary), st)
+            elif model == ALPHA_NOT_SCALED:
+                rc = L.nddm_alpha_not_scaled_simulate(pt(p_dev), *common, float(ext_sigma), int(ext_mode),
+                                                      pt(out_trials), pt(out_summary), pt(out_ext), st)
+            elif model == EXPLICIT_BOUNDARY:
+                rc = L.nddm_explicit_boundary_simulate(pt(p_dev), pt(b_dev), *common, pt(out_trials),
+                                                       pt(out_summary), st)
+            else:
+                raise ValueError("unknown model")
+            _lib.check(rc)
+            # the kernel reads p_dev / b_dev asynchronously: tie their lifetime to the stream
+            p_dev.record_stream(torch.cuda.current_stream(dev))
+            if b_dev is not None:
+                b_dev.record_stream(torch.cuda.current_stream(dev))
+    res = {"seed": seed, "set_offset": set_offset, "params": p_dev}
+    if out_trials is not None:
+        res["trials"] = out_trials
+    if out_summary is not None:
+        res["summary"] = out_summary
+    if out_ext is not None:
+        res["ext"] = out_ext
+    return res
+
+
+def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device=None):
+    """On-device batched draw_prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102): f32 [B, P]."""
+    torch = require_device()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    P = NPARAMS[model]
+    with torch.cuda.device(dev):
+        out = torch.empty((int(batch_size), P), dtype=torch.float32, device=dev)
+        rc = _lib.lib().nddm_draw_prior(model, int(batch_size), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                        int(set_offset) & 0xFFFFFFFFFFFFFFFF, float(gamma), out.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc)
+    return out
+
+
+def debug_normals(counters, k0, k1, fast=False):
+    """4 normals per Philox counter row (tests compare these with the oracle's)."""
+    torch = require_device()
+    c = torch.as_tensor(np.asarray(counters, dtype=np.uint32).view(np.int32)).cuda().contiguous()
+    n = c.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=c.device)
+    rc = _lib.lib().nddm_debug_normals(c.data_ptr(), n, int(k0), int(k1), 1 if fast else 0, out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc)
+    return out.cpu().numpy()

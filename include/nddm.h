@@ -1,0 +1,147 @@
+/*
+ * nddm.h -- C ABI of libnddm_hip.so: the MI355X (gfx950) Euler-Maruyama drift-diffusion
+ * trial simulators that replace the numba/NumPy simulators of mdnunez/bayesflow_nddms.
+ *
+ * Each entry point is what a ctypes (or cffi / cgo / JNI) binding for the reference's
+ * simulator path would bind.  File:line citations are relative to the reference repo.
+ *
+ * Conventions (all entry points):
+ *   - every data pointer is a DEVICE pointer (hipMalloc / torch ROCm tensor .data_ptr());
+ *     the caller allocates and frees all buffers; the library keeps no pointer after the
+ *     call's work on `stream` has completed.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous with respect to the host: they enqueue work on `stream` and return.
+ *   - parameter rows are row-major float32 [B, P] in the REFERENCE'S parameter order.
+ *   - trial output is row-major float32 [B, n_trials, 2]; summary output float32 [B, NDDM_SUMMARY_K].
+ *     Either may be NULL (summary-only mode never writes the 8 bytes per trial).
+ *   - randomness is a pure function of (seed, set_offset + row, trial, draw): output does not
+ *     depend on launch geometry, on how rows are sharded over GPUs, or on call order.
+ *   - timeouts are data (choice 0 / choicert 0), never errors.
+ *   - return value: NDDM_OK or an nddm_status; nddm_last_error() gives thread-local text.
+ *   - re-entrant and thread-safe given distinct output buffers.
+ */
+#ifndef NDDM_H
+#define NDDM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDDM_ABI_VERSION 1
+#define NDDM_SUMMARY_K 10
+
+/* summary_stats[b, :] (single_trial_alpha_not_scaled.py:205-211,
+ * simulations/mean_RT_accuracy_effects.py:88-90, simulations/Basic_DDM_simulations.py:137-145) */
+enum nddm_summary_col {
+    NDDM_S_N_UPPER = 0,       /* trials that hit the upper boundary (choice  1) */
+    NDDM_S_N_LOWER = 1,       /* trials that hit the lower boundary (choice -1) */
+    NDDM_S_N_MISSING = 2,     /* trials that reached max_steps (choice 0) */
+    NDDM_S_MEAN_RT = 3,       /* mean RT (incl. non-decision time) of responded trials; NaN if none */
+    NDDM_S_VAR_RT = 4,        /* population variance (ddof=0) of the same */
+    NDDM_S_MEAN_RT_UPPER = 5, /* EZ-diffusion MRT: mean RT of upper-boundary trials; NaN if none */
+    NDDM_S_VAR_RT_UPPER = 6,  /* EZ-diffusion VRT */
+    NDDM_S_MEAN_Z = 7,        /* mean external datum z1 over all trials (0 for models without z1) */
+    NDDM_S_VAR_Z = 8,         /* population variance of z1 */
+    NDDM_S_CHOICE_MEAN = 9    /* mean(.5 + .5*sign(choicert)) over all trials */
+};
+
+enum nddm_model {
+    NDDM_BASIC_DDM_DC = 0,     /* basic_ddm_dc.py:85-125; P=5: drift, boundary, beta, tau, dc */
+    NDDM_SINGLE_TRIAL = 1,     /* single_trial_alpha_not_scaled.py:107-155 (+_scale :1237-1285, _scale2 :1471-1519);
+                                  P=8: drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, gamma (gamma=1 for the base model) */
+    NDDM_SINGLE_TRIAL_ALT = 2, /* single_trial_alpha_not_scaled.py:926-974; P=8: drift, alpha, beta, ter, std_dc, mu_dc, sigma1, gamma */
+    NDDM_ALPHA_NOT_SCALED = 3, /* alpha_not_scaled.py:52-128 as an Euler-Maruyama process; P=6: Nu, Alpha, Beta, Tau, Eta, Varsigma */
+    NDDM_EXPLICIT_BOUNDARY = 4 /* imputation_from_stahl_not_scaled.py:120-148; P=4: drift, beta, ter, dc; bounds[B, n_trials] */
+};
+
+enum nddm_status {
+    NDDM_OK = 0,
+    NDDM_ERR_NULL = 1,        /* a required pointer is NULL */
+    NDDM_ERR_SHAPE = 2,       /* B < 0, n_trials <= 0, max_steps < 0, n_trials too large for one launch */
+    NDDM_ERR_PARAM = 3,       /* non-finite or non-positive dt; unknown model / flag */
+    NDDM_ERR_HIP = 4,         /* a HIP runtime call failed; text in nddm_last_error() */
+    NDDM_ERR_NO_DEVICE = 5
+};
+
+enum nddm_flags {
+    NDDM_GAUSS_EXACT = 0,     /* Box-Muller from IEEE add/mul/fma/sqrt only: bit-reproducible on a CPU (oracle) */
+    NDDM_GAUSS_FAST = 1       /* Box-Muller on v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 */
+};
+
+/* ---- library / device ------------------------------------------------------------- */
+int nddm_abi_version(void);
+const char *nddm_last_error(void);
+int nddm_device_count(int *count);
+int nddm_set_device(int device);
+int nddm_summary_k(void);
+int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
+
+/* ---- simulators --------------------------------------------------------------------
+ * Common arguments:
+ *   params      device f32 [B, P]
+ *   B           number of parameter sets (rows)
+ *   n_trials    trials per set (the batch-shared N of basic_ddm_dc.py:50-52, 131)
+ *   dt          Euler-Maruyama step (reference default .01, basic_ddm_dc.py:87; fine study .001, single_trial_alpha_not_scaled.py:1719)
+ *   max_steps   step cap (reference default 400; 4000 in the fine study)
+ *   seed        64-bit stream key
+ *   set_offset  global index of row 0 (makes shards of one logical batch reproducible)
+ *   flags       enum nddm_flags
+ *   out_trials  device f32 [B, n_trials, 2] or NULL
+ *   out_summary device f32 [B, NDDM_SUMMARY_K] or NULL
+ */
+
+/* replaces simulate_trials(params, n_trials), basic_ddm_dc.py:114-125 (batched over B sets).
+ * out_trials[b, i, :] = (rt, choice); choice in {1, -1, 0 (timeout; the reference's unbound-variable
+ * bug at basic_ddm_dc.py:110-111 is resolved to 0)}; rt = n_steps*dt + tau. */
+int nddm_basic_ddm_dc_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                               uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                               float *out_summary, void *stream);
+
+/* replaces simulate_trials / simulate_trials_fine / simulate_trials_scale / _scale2,
+ * single_trial_alpha_not_scaled.py:144-155, :1710-1722, :1274-1285, :1508-1519.
+ * out_trials[b, i, :] = (choicert, z1); choicert = +-(ter + rt) or 0; z1 ~ N(gamma*bound_trial, sigma1). */
+int nddm_single_trial_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                               uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                               float *out_summary, void *stream);
+
+/* replaces simulate_trials_alt, single_trial_alpha_not_scaled.py:963-974 (per-trial diffusion coefficient).
+ * out_trials[b, i, :] = (choicert, z1); z1 ~ N(gamma*dc_trial, sigma1). */
+int nddm_single_trial_alt_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                                   uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
+                                   float *out_summary, void *stream);
+
+/* the data generator of alpha_not_scaled.py:52-128 as an Euler-Maruyama process: per-trial drift
+ * ~ N(Nu, Eta) (pyhddmjagsutils.py:124-125), noise Varsigma, one external datum per set
+ * out_extdata[b] = (ext_mode == 0 ? Alpha[b] : 1) + ext_sigma * N(0,1)  (alpha_not_scaled.py:103-106).
+ * out_trials[b, i, :] = (y, acc): y = +-rt signed by the response (:98-100), acc = (sign(y)+1)/2 (:102).
+ * out_extdata: device f32 [B] or NULL. */
+int nddm_alpha_not_scaled_simulate(const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                                   uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
+                                   int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
+                                   void *stream);
+
+/* replaces the per-trial loop over diffusion_trial(drift, bound_trial, beta, ter, dc),
+ * imputation_from_stahl_not_scaled.py:120-148, :207-213.  bounds: device f32 [B, n_trials].
+ * out_trials[b, i, :] = (choicert, bound_trial).  A negative (or NaN) boundary is the reference's ValueError
+ * (:124-125): such a trial is written as (NaN, bound) -- validate on the host (Python adapter does) to raise. */
+int nddm_explicit_boundary_simulate(const float *params, const float *bounds, int64_t B, int32_t n_trials,
+                                    float dt, int32_t max_steps, uint64_t seed, uint64_t set_offset,
+                                    uint32_t flags, float *out_trials, float *out_summary, void *stream);
+
+/* ---- prior / context samplers (basic_ddm_dc.py:50-80, single_trial_alpha_not_scaled.py:66-102) -------
+ * On-device batched draw_prior(): out device f32 [B, P] in the model's parameter order
+ * (P = nddm_model_nparams; gamma column of the single-trial family is filled with `gamma`).
+ * Stream: Philox key (seed), counter (draw, 0, row_lo, row_hi | 2<<28). */
+int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
+                    void *stream);
+
+/* ---- debugging aid used by the parity tests: the 4 normals of Philox block (c0..c3) under key (k0,k1) --- */
+int nddm_debug_normals(const uint32_t *counters /* device u32 [n,4] */, int64_t n, uint32_t k0, uint32_t k1,
+                       uint32_t flags, float *out /* device f32 [n,4] */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDDM_H */

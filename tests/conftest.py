@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "kat.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle

@@ -1,0 +1,144 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Exact Gaussian mode is compared BIT FOR BIT (the oracle runs the identical float32 stream);
+the fast (transcendental-unit) mode is compared by per-trial agreement and by distribution."""
+import numpy as np
+import pytest
+
+import prior_util
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"basic": 0, "single": 1, "alt": 2, "alpha_ns": 3, "explicit": 4}
+
+
+def _params(model, B, seed):
+    if model == "basic":
+        return prior_util.basic_prior(B, seed)
+    if model == "single":
+        return prior_util.single_prior(B, seed, gamma=1.0)
+    if model == "alt":
+        p = prior_util.single_prior(B, seed, gamma=1.0)
+        p[:, 4] = np.minimum(p[:, 4], 1.0)   # std_dc
+        return p
+    if model == "alpha_ns":
+        return prior_util.alpha_ns_prior(B, seed)
+    p = prior_util.basic_prior(B, seed)
+    return p[:, [0, 2, 3, 4]]                 # drift, beta, ter, dc
+
+
+def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, **kw):
+    import oracle
+    from bayesflow_nddms_amd import engine
+    p = _params(model, B, 1234 + B)
+    bounds = None
+    if model == "explicit":
+        bounds = np.abs(np.random.default_rng(5).normal(1.2, 0.4, size=(B, N))).astype(np.float32)
+    want_ext = model == "alpha_ns"
+    g = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast,
+                        bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, **kw)
+    o = oracle.philox_simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset,
+                               bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, want_k=True, threads=8)
+    g = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in g.items()}
+    return p, g, o
+
+
+def test_normals_bit_exact(oracle_mod):
+    """Philox4x32-10 + exact Box-Muller: device == oracle for every bit, incl. corner counters."""
+    from bayesflow_nddms_amd import engine
+    rng = np.random.default_rng(0)
+    ctr = rng.integers(0, 2**32, size=(20000, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[:8] = [[0, 0, 0, 0], [1, 0, 0, 0], [0xffffffff] * 4, [0, 1, 2, 3], [0, 0, 0, 0x10000000],
+               [5, 0xffffffff, 7, 0x1fffffff], [123, 456, 789, 0x20000000], [2**31, 2**31, 2**31, 2**27]]
+    k0, k1 = 2023, 0xdeadbeef
+    dev = engine.debug_normals(ctr, k0, k1, fast=False)
+    ref = np.stack([oracle_mod.philox_normals4(*map(int, c), k0, k1) for c in ctr])
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    # fast transform: same stream, transcendental-unit arithmetic -> tiny absolute differences only
+    fast = engine.debug_normals(ctr, k0, k1, fast=True)
+    assert np.max(np.abs(fast - ref)) < 2e-5
+    # and it is a standard normal sample
+    assert abs(ref.mean()) < 0.02 and abs(ref.std() - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("model", list(MODELS))
+@pytest.mark.parametrize("dt,max_steps", [(0.01, 400.0), (0.001, 4000.0)])
+def test_exact_mode_bit_parity(model, dt, max_steps):
+    """Trials and fused summaries of every model equal the oracle's bit for bit."""
+    p, g, o = _run_both(model, B=96, N=300, dt=dt, max_steps=max_steps, seed=2023)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    gs, os_ = g["summary"], o["summary"]
+    assert np.array_equal(np.isnan(gs), np.isnan(os_))
+    assert np.array_equal(np.nan_to_num(gs).view(np.uint32), np.nan_to_num(os_).view(np.uint32))
+    if model == "alpha_ns":
+        assert np.array_equal(g["ext"].view(np.uint32), o["ext"].view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [1, 3, 60, 63, 64, 65, 257, 300, 1000, 3000])
+def test_ragged_trial_counts(N):
+    """n_trials not a multiple of the wave width, tiny and large (ring sizes 64 ... 2)."""
+    p, g, o = _run_both("basic", B=37, N=N, dt=0.01, max_steps=400.0, seed=7)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    p, g, o = _run_both("single", B=5, N=N, dt=0.01, max_steps=400.0, seed=8)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+
+
+def test_geometry_independence():
+    """Output is a pure function of (seed, set index, trial): chunking / ring / refill policy do not matter,
+    and shards with set_offset reproduce the unsharded batch (the multi-GPU contract)."""
+    from bayesflow_nddms_amd import _lib, engine
+    p = prior_util.basic_prior(300, 99)
+    base = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
+    try:
+        for tune in [(1, 2, 1, 1), (7, 4, 64, 3), (64, 64, 8, 16), (3, 8, 200, 2)]:
+            _lib.check(_lib.lib().nddm_set_tuning(*tune))
+            t = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
+            assert np.array_equal(t.view(np.uint32), base.view(np.uint32)), tune
+    finally:
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0)
+    parts = [engine.simulate(0, p[a:b], 180, dt=0.01, max_steps=400, seed=5, set_offset=1000 + a, fast=False)["trials"].cpu().numpy()
+             for a, b in [(0, 75), (75, 150), (150, 151), (151, 300)]]
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))
+
+
+def test_edge_cases():
+    from bayesflow_nddms_amd import engine
+    # timeouts are data: choice 0, rt = max_steps*dt + tau
+    p = np.array([[0.0, 9.0, 0.5, 0.3, 0.2]], dtype=np.float32)
+    t = engine.simulate(0, p, 64, dt=0.01, max_steps=400, seed=1, fast=False)["trials"].cpu().numpy()
+    assert np.all(t[..., 1] == 0) and np.allclose(t[..., 0], 4.3)
+    s = engine.simulate(1, np.array([[0.0, 9.0, 0.5, 0.3, 0.01, 0.2, 1.0, 1.0]]), 64, seed=1, fast=False)
+    assert np.all(s["trials"].cpu().numpy()[..., 0] == 0)
+    assert s["summary"].cpu().numpy()[0, 2] == 64 and np.isnan(s["summary"].cpu().numpy()[0, 3])
+    # max_steps = 0: no step is taken, nobody responds
+    t = engine.simulate(0, prior_util.basic_prior(4, 1), 10, max_steps=0, seed=1, fast=False)["trials"].cpu().numpy()
+    assert np.all(t[..., 1] == 0)
+    # empty batch
+    e = engine.simulate(0, np.zeros((0, 5), np.float32), 10, seed=1)
+    assert tuple(e["trials"].shape) == (0, 10, 2)
+    # bad input -> ValueError (reference convention)
+    with pytest.raises(ValueError):
+        engine.simulate(0, np.array([[1.0, -1.0, .5, .3, 1.0]]), 10)
+    with pytest.raises(ValueError):
+        engine.simulate(0, np.array([[1.0, np.nan, .5, .3, 1.0]]), 10)
+    with pytest.raises(ValueError):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 0)
+    with pytest.raises(ValueError):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, dt=-1.0)
+    with pytest.raises(ValueError):
+        engine.simulate(4, np.array([[1.0, .5, .3, 1.0]]), 4, bounds=np.array([[1.0, -0.1, 1.0, 1.0]]))
+    with pytest.raises(ValueError):
+        engine.simulate(0, np.zeros((3, 4), np.float32), 10)
+
+
+@pytest.mark.parametrize("model", ["basic", "single", "alpha_ns"])
+def test_fast_mode_agrees_with_exact(model):
+    """Same stream, hardware transcendentals: a trial can only differ when a path grazes a boundary within
+    float rounding, so nearly all (step index, choice) pairs are identical."""
+    p, g, o = _run_both(model, B=200, N=300, dt=0.001, max_steps=4000.0, seed=11, fast=True)
+    same = (g["trials"][..., 0] == o["trials"][..., 0])
+    assert same.mean() > 0.995, same.mean()
+    # summaries agree to float tolerance
+    gs, os_ = g["summary"], o["summary"]
+    assert np.allclose(np.nan_to_num(gs[:, :3]), np.nan_to_num(os_[:, :3]), atol=2)
+    assert np.allclose(np.nan_to_num(gs[:, 3]), np.nan_to_num(os_[:, 3]), rtol=0.02, atol=1e-3)
