@@ -1,0 +1,90 @@
+"""Data parallelism over parameter sets: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
+
+Parameter sets are independent (basic_ddm_dc.py:121-122 has no cross-trial state), so a batch of B sets shards
+into contiguous row blocks, one per rank, with NO collective on the simulate path: the random stream is keyed by
+the GLOBAL set index (set_offset + row), so the union of the shards is bit-identical to the unsharded batch for any
+number of GPUs.  The only exchange step is the optional all-gather that reassembles a training minibatch on every
+rank (north_star); gathering only the fused summaries (40 B/set) instead of the trials (8 B/trial) makes it ~60x
+smaller at N=300.
+"""
+import numpy as np
+
+
+def shard_bounds(n_sets, world_size, rank):
+    """Contiguous block of rows for `rank`: blocks of ceil(B/G), the last ones possibly short or empty."""
+    per = (n_sets + world_size - 1) // world_size
+    lo = min(rank * per, n_sets)
+    hi = min(lo + per, n_sets)
+    return lo, hi
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def all_gather_rows(local, n_sets, group=None):
+    """All-gather row blocks produced under shard_bounds() into the full [n_sets, ...] tensor on every rank.
+    Short blocks are padded to the common block size for the collective and trimmed afterwards."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    per = (n_sets + world - 1) // world
+    pad = per - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
+    local = local.contiguous()
+    full = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    try:
+        dist.all_gather_into_tensor(full, local, group=group)
+    except (RuntimeError, NotImplementedError):      # backends without the flat form
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        full = torch.cat(parts, dim=0)
+    return full[:n_sets]
+
+
+class ShardedSimulator:
+    """`sim(params, n_trials, ...)` over a process group.
+
+    params: the GLOBAL [B, P] parameter matrix (identical on every rank: drawn from a shared seed, or on the device
+    with the counter-based prior), or a callable (lo, hi) -> rows [hi-lo, P] that materialises only this rank's block.
+    simulate_fn(model, params_rows, n_trials, seed=, set_offset=, **kw) -> dict with 'trials' / 'summary' tensors;
+    the default is the HIP engine.  gather: 'trials' | 'summary' | 'both' | 'none'.
+    """
+
+    def __init__(self, model, simulate_fn=None, group=None, gather="trials"):
+        if gather not in ("trials", "summary", "both", "none"):
+            raise ValueError("gather must be 'trials', 'summary', 'both' or 'none'")
+        if simulate_fn is None:
+            from . import engine
+            simulate_fn = engine.simulate
+        self.model, self.simulate_fn, self.group, self.gather = model, simulate_fn, group, gather
+
+    def __call__(self, params, n_sets, n_trials, seed, set_offset=0, **kw):
+        dist = _dist()
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        else:
+            world, rank = 1, 0
+        lo, hi = shard_bounds(n_sets, world, rank)
+        rows = params(lo, hi) if callable(params) else params[lo:hi]
+        want_t = self.gather in ("trials", "both", "none")
+        want_s = self.gather in ("summary", "both", "none")
+        res = self.simulate_fn(self.model, rows, n_trials, seed=seed, set_offset=set_offset + lo,
+                               want_trials=want_t, want_summary=want_s, **kw)
+        out = {"rank": rank, "world_size": world, "rows": (lo, hi)}
+        for key, want in (("trials", want_t), ("summary", want_s)):
+            if not want or key not in res:
+                continue
+            if world > 1 and self.gather != "none":
+                out[key] = all_gather_rows(res[key], n_sets, self.group)
+            else:
+                out[key] = res[key]
+        return out
+
+
+def shared_prior_N(seed, step, n_min=60, n_max=300):
+    """The batch-shared number of trials (basic_ddm_dc.py:50-52, 131) drawn identically on every rank without
+    communication: a pure function of (seed, step)."""
+    return int(np.random.default_rng([int(seed), int(step)]).integers(n_min, n_max + 1))

@@ -1,0 +1,88 @@
+"""Prior and context samplers.
+
+Host versions restate the reference's draw order call for call (basic_ddm_dc.py:50-80,
+single_trial_alpha_not_scaled.py:66-102, :889-913, :1205-1232): `RNG` is a module-level default_rng(2023) (PCG64)
+used for drift / beta / sigma1 / gamma, the truncated normals go through scipy.stats.truncnorm.rvs on NumPy's
+GLOBAL legacy stream, and prior_N uses np.random.randint -- so with the same seeds they return the reference's
+numbers bit for bit (tests/golden/priors.npz).
+
+DevicePrior is the batched on-device sampler (SURVEY f-1): the per-set SciPy calls cost ~0.5 ms per draw, i.e.
+minutes per million sets, which would dwarf the simulate time; the device version fills [B, P] in one launch and is
+checked per marginal by KS against the reference draws.
+"""
+import numpy as np
+from scipy.stats import truncnorm
+
+from . import engine
+
+
+def prior_N(n_min=60, n_max=300):
+    """A prior for the random number of observations (basic_ddm_dc.py:50-52); global NumPy stream."""
+    return np.random.randint(n_min, n_max + 1)
+
+
+def truncnorm_better(mean=0, sd=1, low=-10, upp=10, size=1):
+    """basic_ddm_dc.py:55-57."""
+    return truncnorm.rvs((low - mean) / sd, (upp - mean) / sd, loc=mean, scale=sd, size=size)
+
+
+RNG = np.random.default_rng(2023)   # basic_ddm_dc.py:60 / single_trial_alpha_not_scaled.py:76
+
+
+def reset_host_rng(seed=2023):
+    """Re-create the module-level generator (what re-importing the reference script does)."""
+    global RNG
+    RNG = np.random.default_rng(seed)
+
+
+def draw_prior_basic():
+    """basic_ddm_dc.py:62-80 -> [drift, alpha, beta, ter, dc]."""
+    drift = RNG.normal(0.0, 2.0)
+    alpha = truncnorm_better(mean=1.0, sd=0.5, low=0.0, upp=10)[0]
+    beta = RNG.beta(2.0, 2.0)
+    ter = truncnorm_better(mean=0.5, sd=0.25, low=0.0, upp=1.5)[0]
+    dc = truncnorm_better(mean=1.0, sd=0.5, low=0.0, upp=10)[0]
+    return np.hstack((drift, alpha, beta, ter, dc))
+
+
+def draw_prior_single():
+    """single_trial_alpha_not_scaled.py:78-102 -> [drift, mu_alpha, beta, ter, std_alpha, dc, sigma1]
+    (draw_prior_alt :889-913 has the same marginals with std_dc / mu_dc at indices 4 / 5)."""
+    drift = RNG.normal(0.0, 2.0)
+    mu_alpha = truncnorm_better(mean=1.0, sd=0.5, low=0.0, upp=10)[0]
+    beta = RNG.beta(2.0, 2.0)
+    ter = truncnorm_better(mean=0.5, sd=0.25, low=0.0, upp=1.5)[0]
+    std_alpha = truncnorm_better(mean=1.0, sd=0.5, low=0.0, upp=3)[0]
+    dc = truncnorm_better(mean=1.0, sd=0.5, low=0.0, upp=10)[0]
+    sigma1 = RNG.uniform(0.0, 5.0)
+    return np.hstack((drift, mu_alpha, beta, ter, std_alpha, dc, sigma1))
+
+
+def draw_prior_scale():
+    """single_trial_alpha_not_scaled.py:1205-1232: the 7 parameters above + gamma ~ U(0, 2)."""
+    p = draw_prior_single()
+    gamma = RNG.uniform(0.0, 2.0)
+    return np.hstack((p, gamma))
+
+
+class DevicePrior:
+    """Batched on-device draw_prior: `DevicePrior('basic')(B)` -> torch float32 [B, P] on the GPU.
+
+    model: 'basic' (P=5) | 'single' (P=7) | 'scale' (P=8, gamma ~ U(0,2)).  Counter-based: row i of call c depends
+    only on (seed, global row index), so shards of a batch drawn on different GPUs are consistent."""
+
+    _NCOLS = {"basic": 5, "single": 7, "scale": 8}
+
+    def __init__(self, model="basic", seed=2023, stream_state=None):
+        if model not in self._NCOLS:
+            raise ValueError(f"unknown prior model {model!r}")
+        self.model = model
+        self.state = stream_state or engine.StreamState(seed=seed)
+
+    def __call__(self, batch_size, set_offset=None):
+        seed, off = self.state.take(batch_size) if set_offset is None else (self.state.seed, set_offset)
+        if self.model == "basic":
+            return engine.draw_prior_device(engine.BASIC_DDM_DC, batch_size, seed=seed, set_offset=off)
+        gamma = -1.0 if self.model == "scale" else 1.0
+        out = engine.draw_prior_device(engine.SINGLE_TRIAL, batch_size, seed=seed, set_offset=off, gamma=gamma)
+        return out[:, :self._NCOLS[self.model]].contiguous()

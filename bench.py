@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated DDM trials per second (BASELINE.json metric) on N MI355X GPUs of one node.
+
+One "step" = one pass of the hot path over one batch: `--sets` parameter sets x `--trials` trials of the
+basic_ddm_dc Euler-Maruyama simulator at dt=0.001 / max_steps=4000 (BASELINE.json configs[1]: 1M x 300), parameters
+already resident in HBM, output = float32 (rt, choice) pairs [B, 300, 2] + fused per-set summaries [B, 10].
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); the batch shards embarrassingly --
+rank r simulates global set indices [r*B, (r+1)*B) of each step with no data-path collective (weak scaling);
+`--gather summary|trials` adds the RCCL all-gather that reassembles a training minibatch (north_star) to the
+timed region.
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      HBM view of the dominant kernel (algorithmic bytes / measured kernel time vs 8 TB/s) -- tiny by
+                construction: 8 B are written per trial for ~246 Gaussian draws
+  roofline_valu the binding resource: vector-ALU issue cycles (instruction mix of the step loop x measured
+                per-instruction issue cost) -- see DESIGN.md section 6
+  cpu_baseline  the CPU oracle (C restatement, same Philox stream) timed on this box's host cores on a bounded
+                sample of the same workload; plus the pure-Python/NumPy port the reference runs without numba
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU ceiling model: issue cycles per wave64 for one Philox block = 4 E-M steps, fast Gaussian
+# mode, from the ISA of sim_kernel<basic, fast> x the measured per-instruction issue cost (tools/ubench_valu)
+VALU_MODEL = {
+    "clock_ghz": 2.4, "simds": 1024,
+    "cycles_per_block_fast": None, "cycles_per_block_exact": None,   # filled from profiles/ubench
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sets", type=int, default=1_000_000, help="parameter sets per GPU per step")
+    ap.add_argument("--trials", type=int, default=300)
+    ap.add_argument("--dt", type=float, default=0.001)
+    ap.add_argument("--max-steps", type=float, default=4000.0)
+    ap.add_argument("--gauss", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
+    ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle baseline sample")
+    ap.add_argument("--no-ks", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, n_trials, dt, max_steps, target_s):
+    """Time the CPU oracle (kind 'port': our C restatement on the same Philox stream) on a bounded sample of the
+    same workload: the first S parameter sets, S sized from a pilot so that the single-thread run takes ~target_s."""
+    import oracle
+    from oracle import numpy_port
+    oracle.build()
+    cores = os.cpu_count() or 1
+    pilot = 64
+    t0 = time.perf_counter()
+    oracle.philox_simulate(oracle.M_BASIC, params[:pilot], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=1)
+    t_pilot = time.perf_counter() - t0
+    S = int(max(pilot, min(len(params), pilot * target_s / max(t_pilot, 1e-6))))
+    t0 = time.perf_counter()
+    oracle.philox_simulate(oracle.M_BASIC, params[:S], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=1)
+    t1 = time.perf_counter() - t0
+    v1 = S * n_trials / t1
+    # all host cores, same sample scaled up
+    Sm = int(min(len(params), S * min(cores, 16)))
+    t0 = time.perf_counter()
+    oracle.philox_simulate(oracle.M_BASIC, params[:Sm], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=cores)
+    tm = time.perf_counter() - t0
+    vm = Sm * n_trials / tm
+    # the pure-Python/NumPy algorithm the reference runs when numba is absent (numba is not installed here)
+    Sp = 12
+    np.random.seed(2023)
+    t0 = time.perf_counter()
+    for i in range(Sp):
+        numpy_port.basic_simulate_trials(params[i].astype(np.float64), n_trials, dt=dt, max_steps=max_steps)
+    tp = time.perf_counter() - t0
+    return {"value": v1, "unit": "trials/s", "cores": 1, "kind": "port",
+            "sample": f"first {S} of the step's parameter sets x {n_trials} trials, C oracle (Philox stream), "
+                      f"{t1:.1f} s single thread",
+            "all_cores": {"value": vm, "cores": cores, "sample": f"{Sm} sets, OpenMP over sets, {tm:.1f} s"},
+            "numpy_port": {"value": Sp * n_trials / tp, "cores": 1,
+                           "sample": f"{Sp} sets x {n_trials} trials, pure-Python/NumPy statement of "
+                                     f"basic_ddm_dc.py:85-125 (numba not installed), {tp:.1f} s"}}
+
+
+def ks_vs_golden(engine, dt, max_steps, fast):
+    """KS distance of the signed RT distribution vs the golden histograms made from the reference's NumPy
+    simulator (tests/golden/ks_hist.npz), >= 4e5 trials per side, all fixed basic_ddm_dc parameter sets."""
+    from bayesflow_nddms_amd import diagnostics as dg
+    path = os.path.join(ROOT, "tests", "golden", "ks_hist.npz")
+    if not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    dts = list(gold["dt"])
+    if dt not in dts:
+        return None
+    ci = dts.index(dt)
+    if float(gold["max_steps"][ci]) != float(max_steps):
+        return None
+    K = int(max_steps)
+    worst, per = 0.0, []
+    for si, p in enumerate(gold["basic_sets"]):
+        key = f"basic_hist_s{si}_c{ci}"
+        if key not in gold:
+            continue
+        r = engine.simulate(engine.BASIC_DDM_DC, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=max_steps,
+                            seed=777, set_offset=si * 4096, fast=fast, want_summary=False)
+        h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K)
+        ks = dg.ks_signed(h, gold[key])
+        per.append(round(ks, 5))
+        worst = max(worst, ks)
+    return {"max": worst, "per_set": per, "n_trials_per_side": 409600, "bar": 0.01,
+            "reference": "NumPy reference simulator (basic_ddm_dc.py:85-125), tests/golden/ks_hist.npz"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from bayesflow_nddms_amd import engine
+    import prior_util
+
+    B, N = a.sets, a.trials
+    fast = a.gauss == "fast"
+    # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80), default_rng(2023 + rank), resident in HBM
+    p_host = prior_util.basic_prior(B, 2023 + rank)
+    p_dev = torch.as_tensor(p_host).to(dev)
+    out_trials = None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev)
+    out_summary = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
+    gathered = None
+    if world > 1 and a.gather != "none":
+        src = out_summary if a.gather == "summary" else out_trials
+        gathered = torch.empty((world,) + tuple(src.shape), dtype=torch.float32, device=dev)
+
+    def step(i):
+        # every step is a fresh batch: global set index = (i*world + rank)*B + row, one seed
+        engine.simulate(engine.BASIC_DDM_DC, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
+                        set_offset=(i * world + rank) * B, fast=fast, out_trials=out_trials, out_summary=out_summary,
+                        want_trials=not a.summary_only)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out_summary if a.gather == "summary" else out_trials)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()              # torch's current stream == the stream the kernel is launched on
+        step(a.warmup + i)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    # executed Euler-Maruyama steps of the last step, from the fused summaries (exact integer sums)
+    s = out_summary.double()
+    tau = p_dev[:, 3].double()
+    n_resp = s[:, 0] + s[:, 1]
+    max_k = engine.max_k_of(a.max_steps)
+    mean_k = torch.where(n_resp > 0, (s[:, 3] - tau) / a.dt, torch.zeros_like(tau))
+    em_steps = float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
+    p_missing = float((s[:, 2].sum() / (B * N)).item())
+
+    if rank == 0:
+        trials_per_step = world * B * N
+        value = trials_per_step * a.steps / elapsed
+        alg_bytes = B * N * (0 if a.summary_only else 8) + B * (5 * 4 + engine.SUMMARY_K * 4)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "simulated DDM trials/sec at n_trials=300 dt=0.001 (basic_ddm_dc, max_steps=4000)",
+            "value": value, "unit": "trials/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"basic_ddm_dc HIP simulator, {B} parameter sets x {N} trials per GPU per step, "
+                                   f"dt={a.dt}, max_steps={a.max_steps:g}, params ~ reference prior (default_rng 2023)",
+                       "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
+                       "gauss": a.gauss, "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
+                       "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "nddm::sim_kernel<NDDM_BASIC_DDM_DC, %s>" % ("fast" if fast else "exact"),
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
+            "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
+            "p_missing": p_missing,
+        }
+        cpb = VALU_MODEL["cycles_per_block_fast" if fast else "cycles_per_block_exact"]
+        if cpb:
+            # a wave64 advances 64 lanes x 4 steps per block; ceiling assumes every lane useful
+            peak_steps = VALU_MODEL["simds"] * VALU_MODEL["clock_ghz"] * 1e9 / cpb * 64 * 4
+            res["roofline_valu"] = {"bound": "valu", "achieved": em_steps / (kern_ms * 1e-3) / 1e9,
+                                    "peak": peak_steps / 1e9, "unit": "G E-M steps/s",
+                                    "frac": em_steps / (kern_ms * 1e-3) / peak_steps,
+                                    "issue_cycles_per_block": cpb, "clock_ghz": VALU_MODEL["clock_ghz"]}
+        if world == 1 and not a.no_ks:
+            res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p_host, N, a.dt, a.max_steps, a.cpu_seconds)
+            res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,196 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/nddm.h declares, the
+product path fails loudly without a GPU (no CPU fallback), the BayesFlow-style wrappers and the configurator honour
+the reference's dictionary contract."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nddm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nddm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from bayesflow_nddms_amd import _lib, build
+    build.build_hip()                      # hipcc cross-compiles gfx950 without a GPU
+    L = ctypes.CDLL(build.SO_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/nddm.h but not exported"
+    assert set(syms) <= set(_lib.EXPORTS)
+    assert _lib.lib().nddm_abi_version() == 1
+    assert _lib.lib().nddm_summary_k() == 10
+    assert [_lib.lib().nddm_model_nparams(m) for m in range(6)] == [5, 8, 8, 6, 4, -1]
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Argument validation happens before any HIP call, so it is checkable on a CPU-only box."""
+    from bayesflow_nddms_amd import _lib
+    L = _lib.lib()
+    dummy = ctypes.c_void_p(16)
+    assert L.nddm_basic_ddm_dc_simulate(dummy, -1, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 0, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, -0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 7, dummy, None, None) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_basic_ddm_dc_simulate(None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 0, None, None, None) == _lib.NDDM_ERR_NULL
+    assert L.nddm_explicit_boundary_simulate(dummy, None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 100000, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
+    assert b"n_trials too large" in L.nddm_last_error()
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 0, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_OK  # empty batch
+    with pytest.raises(ValueError):
+        _lib.check(_lib.NDDM_ERR_SHAPE)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.NDDM_ERR_HIP)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from bayesflow_nddms_amd import basic_ddm_dc, engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.simulate(engine.BASIC_DDM_DC, np.array([[1.5, 1.2, .5, .35, 1.0]]), 10)
+    with pytest.raises(RuntimeError):
+        basic_ddm_dc.simulate_trials([1.5, 1.2, .5, .35, 1.0], 10)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under bayesflow_nddms_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "bayesflow_nddms_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src and "ddm_oracle" not in src, f
+
+
+def test_validation_and_stream_state():
+    from bayesflow_nddms_amd import engine
+    engine.validate_params_host(engine.BASIC_DDM_DC, np.array([[1.5, 1.2, .5, .35, 1.0]]))
+    for bad in ([[1.5, -1.2, .5, .35, 1.0]], [[1.5, 1.2, .5, .35, 0.0]], [[np.inf, 1.2, .5, .35, 1.0]]):
+        with pytest.raises(ValueError):
+            engine.validate_params_host(engine.BASIC_DDM_DC, np.array(bad))
+    with pytest.raises(ValueError):   # per-trial boundary that can never be positive
+        engine.validate_params_host(engine.SINGLE_TRIAL, np.array([[0., -5., .5, .3, .1, 1., 1., 1.]]))
+    s = engine.StreamState(seed=5)
+    assert s.take(10) == (5, 0) and s.take(3) == (5, 10) and s.get_state() == {"seed": 5, "offset": 13}
+    s.set_state({"seed": 5, "offset": 10})
+    assert s.take(1) == (5, 10)                      # resume continues the stream
+    assert engine.max_k_of(400.) == 400 and engine.max_k_of(400.5) == 401 and engine.max_k_of(4000) == 4000
+
+
+def test_generative_model_dict_contract(kat):
+    """The wrappers reproduce the keys / shapes the reference's call sites read (basic_ddm_dc.py:146,151,159) with
+    both the per-set simulator_fun loop and the batched form, and carry 'summary_stats' additively."""
+    from bayesflow_nddms_amd.simulation import ContextGenerator, GenerativeModel, Prior, Simulator
+    calls = []
+
+    def draw_prior():
+        return np.arange(5, dtype=np.float64)
+
+    def prior_N():
+        return 77
+
+    def simulate_trials(params, n_trials):
+        calls.append(("set", tuple(np.shape(params)), n_trials))
+        return np.zeros((n_trials, 2))
+
+    def batch_sim(params, n_trials):
+        calls.append(("batch", tuple(np.shape(params)), n_trials))
+        return {"sim_data": np.ones((params.shape[0], n_trials, 2), np.float32),
+                "summary_stats": np.zeros((params.shape[0], 10), np.float32)}
+
+    ctx = ContextGenerator(non_batchable_context_fun=prior_N)
+    gm = GenerativeModel(Prior(prior_fun=draw_prior), Simulator(simulator_fun=simulate_trials, context_generator=ctx))
+    assert calls[:2] == [("set", (5,), 77)] * 2      # construction self-test: batch of 2, per-set calls
+    out = gm(4)
+    assert out["prior_draws"].shape == (4, 5) and out["sim_data"].shape == (4, 77, 2)
+    assert out["sim_non_batchable_context"] == 77 and "summary_stats" not in out
+    assert set(out) >= {"prior_draws", "sim_data", "sim_non_batchable_context", "sim_batchable_context",
+                        "prior_batchable_context", "prior_non_batchable_context"}
+    calls.clear()
+    gmb = GenerativeModel(Prior(prior_fun=draw_prior), Simulator(batch_simulator_fun=batch_sim, context_generator=ctx),
+                          skip_test=True)
+    out = gmb(6)
+    assert calls == [("batch", (6, 5), 77)]           # ONE call for the whole batch
+    assert out["sim_data"].shape == (6, 77, 2) and out["summary_stats"].shape == (6, 10)
+    with pytest.raises(ValueError):
+        Prior()
+    with pytest.raises(ValueError):
+        Simulator(batch_simulator_fun=batch_sim, simulator_fun=simulate_trials)
+
+
+def test_configurator_matches_reference(kat):
+    from bayesflow_nddms_amd import basic_ddm_dc, single_trial_alpha_not_scaled as st
+    sim = {"sim_data": kat["basic_seed2023_p0_n300"][None], "sim_non_batchable_context": 300,
+           "prior_draws": kat["basic_sets"][0][None]}
+    c = basic_ddm_dc.configurator(sim)
+    assert c["summary_conditions"].dtype == np.float32 and c["summary_conditions"].shape == (1, 300, 2)
+    assert c["direct_conditions"].dtype == np.float32
+    # the fixture was made under NumPy 2 (float64 by NEP 50); the reference's pinned NumPy 1.23.5 gives float32
+    assert np.allclose(c["direct_conditions"], kat["conf_direct_conditions"], rtol=1e-7)
+    assert c["parameters"].dtype == np.float32 and c["parameters"].shape == (1, 5)
+    # hand-built dict with prior_draws=None (fitting_stahl_data.py:201-202): 'parameters' is skipped
+    c2 = st.configurator({"sim_data": kat["single_seed2024_p0_n300"][None], "sim_non_batchable_context": 300,
+                          "prior_draws": None})
+    assert "parameters" not in c2 and c2["summary_conditions"].shape == (1, 300, 2)
+    # torch tensors stay tensors
+    import torch
+    c3 = basic_ddm_dc.configurator({k: (torch.as_tensor(v) if isinstance(v, np.ndarray) else v) for k, v in sim.items()})
+    assert isinstance(c3["summary_conditions"], torch.Tensor) and c3["direct_conditions"].shape == (1, 1)
+    assert np.allclose(c3["direct_conditions"].numpy(), np.log(300))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "priors.npz")), reason="priors.npz not generated yet")
+def test_host_priors_bit_exact():
+    """draw_prior / prior_N restated call for call: same seeds -> the reference's numbers."""
+    from bayesflow_nddms_amd import priors
+    g = np.load(os.path.join(GOLDEN, "priors.npz"))
+    for name, fn in (("basic", priors.draw_prior_basic), ("single", priors.draw_prior_single)):
+        np.random.seed(2023)
+        priors.reset_host_rng(2023)
+        d = np.array([fn() for _ in range(16)])
+        n = np.array([priors.prior_N() for _ in range(16)])
+        assert np.array_equal(d, g[f"{name}_draws16"]), name
+        assert np.array_equal(n, g[f"{name}_priorN16"]), name
+    assert priors.draw_prior_scale().shape == (8,)
+
+
+def test_diagnostics_ks():
+    from bayesflow_nddms_amd import diagnostics as dg
+    rng = np.random.default_rng(0)
+    K = 50
+    k = rng.integers(1, K, 20000)
+    ch = rng.choice([1, -1, 0], 20000, p=[.6, .3, .1])
+    tr = np.stack([k * 0.01 + 0.3, ch], axis=1)
+    tr[ch == 0, 0] = K * 0.01 + 0.3
+    h = dg.step_hist_from_trials(tr, 0.3, 0.01, K)
+    assert h.sum() == 20000 and h[2, K] == (ch == 0).sum()
+    assert dg.ks_signed(h, h) == 0.0
+    h2 = h.copy(); h2[0] = np.roll(h2[0], 3)
+    assert 0.01 < dg.ks_signed(h, h2) < 0.2
+    signed = np.stack([np.where(ch == 0, 0, ch * (k * 0.01 + 0.3)), np.zeros(20000)], axis=1)
+    assert np.array_equal(dg.step_hist_from_trials(signed, 0.3, 0.01, K, signed=True)[:2], h[:2])
+    s = rng.normal(size=50000)
+    q = np.quantile(rng.normal(size=400000), np.linspace(0, 1, 2001))
+    assert dg.ks_quantile_table(s, q) < 0.01 and dg.ks_quantile_table(s + 0.2, q) > 0.05
+
+
+def test_shard_bounds_cover_and_partition():
+    from bayesflow_nddms_amd.distributed import shard_bounds, shared_prior_N
+    for B in (0, 1, 7, 8, 9, 1000, 1_000_000):
+        for G in (1, 2, 3, 8):
+            spans = [shard_bounds(B, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert shared_prior_N(3, 5) == shared_prior_N(3, 5) and 60 <= shared_prior_N(3, 6) <= 300

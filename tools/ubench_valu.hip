@@ -1,0 +1,116 @@
+// ubench_valu.hip -- measures the per-SIMD issue cost (cycles per wave64 instruction) of the VALU
+// instructions the DDM kernels are made of, on the GPU it runs on.  The numbers feed the
+// VALU-bound ceiling quoted in DESIGN.md / bench.py (the path has no HBM or MFMA roofline that binds).
+// Build: hipcc -O3 --offload-arch=gfx950 -o tools/ubench_valu tools/ubench_valu.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 16384;
+constexpr int UNROLL = 16;
+
+// each kernel: 8 independent register chains, UNROLL instructions per loop trip
+#define DEF_KERNEL(NAME, DECL, BODY, SINK)                                                      \
+    __global__ __launch_bounds__(256) void NAME(float *out, uint64_t *clk)                      \
+    {                                                                                           \
+        DECL;                                                                                   \
+        uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();     \
+        for (int i = 0; i < ITERS; ++i) { BODY BODY }                                          \
+        uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();     \
+        SINK;                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }        \
+    }
+
+#define F8 float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; float c = 1.0001f
+#define U8 uint32_t a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; uint32_t c = 0xD2511F53u
+#define SINKF out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7
+#define SINKU out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+
+#define OP8(INS) \
+    asm volatile(INS " %0, %0, %1" : "+v"(a0) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a2) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a6) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a7) : "v"(c));
+#define OP8_1(INS) \
+    asm volatile(INS " %0, %0" : "+v"(a0)); asm volatile(INS " %0, %0" : "+v"(a1)); \
+    asm volatile(INS " %0, %0" : "+v"(a2)); asm volatile(INS " %0, %0" : "+v"(a3)); \
+    asm volatile(INS " %0, %0" : "+v"(a4)); asm volatile(INS " %0, %0" : "+v"(a5)); \
+    asm volatile(INS " %0, %0" : "+v"(a6)); asm volatile(INS " %0, %0" : "+v"(a7));
+#define OP8_FMA \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a0) : "v"(c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a2) : "v"(c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a4) : "v"(c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a6) : "v"(c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a7) : "v"(c));
+// v_mad_u64_u32 vdst[2], sdst(carry), a, b, c64
+#define MAD1(A) { uint64_t w; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w) : "v"(A), "v"(c) : "vcc"); A = (uint32_t)(w >> 32) ^ (uint32_t)w; }
+#define MAD1N(A) { uint64_t w; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w) : "v"(A), "v"(c) : "vcc"); asm volatile("" : "=v"(A) : "0"((uint32_t)(w >> 32))); }
+#define OP8_MAD MAD1N(a0) MAD1N(a1) MAD1N(a2) MAD1N(a3) MAD1N(a4) MAD1N(a5) MAD1N(a6) MAD1N(a7)
+
+DEF_KERNEL(k_fma, F8, OP8_FMA, SINKF)
+DEF_KERNEL(k_add, F8, OP8("v_add_f32"), SINKF)
+DEF_KERNEL(k_mul, F8, OP8("v_mul_f32"), SINKF)
+DEF_KERNEL(k_xor, U8, OP8("v_xor_b32"), SINKU)
+DEF_KERNEL(k_add_u32, U8, OP8("v_add_u32"), SINKU)
+DEF_KERNEL(k_mul_lo, U8, OP8("v_mul_lo_u32"), SINKU)
+DEF_KERNEL(k_mul_hi, U8, OP8("v_mul_hi_u32"), SINKU)
+DEF_KERNEL(k_mul_u24, U8, OP8("v_mul_u32_u24"), SINKU)
+DEF_KERNEL(k_mul_hi_u24, U8, OP8("v_mul_hi_u32_u24"), SINKU)
+DEF_KERNEL(k_mad64, U8, OP8_MAD, SINKU)
+DEF_KERNEL(k_log, F8, OP8_1("v_log_f32"), SINKF)
+DEF_KERNEL(k_sqrt, F8, OP8_1("v_sqrt_f32"), SINKF)
+DEF_KERNEL(k_sin, F8, OP8_1("v_sin_f32"), SINKF)
+DEF_KERNEL(k_cos, F8, OP8_1("v_cos_f32"), SINKF)
+DEF_KERNEL(k_rcp, F8, OP8_1("v_rcp_f32"), SINKF)
+DEF_KERNEL(k_cvt_f32_u32, F8, OP8_1("v_cvt_f32_u32"), SINKF)
+DEF_KERNEL(k_cmp, F8, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0" :: "v"(a0), "v"(c) : "vcc");, SINKF)
+
+typedef void (*kern_t)(float *, uint64_t *);
+struct Entry { const char *name; kern_t k; };
+
+int main(int argc, char **argv)
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device: %s  CUs=%d  clockRate=%d kHz\n", prop.name, cus, prop.clockRate);
+    float *out; uint64_t *clk;
+    const int wpc_list[] = {4, 8, 16, 32};   // waves per CU (1, 2, 4, 8 per SIMD)
+    CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * sizeof(float)));
+    CHECK(hipMalloc(&clk, 16));
+    Entry es[] = {{"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_mul_f32", k_mul}, {"v_xor_b32", k_xor},
+                  {"v_add_u32", k_add_u32}, {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi},
+                  {"v_mul_u32_u24", k_mul_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u24}, {"v_mad_u64_u32", k_mad64},
+                  {"v_log_f32", k_log}, {"v_sqrt_f32", k_sqrt}, {"v_sin_f32", k_sin}, {"v_cos_f32", k_cos},
+                  {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}};
+    printf("%-18s", "instr \\ waves/SIMD");
+    for (int w : wpc_list) printf("  %6d", w / 4);
+    printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
+    for (auto &e : es) {
+        printf("%-18s", e.name);
+        for (int wpc : wpc_list) {
+            const int blocks = cus * wpc / 4;    // 256-thread blocks = 4 waves
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, clk);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, clk);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            uint64_t h[2]; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+            // wall-clock view: every SIMD hosts wpc/4 waves, each issuing ITERS*UNROLL instructions;
+            // clock = the in-kernel shader clock of this very kernel (s_memtime / s_memrealtime * 100 MHz)
+            const double ghz = (double)h[0] / (double)h[1] * 0.1;
+            const double instr_per_simd = (double)(wpc / 4) * ITERS * UNROLL;
+            const double per_simd = (ms * 1e-3) * ghz * 1e9 / instr_per_simd;
+            printf("  %6.2f", per_simd);
+            if (wpc == 32) printf("   clock %.3f GHz, wall %.3f ms", ghz, ms);
+        }
+        printf("\n");
+    }
+    return 0;
+}
