@@ -1,0 +1,216 @@
+"""GPU distribution tests: the HIP simulators against golden fixtures made by RUNNING the reference
+(tests/golden/*.npz), and size-independent properties at the full BASELINE size (1M sets x 300 trials).
+
+Tolerance (north_star): KS distance of the simulated RT/choice distribution vs the NumPy reference < 0.01,
+with >= 4e5 trials per side (two-sample noise floor ~0.003)."""
+import os
+
+import numpy as np
+import pytest
+
+import prior_util
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+KS_BAR = 0.01
+
+
+def _gold(name):
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} missing")
+    return np.load(path)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("ci", [0, 1])
+def test_ks_basic_vs_reference(ci, fast):
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("ks_hist.npz")
+    dt, ms = float(gold["dt"][ci]), float(gold["max_steps"][ci])
+    K = int(ms)
+    worst = 0.0
+    for si, p in enumerate(gold["basic_sets"]):
+        r = engine.simulate(engine.BASIC_DDM_DC, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=ms, seed=41,
+                            set_offset=si * 10000, fast=fast, want_summary=False)
+        h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K)
+        g = gold[f"basic_hist_s{si}_c{ci}"]
+        ks = dg.ks_signed(h, g)
+        worst = max(worst, ks)
+        assert ks < KS_BAR, (si, ks)
+        assert np.max(np.abs(dg.choice_probs(h) - dg.choice_probs(g))) < KS_BAR      # |dP(upper)|, |dP(timeout)|
+        for row in (0, 1):
+            if g[row].sum() > 20000:
+                assert dg.ks_conditional(h, g, row) < 0.015, (si, row)
+    print(f"basic dt={dt} fast={fast}: max KS {worst:.4f}")
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("ci", [0, 1])
+def test_ks_single_trial_vs_reference(ci, fast):
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("ks_hist.npz")
+    dt, ms = float(gold["dt"][ci]), float(gold["max_steps"][ci])
+    K = int(ms)
+    for si, p in enumerate(gold["single_sets"]):
+        r = engine.simulate(engine.SINGLE_TRIAL, np.tile(np.append(p, 1.0), (2048, 1)), 200, dt=dt, max_steps=ms,
+                            seed=42, set_offset=si * 10000, fast=fast, want_summary=True)
+        t = r["trials"].cpu().numpy()
+        h = dg.step_hist_from_trials(t, float(np.float32(p[3])), dt, K, signed=True)
+        g = gold[f"single_hist_s{si}_c{ci}"]
+        assert dg.ks_signed(h, g) < KS_BAR, (si, dg.ks_signed(h, g))
+        assert dg.ks_quantile_table(t[..., 1].ravel(), gold[f"single_zq_s{si}_c{ci}"]) < KS_BAR, si
+        zm = gold[f"single_zmom_s{si}_c{ci}"]
+        s = r["summary"].cpu().numpy()
+        assert abs(s[:, 7].mean() - zm[0]) < 0.02 * max(1.0, np.sqrt(zm[1]))     # fused mean z vs reference
+        assert abs(s[:, 8].mean() / zm[1] - 1) < 0.03                              # fused var z
+
+
+def test_alpha_not_scaled_em_vs_exact_sampler():
+    """Config 3: the Euler-Maruyama process vs the reference's generator simulratcliff, an EXACT first-passage
+    sampler.  Discrete monitoring of the boundaries delays detection by ~0.58*sigma*sqrt(dt) per boundary, so the
+    plain E-M output is biased towards longer RTs by O(sqrt(dt)); stated tolerances for PLAIN Euler-Maruyama: KS < 0.10
+    at dt=.001, < 0.05 at dt=.00025, and the distance must shrink as dt -> 0 (measured: ~halves per 4x smaller dt)."""
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("ratcliff.npz")
+    for si, p in enumerate(gold["sets"]):
+        ks = []
+        for dt in (0.004, 0.001, 0.00025):
+            r = engine.simulate(engine.ALPHA_NOT_SCALED, np.tile(p, (1024, 1)), 200, dt=dt, max_steps=8.0 / dt, seed=43,
+                                set_offset=si * 10000, fast=True, want_summary=False)
+            y = r["trials"][..., 0].cpu().numpy().ravel()
+            ks.append(dg.ks_quantile_table(y, gold[f"yq_s{si}"]))
+            if dt == 0.001:
+                assert abs((y > 0).mean() - gold[f"pupper_s{si}"][0]) < 0.02
+        assert ks[2] < 0.05 and ks[1] < 0.10, (si, ks)
+        assert ks[2] < ks[1] < ks[0] + 0.005, (si, ks)
+
+
+def test_device_prior_marginals():
+    """On-device draw_prior vs 1e5 draws of the reference's draw_prior: KS per marginal < 0.01."""
+    from bayesflow_nddms_amd import diagnostics as dg
+    from bayesflow_nddms_amd.priors import DevicePrior
+    gold = _gold("priors.npz")
+    for name in ("basic", "single"):
+        d = DevicePrior(name, seed=7)(400_000).cpu().numpy()
+        q = gold[f"{name}_quantiles"]
+        assert d.shape[1] == q.shape[1]
+        for j in range(d.shape[1]):
+            assert dg.ks_quantile_table(d[:, j], q[:, j]) < 0.01, (name, j)
+    s = DevicePrior("scale", seed=7)(100_000).cpu().numpy()
+    assert s.shape[1] == 8 and 0 <= s[:, 7].min() and s[:, 7].max() <= 2 and abs(s[:, 7].mean() - 1) < 0.02
+    # counter-based: shards reproduce the full draw
+    a = DevicePrior("basic", seed=9)(1000).cpu().numpy()
+    b = DevicePrior("basic", seed=9)(400, set_offset=600).cpu().numpy()
+    assert np.array_equal(a[600:], b)
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1]: 1M sets x 300 trials, dt=.001.  Size-independent properties of the result:
+    value domains, the timeout encoding, fused summaries == a torch recomputation from the trials, and the stream
+    being a pure function of (seed, set, trial): rows re-simulated alone reproduce their bits."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N, dt, ms = 1_000_000, 300, 0.001, 4000
+    p = torch.as_tensor(prior_util.basic_prior(B, 2023)).cuda()
+    r = engine.simulate(engine.BASIC_DDM_DC, p, N, dt=dt, max_steps=ms, seed=2023, set_offset=0, fast=True)
+    t, s = r["trials"], r["summary"]
+    rt, ch = t[..., 0], t[..., 1]
+    tau = p[:, 3:4]
+    assert bool(((ch == 1) | (ch == -1) | (ch == 0)).all())
+    assert bool((rt >= tau + dt * 0.999).all())                      # the crossing step is counted: min RT = dt + tau
+    miss = ch == 0
+    assert bool(torch.allclose(rt[miss], (tau + ms * dt).expand_as(rt)[miss], rtol=1e-6))
+    frac_missing = float(miss.float().mean())
+    assert 0.001 < frac_missing < 0.01                               # SURVEY: ~0.4 % reach the cap under the prior
+    # fused summaries vs recomputation
+    n_up, n_lo, n_miss = (ch == 1).sum(1), (ch == -1).sum(1), miss.sum(1)
+    assert bool((s[:, 0] == n_up).all() and (s[:, 1] == n_lo).all() and (s[:, 2] == n_miss).all())
+    resp = (~miss).double()
+    nr = resp.sum(1).clamp(min=1)
+    mean_rt = (rt.double() * resp).sum(1) / nr
+    ok = resp.sum(1) > 0
+    assert bool(torch.allclose(s[ok, 3].double(), mean_rt[ok], rtol=2e-6, atol=2e-6))
+    var_rt = ((rt.double() - mean_rt[:, None]) ** 2 * resp).sum(1) / nr
+    assert bool(torch.allclose(s[ok, 4].double(), var_rt[ok], rtol=2e-3, atol=1e-7))
+    assert bool(torch.allclose(s[:, 9].double(), (0.5 + 0.5 * torch.sign(ch.double())).mean(1), atol=1e-6))
+    mean_steps = float(((rt - tau) / dt).mean())
+    assert 200 < mean_steps < 300                                    # SURVEY: 246 steps/trial under the prior
+    # geometry independence at full size: re-simulate scattered single rows and blocks
+    for lo, hi in ((0, 1), (123_456, 123_460), (999_999, 1_000_000), (500_000, 500_257)):
+        r2 = engine.simulate(engine.BASIC_DDM_DC, p[lo:hi], N, dt=dt, max_steps=ms, seed=2023, set_offset=lo, fast=True)
+        assert torch.equal(r2["trials"], t[lo:hi])
+        assert torch.equal(torch.nan_to_num(r2["summary"]), torch.nan_to_num(s[lo:hi]))
+    # summary-only mode gives the same summaries without writing trials
+    r3 = engine.simulate(engine.BASIC_DDM_DC, p[:100_000], N, dt=dt, max_steps=ms, seed=2023, set_offset=0, fast=True,
+                         want_trials=False)
+    assert "trials" not in r3 and torch.equal(torch.nan_to_num(r3["summary"]), torch.nan_to_num(s[:100_000]))
+
+
+def test_drop_in_api_on_device(kat):
+    """The reference's call shapes end to end on the GPU: per-set simulator_fun, batched generative model, dict keys,
+    configurator, alpha_not_scaled generator, imputation loop."""
+    import torch
+    import bayesflow_nddms_amd as nd
+    from bayesflow_nddms_amd import alpha_not_scaled, basic_ddm_dc, imputation, single_trial_alpha_not_scaled as st
+    # per-set call == row of the batched call (same seed / set index)
+    p = kat["basic_sets"]
+    one = basic_ddm_dc.simulate_trials(p[3], 120, seed=5, set_offset=3)
+    allb = basic_ddm_dc.batch_simulate_trials(p, 120, seed=5, set_offset=0)
+    assert one.shape == (120, 2) and one.dtype == np.float64
+    assert np.array_equal(one.astype(np.float32), allb["sim_data"][3])
+    rt, choice = basic_ddm_dc.diffusion_trial(*p[0], seed=1, set_offset=0)
+    assert rt > p[0][3] and choice in (-1, 0, 1)
+    # the package-level stream: consecutive calls differ, re-seeding reproduces
+    nd.seed(123)
+    a1, a2 = basic_ddm_dc.simulate_trials(p[0], 50), basic_ddm_dc.simulate_trials(p[0], 50)
+    nd.seed(123)
+    b1 = basic_ddm_dc.simulate_trials(p[0], 50)
+    assert np.array_equal(a1, b1) and not np.array_equal(a1, a2)
+    # generative models: reference wrapper block, per-set and batched, host and device priors
+    np.random.seed(2023)
+    for kw in (dict(batched=False), dict(batched=True), dict(batched=True, device_prior=True, as_numpy=False)):
+        gm = basic_ddm_dc.make_generative_model(**kw)
+        out = gm(32)
+        N = out["sim_non_batchable_context"]
+        assert 60 <= N <= 300 and tuple(out["sim_data"].shape) == (32, N, 2) and tuple(out["prior_draws"].shape) == (32, 5)
+        conf = basic_ddm_dc.configurator(out)
+        assert tuple(conf["summary_conditions"].shape) == (32, N, 2) and tuple(conf["direct_conditions"].shape) == (32, 1)
+        assert tuple(conf["parameters"].shape) == (32, 5)
+        if kw.get("batched"):
+            assert tuple(out["summary_stats"].shape) == (32, 10)
+        if kw.get("as_numpy") is False:
+            assert isinstance(out["sim_data"], torch.Tensor) and out["sim_data"].is_cuda
+    gm = st.make_generative_model(batched=True, fine=True)
+    out = gm(8)
+    assert out["sim_data"].shape[0] == 8 and out["prior_draws"].shape == (8, 7)
+    # the reference's fixed-parameter test case (single_trial_alpha_not_scaled.py:852-885)
+    input_params = np.hstack((3, 1.5, .5, .4, 1, 1, 0.1))
+    obs = st.simulate_trials(input_params, 300, seed=2024, set_offset=0)
+    obs_dict = {'sim_data': obs[np.newaxis, :, :], 'sim_non_batchable_context': 300, 'prior_draws': input_params}
+    conf = st.configurator(obs_dict)
+    assert conf["summary_conditions"].shape == (1, 300, 2)
+    assert (np.sign(obs[:, 0]) == 1).mean() > 0.85                  # reference: P(upper) = 0.95 for these parameters
+    assert abs(obs[:, 1].mean() - 1.64) < 0.25                       # reference: mean z = 1.6437 (n=300)
+    for f, pp in ((st.simulate_trials_fine, input_params), (st.simulate_trials_alt, [3.0, 1.5, .5, .4, .5, 1.0, .1]),
+                  (st.simulate_trials_scale, np.append(input_params, 0.7)), (st.simulate_trials_scale2, input_params)):
+        assert f(pp, 64, seed=1, set_offset=0).shape == (64, 2)
+    z1 = st.simulate_trials(input_params, 2000, seed=3, set_offset=0)[:, 1]
+    z2 = st.simulate_trials_scale2(input_params, 2000, seed=3, set_offset=0)[:, 1]
+    assert abs(z2.mean() / z1.mean() - 2.0) < 0.05                   # gamma = 2 doubles the datum's mean
+    # alpha_not_scaled.py:52-128
+    g = alpha_not_scaled.generate_data(test_num=2, nparts=100, ntrials=100)
+    assert set(g) >= {"ndt", "beta", "alpha", "delta", "deltatrialsd", "varsigma", "sigma", "rt", "acc", "y",
+                      "extdata", "participant", "nparts", "ntrials", "N"}
+    assert g["y"].shape == (10000,) and g["extdata"].shape == (100,) and g["alpha"][17] == 1.2
+    assert abs(np.corrcoef(g["extdata"], g["alpha"])[0, 1]) > 0.7     # sigma=.1 vs sd(alpha)=.17
+    assert np.all(np.abs(g["y"][g["y"] != 0]) >= g["ndt"].min())
+    y = alpha_not_scaled.simulratcliff_em(N=500, Alpha=1.2, Tau=.4, Nu=3.5, Beta=.5, Eta=1.0, Varsigma=1.2, seed=1, set_offset=0)
+    assert y.shape == (500,) and (y > 0).mean() > 0.8
+    # imputation loop
+    b = np.abs(np.random.default_rng(0).normal(1.2, .3, size=(4, 50)))
+    c = imputation.impute_choicert(1.0, b, .5, .3, 1.1, seed=2, set_offset=0)
+    assert c.shape == (4, 50) and np.all(np.abs(c[c != 0]) > 0.3)
+    with pytest.raises(ValueError):
+        imputation.diffusion_trial(1.0, -0.5, .5, .3, 1.1)
