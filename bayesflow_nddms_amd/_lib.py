@@ -6,7 +6,7 @@ import os
 from .build import SO_PATH
 
 NDDM_OK, NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM, NDDM_ERR_HIP, NDDM_ERR_NO_DEVICE = range(6)
-GAUSS_EXACT, GAUSS_FAST = 0, 1
+GAUSS_EXACT, GAUSS_FAST, BRIDGE = 0, 1, 2
 ABI_VERSION = 1
 
 _lib = None
@@ -26,6 +26,7 @@ def _declare(L):
     L.nddm_summary_k.restype = c.c_int
     L.nddm_model_nparams.argtypes = [c.c_int]
     L.nddm_set_tuning.argtypes = [c.c_int] * 4
+    L.nddm_set_debug_counters.argtypes = [c.c_void_p]
     common = [c.c_int64, c.c_int32, c.c_float, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32]
     for name in ("nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate", "nddm_single_trial_alt_simulate"):
         getattr(L, name).argtypes = [fp] + common + [fp, fp, vp]
@@ -43,7 +44,7 @@ EXPORTS = [
     "nddm_abi_version", "nddm_last_error", "nddm_device_count", "nddm_set_device", "nddm_summary_k",
     "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
-    "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning",
+    "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_counters",
 ]
 
 

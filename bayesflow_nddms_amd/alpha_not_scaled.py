@@ -4,8 +4,11 @@ extdata[p] ~ N(alpha[p], sigma) that identifies the diffusion coefficient.
 
 The reference generates the choice-RTs with pyhddmjagsutils.simulratcliff, an EXACT first-passage sampler
 (pyhddmjagsutils.py:47-176), not with Euler-Maruyama.  Here the same process is integrated by the Euler-Maruyama
-HIP kernel (north_star), so its output carries the O(sqrt(dt)) discretisation bias of discrete boundary
-monitoring against the exact sampler; tests state the tolerance per dt (tests/test_gpu_distribution.py).
+HIP kernel (north_star).  Plain Euler-Maruyama monitors the boundaries only on the time grid and therefore detects
+crossings late by O(sqrt(dt)) (KS ~0.07 vs the exact sampler at dt=.001 for fast trials); by default this module
+switches on the kernel's Brownian-bridge boundary correction (bridge=True), which samples the between-grid-point
+crossings with their exact conditional probability and brings the KS distance to the exact sampler below 0.01 at
+dt=.001 (tests/test_gpu_distribution.py).  bridge=False gives the plain scheme of the other models.
 """
 import numpy as np
 
@@ -16,13 +19,14 @@ SIGMA_OF_TEST = {1: .5, 2: .1, 3: .01, 4: .2}   # alpha_not_scaled.py:73-81
 
 
 def simulratcliff_em(N=100, Alpha=1, Tau=.4, Nu=1, Beta=.5, Eta=.3, Varsigma=1, dt=.001, max_steps=4000,
-                     seed=None, set_offset=None, fast=None):
+                     seed=None, set_offset=None, fast=None, bridge=True):
     """Same call shape as simulratcliff(N, Alpha, Tau, Nu, Beta, Eta=, Varsigma=) (pyhddmjagsutils.py:47) without
     the range* arguments the generator never uses: signed RTs float64 [N] (negative = response B)."""
     if (Nu < -5) or (Nu > 5):          # pyhddmjagsutils.py:102-103
         Nu = np.sign(Nu) * 5
     r = engine.simulate(engine.ALPHA_NOT_SCALED, [[Nu, Alpha, Beta, Tau, Eta, Varsigma]], N, dt=dt,
-                        max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=False)
+                        max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, bridge=bridge,
+                        want_summary=False)
     return r["trials"][0, :, 0].cpu().numpy().astype(np.float64)
 
 
@@ -41,7 +45,7 @@ def draw_participants(nparts=100, seed=2021):
 
 
 def generate_data(test_num=2, nparts=100, ntrials=100, seed=2021, dt=.001, max_steps=4000, sim_seed=None,
-                  set_offset=None, fast=None):
+                  set_offset=None, fast=None, bridge=True):
     """alpha_not_scaled.py:52-128 in one launch: returns the `genparam` dictionary the reference saves to .mat
     (same keys), all participants simulated as one batch of `nparts` parameter sets x `ntrials` trials."""
     sigma = SIGMA_OF_TEST[test_num]
@@ -50,7 +54,7 @@ def generate_data(test_num=2, nparts=100, ntrials=100, seed=2021, dt=.001, max_s
                   par["varsigma"]], axis=1)
     r = engine.simulate(engine.ALPHA_NOT_SCALED, P, ntrials, dt=dt, max_steps=max_steps,
                         seed=seed if sim_seed is None else sim_seed, set_offset=0 if set_offset is None else set_offset,
-                        fast=fast, ext_sigma=sigma, ext_mode=1 if test_num == 4 else 0, want_ext=True,
+                        fast=fast, bridge=bridge, ext_sigma=sigma, ext_mode=1 if test_num == 4 else 0, want_ext=True,
                         want_summary=False)
     y = r["trials"][..., 0].cpu().numpy().astype(np.float64).reshape(-1)
     N = nparts * ntrials

@@ -52,11 +52,13 @@ struct SimArgs {
     int max_k;
     float dt;
     float sqrt_dt;
+    float tscale;             // seconds per unit of the packed time field: dt, or dt/256 with the bridge correction
     uint32_t k0, k1;
     int sets_per_chunk;
     int ring;                 // LDS ring slots (power of two)
     float ext_sigma;
     int ext_mode;
+    unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
     int max_blocks;           // ... or after this many Philox blocks (4 steps each)
 };
@@ -110,10 +112,10 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set_in_call * N : nullptr;
     for (int j = lane; j < N; j += WAVE) {
         const uint32_t v = res[j];
-        const uint32_t k = v & 0x3fffffffu;
+        const uint32_t k = v & 0x3fffffffu;                  // time in units of A.tscale (step index, or 1/256 step)
         const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
         const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
-        const float rt = __builtin_fmaf((float)k, A.dt, tau);
+        const float rt = __builtin_fmaf((float)k, A.tscale, tau);
         float zval = 0.0f;
         if constexpr (T::HAS_Z) zval = zres[j];
         float2 o;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
         }
         if (lane == 0) {
             float *o = A.out_summary + set_in_call * NDDM_SUMMARY_K;
-            const double dtd = (double)A.dt, taud = (double)tau;
+            const double dtd = (double)A.tscale, taud = (double)tau;
             const double n_resp = (double)(n_up + n_lo);
             o[0] = (float)n_up; o[1] = (float)n_lo; o[2] = (float)n_miss;
             if (n_resp > 0) {
@@ -178,7 +180,19 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     }
 }
 
-template <int MODEL, bool FAST>
+// (x > 0) && (x < a) for finite a > 0 as ONE unsigned compare on the float bits: positive floats order like their
+// bit patterns, +0 wraps to 0xffffffff, negatives (sign bit) and NaN land above every finite positive bound.
+__device__ __forceinline__ bool in_range(float x, uint32_t a_bits_m1)
+{
+    return (__float_as_uint(x) - 1u) < a_bits_m1;
+}
+
+// MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
+// once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
+// points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
+// the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
+// generator is an exact first-passage sampler.
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -204,21 +218,28 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     __syncthreads();
 
     // per-lane trial state
-    float x = 0.0f, a = 0.0f, mu_dt = 0.0f, sig = 0.0f, zout = 0.0f;
+    float x = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;
+    uint32_t am1 = 0;        // bits(boundary) - 1
     int k = 0;
-    uint32_t trial = 0, tile = 0, set_lo = 0, c3 = 0;
+    uint32_t trial = 0, tile = 0, set_lo = 0, c3 = 0, jit = 0;
     bool has = false, active = false, invalid = false;
 
     uint32_t next_g = 0;     // wave-uniform: next unassigned trial of the chunk
     int flushed = 0;         // wave-uniform: sets already flushed (flushes are in order)
+    unsigned long long dbg_blocks = 0, dbg_refills = 0, dbg_t0 = 0, dbg_r0 = 0;
+    if (A.dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     while (true) {
         // ------------------------------------------------------------ retire finished trials
         const bool fin = has && !active;
+        dbg_refills++;
         if (fin) {
+            const float a = __uint_as_float(am1 + 1u);
             const uint32_t code = invalid ? 3u : (x >= a ? 1u : (x <= 0.0f ? 2u : 0u));
+            uint32_t tfix = (uint32_t)k;
+            if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = (int)tile & ring_mask;
-            res[(size_t)slot * N + trial] = (uint32_t)k | (code << 30);
+            res[(size_t)slot * N + trial] = tfix | (code << 30);
             if constexpr (T::HAS_Z) zres[(size_t)slot * N + trial] = zout;
             atomicAdd(&cnt[slot], 1);
             has = false;
@@ -239,11 +260,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         __syncthreads();
         // ------------------------------------------------------------ hand out new trials
         {
-            const unsigned long long want_mask = __ballot(!has);
+            const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(!has);
             const uint32_t g = next_g + lane_rank(want_mask);
             const uint32_t tl = g / (uint32_t)N;
             const bool ok = !has && g < G && (int)tl < flushed + ring;
-            const unsigned long long ok_mask = __ballot(ok);
+            const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(ok);
             next_g += (uint32_t)__popcll(ok_mask);
             if (ok) {
                 tile = tl;
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const unsigned long long gset = A.set_offset + (unsigned long long)(set0 + tl);
                 set_lo = (uint32_t)gset;
                 c3 = (uint32_t)(gset >> 32) & 0x0fffffffu;
-                float drift, beta, sig_c;
+                float drift, a, beta, sig_c;
                 invalid = false;
                 zout = 0.0f;
                 if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
@@ -282,29 +303,76 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                 }
                 mu_dt = drift * A.dt;
-                sig = A.sqrt_dt * sig_c;
+                const float sig = A.sqrt_dt * sig_c;
+                rscale = radius_scale<FAST>(sig);
+                if constexpr (BRIDGE) {
+                    cb = -2.0f / (sig * sig);
+                    if constexpr (FAST) cb = cb * 1.4426950408889634f;     // v_exp_f32 is 2^x
+                }
+                am1 = __float_as_uint(a) - 1u;
                 x = a * beta;
                 k = 0;
+                jit = 0;
                 has = true;
-                active = !invalid && (x > 0.0f) && (x < a) && (k < A.max_k);
+                active = !invalid && in_range(x, am1) && (0 < A.max_k);
             }
         }
         // ------------------------------------------------------------ step phase
         for (int it = 0; it < A.max_blocks; ++it) {
-            float z[4];
-            normals4<FAST>((uint32_t)k >> 2, trial, set_lo, c3, A.k0, A.k1, z);
+            dbg_blocks++;
+            const uint32_t blk = (uint32_t)k >> 2;
+            const u32x4 rb = philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
+            float inc[4];
+            {
+                float r, cs, sn;
+                polar_pair<FAST>(rb.x, rb.y, rscale, r, cs, sn);
+                inc[0] = __builtin_fmaf(r, cs, mu_dt);
+                inc[1] = __builtin_fmaf(r, sn, mu_dt);
+                polar_pair<FAST>(rb.z, rb.w, rscale, r, cs, sn);
+                inc[2] = __builtin_fmaf(r, cs, mu_dt);
+                inc[3] = __builtin_fmaf(r, sn, mu_dt);
+            }
+            uint32_t ub[4] = {0u, 0u, 0u, 0u};
+            if constexpr (BRIDGE) {
+                const u32x4 u4 = philox4x32_10(blk, trial, set_lo, c3 | 0x30000000u, A.k0, A.k1);   // stream 3
+                ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (active) {
-                    x = x + __builtin_fmaf(sig, z[j], mu_dt);
+                    float x1 = x + inc[j];
+                    if constexpr (BRIDGE) {
+                        if (in_range(x1, am1)) {
+                            const float a = __uint_as_float(am1 + 1u);
+                            const float eu = cb * ((a - x) * (a - x1));
+                            const float el = cb * (x * x1);
+                            float pu, pl;
+                            if constexpr (FAST) { pu = __builtin_amdgcn_exp2f(eu); pl = __builtin_amdgcn_exp2f(el); }
+                            else { pu = exact_expf_neg(eu); pl = exact_expf_neg(el); }
+                            const float uu = (float)(ub[j] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
+                            if (uu < pu) x1 = a;
+                            else if (uu >= 1.0f - pl) x1 = 0.0f;
+                        }
+                        jit = ub[j] & 0xffu;
+                    }
+                    x = x1;
                     k++;
-                    active = (x > 0.0f) && (x < a) && (k < A.max_k);
+                    if constexpr (CAP4) active = in_range(x, am1);
+                    else active = in_range(x, am1) && (k < A.max_k);
                 }
             }
-            const unsigned long long act_mask = __ballot(active);
-            const unsigned long long fin_mask = __ballot(has && !active);
+            if constexpr (CAP4) active = active && (k < A.max_k);
+            const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
+            const unsigned long long fin_mask = __builtin_amdgcn_ballot_w64(has && !active);
             if (act_mask == 0ull || __popcll(fin_mask) >= A.refill_thresh) break;
         }
+    }
+    if (A.dbg && lane == 0) {
+        atomicAdd(A.dbg + 0, dbg_blocks);
+        atomicAdd(A.dbg + 1, dbg_refills);
+        atomicAdd(A.dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
+        atomicAdd(A.dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0));
+        atomicAdd(A.dbg + 4, 1ull);
     }
 }
 
@@ -399,11 +467,15 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-template <int MODEL>
+template <int MODEL, bool BRIDGE>
 static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, hipStream_t st)
 {
-    if (fast) hipLaunchKernelGGL((sim_kernel<MODEL, true>), dim3(n_chunks), dim3(WAVE), lds_bytes, st, A);
-    else      hipLaunchKernelGGL((sim_kernel<MODEL, false>), dim3(n_chunks), dim3(WAVE), lds_bytes, st, A);
+    const bool cap4 = (A.max_k % 4) == 0;
+    const dim3 grid(n_chunks), block(WAVE);
+    if (fast && cap4)       hipLaunchKernelGGL((sim_kernel<MODEL, true, true, BRIDGE>), grid, block, lds_bytes, st, A);
+    else if (fast)          hipLaunchKernelGGL((sim_kernel<MODEL, true, false, BRIDGE>), grid, block, lds_bytes, st, A);
+    else if (cap4)          hipLaunchKernelGGL((sim_kernel<MODEL, false, true, BRIDGE>), grid, block, lds_bytes, st, A);
+    else                    hipLaunchKernelGGL((sim_kernel<MODEL, false, false, BRIDGE>), grid, block, lds_bytes, st, A);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return NDDM_OK;
@@ -411,6 +483,7 @@ static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chu
 
 struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks; };
 static Tuning g_tuning = {0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+static unsigned long long *g_dbg = nullptr;   // nddm_set_debug_counters (profiling aid)
 
 static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
                     int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
@@ -430,7 +503,11 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (B < 0 || n_trials <= 0 || max_steps < 0) return fail(NDDM_ERR_SHAPE, "B < 0, n_trials <= 0 or max_steps < 0%s");
     if (max_steps >= (1 << 30)) return fail(NDDM_ERR_SHAPE, "max_steps must be < 2^30%s");
     if (!(dt > 0.0f) || !isfinite(dt)) return fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
-    if (flags > 1u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
+    if (flags > 3u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
+    const bool bridge = (flags & NDDM_BRIDGE) != 0;
+    if (bridge && model != NDDM_ALPHA_NOT_SCALED)
+        return fail(NDDM_ERR_PARAM, "NDDM_BRIDGE is only available for NDDM_ALPHA_NOT_SCALED%s");
+    if (bridge && max_steps >= (1 << 22)) return fail(NDDM_ERR_SHAPE, "max_steps must be < 2^22 with NDDM_BRIDGE%s");
     if (B == 0) return NDDM_OK;
     if (!params) return fail(NDDM_ERR_NULL, "params is NULL%s");
     if (model == NDDM_EXPLICIT_BOUNDARY && !bounds) return fail(NDDM_ERR_NULL, "bounds is NULL%s");
@@ -440,8 +517,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     memset(&A, 0, sizeof A);
     A.params = params; A.bounds = bounds; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_ext;
     A.B = B; A.set_offset = set_offset; A.n_trials = n_trials; A.max_k = max_steps; A.dt = dt; A.sqrt_dt = sqrtf(dt);
+    A.tscale = bridge ? dt * 0.00390625f : dt;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
+    A.dbg = g_dbg;
 
     // geometry: ring slots so that >= ~4 wavefronts' worth of trials can be in flight per wave window
     int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((256 + n_trials - 1) / n_trials);
@@ -470,11 +549,13 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
     switch (model) {
-    case NDDM_BASIC_DDM_DC: return launch_model<NDDM_BASIC_DDM_DC>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_SINGLE_TRIAL: return launch_model<NDDM_SINGLE_TRIAL>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_SINGLE_TRIAL_ALT: return launch_model<NDDM_SINGLE_TRIAL_ALT>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_ALPHA_NOT_SCALED: return launch_model<NDDM_ALPHA_NOT_SCALED>(A, fast, lds, (int)n_chunks, st);
-    default: return launch_model<NDDM_EXPLICIT_BOUNDARY>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_BASIC_DDM_DC: return launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_SINGLE_TRIAL: return launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_SINGLE_TRIAL_ALT: return launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st);
+    case NDDM_ALPHA_NOT_SCALED:
+        return bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
+                      : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
+    default: return launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st);
     }
 }
 
@@ -519,6 +600,14 @@ int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blo
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
     nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks};
+    return NDDM_OK;
+}
+
+/* profiling aid: device u64[8], the next launches accumulate (step-loop blocks, refill phases, sum of per-wave
+ * s_memtime cycles, sum of per-wave s_memrealtime ticks (100 MHz), waves); NULL switches it off */
+int nddm_set_debug_counters(void *dev_u64x8)
+{
+    nddm::g_dbg = static_cast<unsigned long long *>(dev_u64x8);
     return NDDM_OK;
 }
 

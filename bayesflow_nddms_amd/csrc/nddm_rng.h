@@ -62,19 +62,18 @@ __device__ __forceinline__ float exact_logf(float u)
     return r;
 }
 
-// correctly rounded sqrt for s in [0, 46]: v_sqrt_f32 (<= 1 ulp) + one fma residual fix-up
+// correctly rounded sqrt for s >= 0: v_sqrt_f32 (<= 1 ulp) + one fma residual fix-up -- the scheme LLVM uses for
+// its IEEE f32 sqrt lowering.  +-0 comes back unchanged (NaN residuals compare false), as from an IEEE sqrt.
 __device__ __forceinline__ float exact_sqrtf(float s)
 {
     float r = __builtin_amdgcn_sqrtf(s);
-    // candidates one ulp below / above; pick by the sign of the fma residuals (the scheme LLVM
-    // uses for its IEEE f32 sqrt lowering).  s == 0 -> r == 0, residuals 0, r kept.
     const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
     const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
     const float e_dn = __builtin_fmaf(-r_dn, r, s);
     const float e_up = __builtin_fmaf(-r_up, r, s);
     r = (e_dn <= 0.0f) ? r_dn : r;
     r = (e_up > 0.0f) ? r_up : r;
-    return (s == 0.0f) ? 0.0f : r;
+    return r;
 }
 
 // sin, cos of 2*pi*x/2^32: quadrant from the integer, Cephes sinf/cosf kernels on [-pi/4, pi/4)
@@ -99,32 +98,63 @@ __device__ __forceinline__ void exact_sincos_turn(uint32_t x, float &sn, float &
     cs = ((q + 1u) & 2u) ? -b : b;
 }
 
-template <bool FAST>
-__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &z0, float &z1)
+// exp(x) for x <= 0, Cephes expf with every rounding spelled out; 0 below -87
+__device__ __forceinline__ float exact_expf_neg(float x)
 {
-    const float u = __builtin_fmaf((float)xa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    if (x < -87.0f) return 0.0f;
+    const float z = __builtin_floorf(__builtin_fmaf(1.44269504088896341f, x, 0.5f));
+    const int n = (int)z;
+    x = __builtin_fmaf(z, -0.693359375f, x);
+    x = __builtin_fmaf(z, 2.12194440e-4f, x);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, x, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, x, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, x, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, x, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, x, 5.0000001201e-1f);
+    p = __builtin_fmaf(p * x, x, x) + 1.0f;
+    return p * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+// Per-lane scale of the Gaussian radius: with sigma folded in, one Box-Muller pair is
+//   r = sqrt(scale * log(u)),  scale = -2 sigma^2      (exact: natural log; fast: v_log_f32 is log2, so scale *= ln 2)
+// and an Euler-Maruyama increment is fma(r, cos|sin, mu*dt): no separate multiply by sigma per step.
+template <bool FAST>
+__device__ __forceinline__ float radius_scale(float sigma)
+{
+    const float s2 = sigma * sigma;
+    return FAST ? -1.3862943611198906f * s2 : -2.0f * s2;
+}
+
+// (r, cos, sin) of one Box-Muller pair from two u32
+template <bool FAST>
+__device__ __forceinline__ void polar_pair(uint32_t xa, uint32_t xb, float scale, float &r, float &cs, float &sn)
+{
+    const float u = __builtin_fmaf((float)xa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);   // (0, 1]
     if constexpr (FAST) {
-        // -2 ln u = -2 ln2 * log2 u
-        const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);
-        const float ang = (float)xb * 2.3283064365386963e-10f;   // turns
-        z0 = r * __builtin_amdgcn_cosf(ang);
-        z1 = r * __builtin_amdgcn_sinf(ang);
+        r = __builtin_amdgcn_sqrtf(scale * __builtin_amdgcn_logf(u));
+        // v_sin/v_cos take turns and reduce the integer part themselves: feed [1, 2) built from the top 23 bits
+        const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, xb, 9u));   // 0x3f800000 | (xb >> 9)
+        cs = __builtin_amdgcn_cosf(ang);
+        sn = __builtin_amdgcn_sinf(ang);
     } else {
-        const float r = exact_sqrtf(-2.0f * exact_logf(u));
-        float sn, cs;
+        r = exact_sqrtf(scale * exact_logf(u));
         exact_sincos_turn(xb, sn, cs);
-        z0 = r * cs;
-        z1 = r * sn;
     }
 }
 
+// 4 standard normals of one Philox block
 template <bool FAST>
 __device__ __forceinline__ void normals4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                          uint32_t k0, uint32_t k1, float (&z)[4])
 {
     const u32x4 x = philox4x32_10(c0, c1, c2, c3, k0, k1);
-    box_muller<FAST>(x.x, x.y, z[0], z[1]);
-    box_muller<FAST>(x.z, x.w, z[2], z[3]);
+    const float sc = radius_scale<FAST>(1.0f);
+    float r, cs, sn;
+    polar_pair<FAST>(x.x, x.y, sc, r, cs, sn);
+    z[0] = r * cs; z[1] = r * sn;
+    polar_pair<FAST>(x.z, x.w, sc, r, cs, sn);
+    z[2] = r * cs; z[3] = r * sn;
 }
 
 // uniform in (0,1) from one u32 (prior sampler)

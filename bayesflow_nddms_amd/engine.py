@@ -91,7 +91,7 @@ def validate_params_host(model, params):
 
 
 def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
-             bounds=None, ext_sigma=0.0, ext_mode=0, want_trials=True, want_summary=True, want_ext=False,
+             bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, want_trials=True, want_summary=True, want_ext=False,
              out_trials=None, out_summary=None, stream_state=None, device=None):
     """Run one batched simulation on the current ROCm device.
 
@@ -149,7 +149,9 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     set_offset = int(set_offset) & 0xFFFFFFFFFFFFFFFF
     fast = DEFAULT_FAST if fast is None else bool(fast)
-    flags = _lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT
+    flags = (_lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT) | (_lib.BRIDGE if bridge else 0)
+    if bridge and model != ALPHA_NOT_SCALED:
+        raise ValueError("the Brownian-bridge correction is only available for the alpha_not_scaled model")
 
     with torch.cuda.device(dev):
         if want_trials and out_trials is None:

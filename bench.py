@@ -34,7 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # mode, from the ISA of sim_kernel<basic, fast> x the measured per-instruction issue cost (tools/ubench_valu)
 VALU_MODEL = {
     "clock_ghz": 2.4, "simds": 1024,
-    "cycles_per_block_fast": None, "cycles_per_block_exact": None,   # filled from profiles/ubench
+    # python tools/isa_mix.py: instruction mix of the step loop x per-instruction issue cost (profiles/r1_ubench_valu.txt)
+    "cycles_per_block_fast": 353.0, "cycles_per_block_exact": 625.0,
 }
 
 

@@ -67,7 +67,12 @@ enum nddm_status {
 
 enum nddm_flags {
     NDDM_GAUSS_EXACT = 0,     /* Box-Muller from IEEE add/mul/fma/sqrt only: bit-reproducible on a CPU (oracle) */
-    NDDM_GAUSS_FAST = 1       /* Box-Muller on v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 */
+    NDDM_GAUSS_FAST = 1,      /* Box-Muller on v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 */
+    NDDM_BRIDGE = 2           /* (alpha_not_scaled only) Brownian-bridge boundary correction: between two grid points
+                                 inside (0, a) the path crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt));
+                                 removes the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama against the exact
+                                 first-passage sampler the reference uses for this model (pyhddmjagsutils.py:47-176);
+                                 RTs get a uniform sub-step jitter, (k - U) dt, instead of k dt */
 };
 
 /* ---- library / device ------------------------------------------------------------- */

@@ -87,6 +87,27 @@ def test_alpha_not_scaled_em_vs_exact_sampler():
         assert ks[2] < ks[1] < ks[0] + 0.005, (si, ks)
 
 
+def test_alpha_not_scaled_bridge_vs_exact_sampler():
+    """Config 3 with the Brownian-bridge boundary correction (NDDM_BRIDGE): crossings between grid points are
+    sampled with their exact conditional probability, so the first-passage distribution matches the reference's
+    exact sampler simulratcliff (2e5 trials per set in tests/golden/ratcliff.npz; two-sample noise floor ~0.004) at
+    the BASELINE step dt=.001 -- tolerance KS < 0.01 like the other configs -- and already at dt=.004 to < 0.02."""
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("ratcliff.npz")
+    worst = {}
+    for dt, bar in ((0.001, 0.01), (0.004, 0.02)):
+        for si, p in enumerate(gold["sets"]):
+            for fast in (True, False):
+                r = engine.simulate(engine.ALPHA_NOT_SCALED, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=8.0 / dt,
+                                    seed=44, set_offset=si * 10000, fast=fast, bridge=True, want_summary=False)
+                y = r["trials"][..., 0].cpu().numpy().ravel()
+                ks = dg.ks_quantile_table(y, gold[f"yq_s{si}"])
+                worst[dt] = max(worst.get(dt, 0.0), ks)
+                assert ks < bar, (dt, si, fast, ks)
+                assert abs((y > 0).mean() - gold[f"pupper_s{si}"][0]) < 0.01
+    print("bridge KS vs simulratcliff:", worst)
+
+
 def test_device_prior_marginals():
     """On-device draw_prior vs 1e5 draws of the reference's draw_prior: KS per marginal < 0.01."""
     from bayesflow_nddms_amd import diagnostics as dg

@@ -26,7 +26,7 @@ def _params(model, B, seed):
     return p[:, [0, 2, 3, 4]]                 # drift, beta, ter, dc
 
 
-def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, **kw):
+def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, bridge=False, **kw):
     import oracle
     from bayesflow_nddms_amd import engine
     p = _params(model, B, 1234 + B)
@@ -35,9 +35,10 @@ def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, **kw):
         bounds = np.abs(np.random.default_rng(5).normal(1.2, 0.4, size=(B, N))).astype(np.float32)
     want_ext = model == "alpha_ns"
     g = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast,
-                        bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, **kw)
+                        bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, bridge=bridge, **kw)
     o = oracle.philox_simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset,
-                               bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, want_k=True, threads=8)
+                               bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, want_k=True, threads=8,
+                               bridge=bridge)
     g = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in g.items()}
     return p, g, o
 
@@ -71,6 +72,32 @@ def test_exact_mode_bit_parity(model, dt, max_steps):
     assert np.array_equal(np.nan_to_num(gs).view(np.uint32), np.nan_to_num(os_).view(np.uint32))
     if model == "alpha_ns":
         assert np.array_equal(g["ext"].view(np.uint32), o["ext"].view(np.uint32))
+
+
+@pytest.mark.parametrize("dt,max_steps", [(0.01, 400.0), (0.001, 4000.0), (0.004, 1001.0)])
+def test_bridge_mode_bit_parity(dt, max_steps):
+    """alpha_not_scaled with the Brownian-bridge boundary correction (exact exp, stream-3 uniforms, sub-step jitter):
+    trials, summaries and the per-set external datum equal the oracle's bit for bit."""
+    p, g, o = _run_both("alpha_ns", B=96, N=300, dt=dt, max_steps=max_steps, seed=77, bridge=True)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+    assert np.array_equal(g["ext"].view(np.uint32), o["ext"].view(np.uint32))
+    # jittered RTs are no longer on the dt grid, and they are earlier on average than plain Euler-Maruyama's
+    p2, g2, _ = _run_both("alpha_ns", B=96, N=300, dt=dt, max_steps=max_steps, seed=77, bridge=False)
+    rt, rt2 = np.abs(g["trials"][..., 0]), np.abs(g2["trials"][..., 0])
+    assert rt[rt > 0].mean() < rt2[rt2 > 0].mean()
+    from bayesflow_nddms_amd import engine
+    with pytest.raises(ValueError):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, bridge=True)
+
+
+@pytest.mark.parametrize("max_steps", [1.0, 2.0, 3.0, 5.0, 399.0, 401.0, 400.5])
+def test_step_caps_not_multiple_of_four(max_steps):
+    """The step cap is tested per Philox block when max_steps % 4 == 0 and per step otherwise: same semantics."""
+    p, g, o = _run_both("basic", B=40, N=100, dt=0.01, max_steps=max_steps, seed=3)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    k = np.rint((g["trials"][..., 0] - p[:, None, 3]) / 0.01)
+    assert k.max() <= np.ceil(max_steps)
 
 
 @pytest.mark.parametrize("N", [1, 3, 60, 63, 64, 65, 257, 300, 1000, 3000])
