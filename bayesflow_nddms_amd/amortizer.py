@@ -1,0 +1,273 @@
+"""Minimal PyTorch-ROCm stand-in for the BayesFlow objects the reference builds at basic_ddm_dc.py:163-176 and drives
+at :199-207, :223 (SURVEY f-4 / BASELINE config 5): a DeepSet summary network, a conditional affine-coupling flow, an
+amortized posterior, and a trainer with online and experience-replay loops that consume `generative_model(B)` ->
+`configurator(dict)` exactly as BayesFlow's Trainer does.
+
+    summary_net = InvariantNetwork()
+    inference_net = InvertibleNetwork(num_params=num_params)
+    amortizer = AmortizedPosterior(inference_net, summary_net)
+    trainer = Trainer(amortizer=amortizer, generative_model=generative_model, configurator=configurator,
+                      checkpoint_path=f"checkpoint/{model_name}")
+    losses = trainer.train_experience_replay(epochs=…, batch_size=32, iterations_per_epoch=1000)
+    post = amortizer.sample(configurator(generative_model(1)), n_samples=10000)
+
+BayesFlow/TensorFlow are not installable here, so parity with BayesFlow's networks is UNPINNED; what is pinned is
+the dictionary contract on both sides ('summary_conditions', 'direct_conditions', 'parameters').  This module is
+plain PyTorch (no custom kernels): the data-parallel hot path of the repository is the simulator that feeds it.
+"""
+import math
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def _mlp(d_in, d_hidden, d_out, n_hidden=2, act=nn.ReLU):
+    layers, d = [], d_in
+    for _ in range(n_hidden):
+        layers += [nn.Linear(d, d_hidden), act()]
+        d = d_hidden
+    layers.append(nn.Linear(d, d_out))
+    return nn.Sequential(*layers)
+
+
+class _Equivariant(nn.Module):
+    """x[b,n,:] -> f(x[b,n,:], mean_n g(x[b,n,:])): permutation-equivariant DeepSet block."""
+
+    def __init__(self, d_in, d_hidden):
+        super().__init__()
+        self.inv = _mlp(d_in, d_hidden, d_hidden)
+        self.eq = _mlp(d_in + d_hidden, d_hidden, d_hidden)
+
+    def forward(self, x):
+        pooled = self.inv(x).mean(dim=1, keepdim=True).expand(-1, x.shape[1], -1)
+        return self.eq(torch.cat([x, pooled], dim=-1))
+
+
+class InvariantNetwork(nn.Module):
+    """bf.networks.InvariantNetwork(): exchangeable trials [B, N, D] -> learned summary [B, summary_dim]."""
+
+    def __init__(self, input_dim=2, summary_dim=10, hidden=64, num_equiv=2):
+        super().__init__()
+        blocks, d = [], input_dim
+        for _ in range(num_equiv):
+            blocks.append(_Equivariant(d, hidden))
+            d = hidden
+        self.equiv = nn.Sequential(*blocks)
+        self.pre_pool = _mlp(d, hidden, hidden)
+        self.post_pool = _mlp(hidden, hidden, summary_dim)
+        self.summary_dim = summary_dim
+
+    def forward(self, x):
+        return self.post_pool(self.pre_pool(self.equiv(x)).mean(dim=1))
+
+
+class _AffineCoupling(nn.Module):
+    def __init__(self, dim, cond_dim, hidden, clamp=1.9):
+        super().__init__()
+        self.d1 = dim // 2
+        self.d2 = dim - self.d1
+        self.clamp = clamp
+        self.net1 = _mlp(self.d1 + cond_dim, hidden, 2 * self.d2, act=nn.ELU)
+        self.net2 = _mlp(self.d2 + cond_dim, hidden, 2 * self.d1, act=nn.ELU)
+
+    def _st(self, net, h, cond):
+        s, t = net(torch.cat([h, cond], dim=-1)).chunk(2, dim=-1)
+        return self.clamp * torch.tanh(s / self.clamp), t
+
+    def forward(self, x, cond):
+        x1, x2 = x[:, :self.d1], x[:, self.d1:]
+        s, t = self._st(self.net1, x1, cond)
+        y2 = x2 * torch.exp(s) + t
+        ld = s.sum(-1)
+        s, t = self._st(self.net2, y2, cond)
+        y1 = x1 * torch.exp(s) + t
+        return torch.cat([y1, y2], dim=-1), ld + s.sum(-1)
+
+    def inverse(self, y, cond):
+        y1, y2 = y[:, :self.d1], y[:, self.d1:]
+        s, t = self._st(self.net2, y2, cond)
+        x1 = (y1 - t) * torch.exp(-s)
+        s, t = self._st(self.net1, x1, cond)
+        x2 = (y2 - t) * torch.exp(-s)
+        return torch.cat([x1, x2], dim=-1)
+
+
+class InvertibleNetwork(nn.Module):
+    """bf.networks.InvertibleNetwork(num_params): conditional normalising flow of affine coupling layers with fixed
+    permutations and a learnable ActNorm in front of each."""
+
+    def __init__(self, num_params, cond_dim=11, num_coupling_layers=6, hidden=128, seed=0):
+        super().__init__()
+        self.num_params = num_params
+        self.layers = nn.ModuleList(_AffineCoupling(num_params, cond_dim, hidden) for _ in range(num_coupling_layers))
+        g = torch.Generator().manual_seed(seed)
+        for i in range(num_coupling_layers):
+            self.register_buffer(f"perm{i}", torch.randperm(num_params, generator=g))
+        self.an_scale = nn.Parameter(torch.zeros(num_coupling_layers, num_params))
+        self.an_bias = nn.Parameter(torch.zeros(num_coupling_layers, num_params))
+
+    def forward(self, theta, cond):
+        z, log_det = theta, theta.new_zeros(theta.shape[0])
+        for i, layer in enumerate(self.layers):
+            z = z * torch.exp(self.an_scale[i]) + self.an_bias[i]
+            log_det = log_det + self.an_scale[i].sum()
+            z = z[:, getattr(self, f"perm{i}")]
+            z, ld = layer(z, cond)
+            log_det = log_det + ld
+        return z, log_det
+
+    def inverse(self, z, cond):
+        x = z
+        for i in reversed(range(len(self.layers))):
+            x = self.layers[i].inverse(x, cond)
+            x = x[:, torch.argsort(getattr(self, f"perm{i}"))]
+            x = (x - self.an_bias[i]) * torch.exp(-self.an_scale[i])
+        return x
+
+
+class AmortizedPosterior(nn.Module):
+    """bf.amortizers.AmortizedPosterior(inference_net, summary_net): maximum-likelihood training of q(theta | data)."""
+
+    def __init__(self, inference_net, summary_net):
+        super().__init__()
+        self.inference_net, self.summary_net = inference_net, summary_net
+
+    def _t(self, v):
+        dev = next(self.parameters()).device
+        return v.to(dev, torch.float32) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev)
+
+    def _conditions(self, input_dict):
+        summ = self.summary_net(self._t(input_dict["summary_conditions"]))
+        direct = input_dict.get("direct_conditions", None)
+        return summ if direct is None else torch.cat([summ, self._t(direct)], dim=-1)
+
+    def forward(self, input_dict):
+        return self.inference_net(self._t(input_dict["parameters"]), self._conditions(input_dict))
+
+    def compute_loss(self, input_dict):
+        z, log_det = self(input_dict)
+        return (0.5 * (z ** 2).sum(-1) - log_det).mean()
+
+    @torch.no_grad()
+    def sample(self, input_dict, n_samples, to_numpy=True):
+        """amortizer.sample(dict, n_samples) (basic_ddm_dc.py:223): [n_samples, P] for a single data set,
+        [B, n_samples, P] for a batch."""
+        cond = self._conditions(input_dict)
+        B = cond.shape[0]
+        z = torch.randn(B * n_samples, self.inference_net.num_params, device=cond.device)
+        out = self.inference_net.inverse(z, cond.repeat_interleave(n_samples, dim=0))
+        out = out.reshape(B, n_samples, -1)
+        if B == 1:
+            out = out[0]
+        return out.cpu().numpy() if to_numpy else out
+
+
+class Trainer:
+    """bf.trainers.Trainer(amortizer, generative_model, configurator, checkpoint_path): online and experience-replay
+    training (basic_ddm_dc.py:172-176, 199-202), `load_pretrained_network` (:207).  Checkpoints also carry the
+    simulator's (seed, offset) stream state, so a resumed run continues the random stream."""
+
+    def __init__(self, amortizer, generative_model, configurator=None, checkpoint_path=None, learning_rate=5e-4,
+                 device=None, stream_state=None):
+        self.amortizer, self.generative_model = amortizer, generative_model
+        self.configurator = configurator or (lambda d: d)
+        self.checkpoint_path = checkpoint_path
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self.amortizer.to(self.device)
+        self.lr = learning_rate
+        self.optimizer = torch.optim.Adam(self.amortizer.parameters(), lr=learning_rate)
+        self.scheduler = None
+        self.stream_state = stream_state
+        self.loss_history = []
+        self.replay = []
+
+    def _simulate(self, batch_size):
+        return self.configurator(self.generative_model(batch_size))
+
+    def _step(self, conf):
+        loss = self.amortizer.compute_loss(conf)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.amortizer.parameters(), 5.0)
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return float(loss.detach())
+
+    def _setup_schedule(self, total_steps):
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=max(1, total_steps))
+
+    def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, **_):
+        self._setup_schedule(epochs * iterations_per_epoch)
+        for ep in range(epochs):
+            for _ in range(iterations_per_epoch):
+                self.loss_history.append(self._step(self._simulate(batch_size)))
+            if save_checkpoint:
+                self.save_checkpoint()
+        return self.loss_history
+
+    def train_experience_replay(self, epochs, iterations_per_epoch, batch_size, capacity_in_batches=100,
+                                save_checkpoint=True, validation_sims=None, **_):
+        """Each iteration simulates one fresh batch into a ring buffer of `capacity_in_batches` batches and trains on
+        a randomly chosen stored batch (BayesFlow's experience replay, used at basic_ddm_dc.py:199-202).  Batches keep
+        their own N (the non-batchable context), as in BayesFlow's buffer."""
+        self._setup_schedule(epochs * iterations_per_epoch)
+        rng = np.random.default_rng(0)
+        val = []
+        for ep in range(epochs):
+            for _ in range(iterations_per_epoch):
+                conf = self._simulate(batch_size)
+                if len(self.replay) < capacity_in_batches:
+                    self.replay.append(conf)
+                else:
+                    self.replay[rng.integers(capacity_in_batches)] = conf
+                self.loss_history.append(self._step(self.replay[rng.integers(len(self.replay))]))
+            if validation_sims is not None:
+                with torch.no_grad():
+                    val.append(float(self.amortizer.compute_loss(self.configurator(validation_sims))))
+            if save_checkpoint:
+                self.save_checkpoint()
+        return {"train_losses": self.loss_history, "val_losses": val}
+
+    # ---- checkpoint / resume -----------------------------------------------------------------------
+    def save_checkpoint(self):
+        if not self.checkpoint_path:
+            return
+        os.makedirs(self.checkpoint_path, exist_ok=True)
+        state = {"model": self.amortizer.state_dict(), "optimizer": self.optimizer.state_dict(),
+                 "loss_history": self.loss_history}
+        if self.stream_state is not None:
+            state["stream_state"] = self.stream_state.get_state()
+        torch.save(state, os.path.join(self.checkpoint_path, "ckpt.pt"))
+        with open(os.path.join(self.checkpoint_path, "history.pkl"), "wb") as f:
+            pickle.dump({"loss_history": self.loss_history}, f)
+
+    def load_pretrained_network(self):
+        path = os.path.join(self.checkpoint_path or "", "ckpt.pt")
+        if not os.path.exists(path):
+            return False
+        state = torch.load(path, map_location=self.device)
+        self.amortizer.load_state_dict(state["model"])
+        self.optimizer.load_state_dict(state["optimizer"])
+        self.loss_history = list(state.get("loss_history", []))
+        if self.stream_state is not None and "stream_state" in state:
+            self.stream_state.set_state(state["stream_state"])
+        return True
+
+
+def posterior_recovery(amortizer, generative_model, configurator, n_datasets=100, n_samples=1000):
+    """The recovery loop of basic_ddm_dc.py:218-223 in miniature: posterior means vs true parameters -> per-parameter
+    Pearson correlation (the reference plots R^2 / rho, pyhddmjagsutils.py:609-623)."""
+    true, means = [], []
+    for _ in range(n_datasets):
+        conf = configurator(generative_model(1))
+        post = amortizer.sample(conf, n_samples)
+        p = conf["parameters"]
+        true.append((p.cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p))[0])
+        means.append(post.mean(axis=0))
+    true, means = np.array(true), np.array(means)
+    return np.array([np.corrcoef(true[:, j], means[:, j])[0, 1] for j in range(true.shape[1])])
