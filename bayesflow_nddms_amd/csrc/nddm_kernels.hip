@@ -6,12 +6,13 @@
 //   alpha_not_scaled.py:52-128 generator recast as an Euler-Maruyama process.
 //
 // Execution design:
-//   * one 64-lane wavefront per workgroup; a wavefront owns a CHUNK of consecutive parameter
-//     sets whose raw parameters it stages in LDS once.
+//   * one 64-lane wavefront per workgroup, PERSISTENT grid (as many waves as stay resident);
+//     a wave pulls CHUNKS of consecutive parameter sets from a device-wide atomic counter and
+//     streams through them without draining between chunks.
 //   * one lane = one trial at a time.  Trial length is heavy-tailed (median 107, p99 2243
 //     steps at dt=.001), so lanes are PERSISTENT: a lane whose trial has ended retires it and
-//     takes the next unassigned (set, trial) of the chunk in order (wave ballot + prefix
-//     count), instead of idling until the slowest trial of its set ends.
+//     takes the next unassigned (set, trial) of the wave's stream in order (wave ballot +
+//     prefix count), instead of idling until the slowest trial of its set ends.
 //   * results are staged in an LDS ring of per-set slots as packed (step index | choice);
 //     when the last trial of a set retires the wave FLUSHES the slot: one coalesced float2
 //     store sweep to HBM plus the fused per-set summary reduction (integer sums reduced
@@ -24,6 +25,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "../../include/nddm.h"
 #include "nddm_rng.h"
@@ -55,6 +58,8 @@ struct SimArgs {
     float tscale;             // seconds per unit of the packed time field: dt, or dt/256 with the bridge correction
     uint32_t k0, k1;
     int sets_per_chunk;
+    int n_chunks;
+    unsigned int *chunk_counter;   // device word, zeroed before the launch: the next chunk to hand out
     int ring;                 // LDS ring slots (power of two)
     float ext_sigma;
     int ext_mode;
@@ -192,7 +197,9 @@ __device__ __forceinline__ bool in_range(float x, uint32_t a_bits_m1)
 // points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
 // the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
 // generator is an exact first-passage sampler.
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE>
+// KEYS_V (Philox round keys in VGPRs): measured neutral on MI355X -- the ~35 issue cycles it saves per block are
+// paid back by the drop from 7 to 5 resident waves per SIMD -- so it stays off.
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool KEYS_V = false>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -201,76 +208,113 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     const int lane = threadIdx.x;
     const int N = A.n_trials;
-    const long long set0 = (long long)blockIdx.x * A.sets_per_chunk;      // first set of this wave's chunk (in-call index)
-    const long long rem_sets = A.B - set0;
-    const int nsets = (int)(rem_sets < A.sets_per_chunk ? rem_sets : A.sets_per_chunk);
-    const uint32_t G = (uint32_t)nsets * (uint32_t)N;                    // trials of the chunk
     const int ring = A.ring, ring_mask = A.ring - 1;
 
-    // LDS carve-up: raw parameter rows | per-slot retire counters | packed results | z column
+    // LDS carve-up, one ring slot per in-flight parameter set ("tile"):
+    //   raw parameter row | in-call set index | retire counter | packed results | z column
     float *lp = reinterpret_cast<float *>(lds_raw);
-    int *cnt = reinterpret_cast<int *>(lp + A.sets_per_chunk * P);
+    int *slot_set = reinterpret_cast<int *>(lp + ring * P);
+    int *cnt = slot_set + ring;
     uint32_t *res = reinterpret_cast<uint32_t *>(cnt + ring);
     float *zres = reinterpret_cast<float *>(res + (size_t)ring * N);
-
-    for (int i = lane; i < nsets * P; i += WAVE) lp[i] = A.params[set0 * P + i];
-    for (int i = lane; i < ring; i += WAVE) cnt[i] = 0;
-    __syncthreads();
 
     // per-lane trial state
     float x = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;
     uint32_t am1 = 0;        // bits(boundary) - 1
     int k = 0;
-    uint32_t trial = 0, tile = 0, set_lo = 0, c3 = 0, jit = 0;
+    uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;
+    int tile = 0;            // wave-local sequence number of the set this lane works on
     bool has = false, active = false, invalid = false;
 
-    uint32_t next_g = 0;     // wave-uniform: next unassigned trial of the chunk
-    int flushed = 0;         // wave-uniform: sets already flushed (flushes are in order)
+    // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
+    int tile_open = 0;       // tiles whose parameters are staged in LDS
+    int flushed = 0;         // tiles already flushed
+    int next_tile = 0, next_trial = 0;            // next unassigned trial of the wave's stream
+    unsigned long long retired = 0;               // trials retired so far
+    unsigned long long gate = (unsigned long long)N;   // the oldest tile cannot be complete before retired >= gate
+    int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left
+    bool more = true;                             // chunks may remain in the global queue
     unsigned long long dbg_blocks = 0, dbg_refills = 0, dbg_t0 = 0, dbg_r0 = 0;
     if (A.dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // open tiles while ring slots are free: fetch chunk ids dynamically, stage the parameter row of each new tile
+    auto open_tiles = [&]() {
+        while (tile_open < flushed + ring) {
+            if (chunk_left == 0) {
+                if (!more) break;
+                unsigned int c = 0;
+                if (lane == 0) c = atomicAdd(A.chunk_counter, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= (unsigned int)A.n_chunks) { more = false; break; }
+                chunk_set = (int)c * A.sets_per_chunk;
+                const long long left = A.B - (long long)chunk_set;
+                chunk_left = (int)(left < A.sets_per_chunk ? left : A.sets_per_chunk);
+            }
+            const int slot = tile_open & ring_mask;
+            if (lane < P) lp[slot * P + lane] = A.params[(long long)chunk_set * P + lane];
+            if (lane == 0) { slot_set[slot] = chunk_set; cnt[slot] = 0; }
+            chunk_set++; chunk_left--; tile_open++;
+        }
+    };
+    open_tiles();
+    __syncthreads();
+
+    PhiloxKeys PK;
+    if constexpr (KEYS_V) PK.init(A.k0, A.k1);
 
     while (true) {
         // ------------------------------------------------------------ retire finished trials
         const bool fin = has && !active;
+        const unsigned long long fin_mask0 = __builtin_amdgcn_ballot_w64(fin);
         dbg_refills++;
         if (fin) {
             const float a = __uint_as_float(am1 + 1u);
             const uint32_t code = invalid ? 3u : (x >= a ? 1u : (x <= 0.0f ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
-            const int slot = (int)tile & ring_mask;
+            const int slot = tile & ring_mask;
             res[(size_t)slot * N + trial] = tfix | (code << 30);
             if constexpr (T::HAS_Z) zres[(size_t)slot * N + trial] = zout;
             atomicAdd(&cnt[slot], 1);
             has = false;
         }
-        __syncthreads();
-        // ------------------------------------------------------------ flush complete sets, in order
-        while (flushed < nsets) {
-            const int slot = flushed & ring_mask;
-            const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
-            if (c != N) break;
-            flush_set<MODEL, FAST>(A, lane, set0 + flushed, lp + flushed * P, res + (size_t)slot * N,
-                                   zres + (size_t)slot * N);
+        retired += (unsigned long long)__popcll(fin_mask0);
+        // ------------------------------------------------------------ flush complete sets, in order (rare path:
+        // only entered when enough trials have retired for the oldest tile to possibly be complete)
+        if (retired >= gate) {
             __syncthreads();
-            if (lane == 0) cnt[slot] = 0;
-            flushed++;
+            while (flushed < tile_open) {
+                const int slot = flushed & ring_mask;
+                const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
+                if (c != N) break;
+                const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
+                flush_set<MODEL, FAST>(A, lane, (long long)set_in_call, lp + slot * P, res + (size_t)slot * N,
+                                       zres + (size_t)slot * N);
+                flushed++;
+                gate += (unsigned long long)N;
+            }
+            __syncthreads();
+            open_tiles();
+            __syncthreads();
         }
-        if (flushed == nsets) break;
-        __syncthreads();
+        if (flushed == tile_open && !more && chunk_left == 0) break;
         // ------------------------------------------------------------ hand out new trials
         {
             const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(!has);
-            const uint32_t g = next_g + lane_rank(want_mask);
-            const uint32_t tl = g / (uint32_t)N;
-            const bool ok = !has && g < G && (int)tl < flushed + ring;
+            int tr = next_trial + (int)lane_rank(want_mask);
+            int tl = next_tile;
+            while (tr >= N) { tr -= N; tl++; }
+            const bool ok = !has && tl < tile_open;
             const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(ok);
-            next_g += (uint32_t)__popcll(ok_mask);
+            next_trial += (int)__popcll(ok_mask);
+            while (next_trial >= N) { next_trial -= N; next_tile++; }
             if (ok) {
                 tile = tl;
-                trial = g - tl * (uint32_t)N;
-                const float *pp = lp + tl * P;
-                const unsigned long long gset = A.set_offset + (unsigned long long)(set0 + tl);
+                trial = (uint32_t)tr;
+                const int slot = tl & ring_mask;
+                const float *pp = lp + slot * P;
+                const long long set_in_call = (long long)slot_set[slot];
+                const unsigned long long gset = A.set_offset + (unsigned long long)set_in_call;
                 set_lo = (uint32_t)gset;
                 c3 = (uint32_t)(gset >> 32) & 0x0fffffffu;
                 float drift, a, beta, sig_c;
@@ -298,7 +342,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     a = pp[1]; beta = pp[2]; sig_c = pp[5];
                 } else {   // NDDM_EXPLICIT_BOUNDARY
                     drift = pp[0]; beta = pp[1]; sig_c = pp[3];
-                    a = A.bounds[(set0 + tl) * N + trial];
+                    a = A.bounds[set_in_call * N + trial];
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                 }
@@ -321,7 +365,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
             const uint32_t blk = (uint32_t)k >> 2;
-            const u32x4 rb = philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
+            const u32x4 rb = KEYS_V ? philox4x32_10(blk, trial, set_lo, c3, PK) : philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
             float inc[4];
             {
                 float r, cs, sn;
@@ -340,6 +384,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (active) {
+                    // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
+                    // each on gfx950) cost more VALU issue than the predicated add / count they would replace
+                    asm volatile("" ::: "memory");
                     float x1 = x + inc[j];
                     if constexpr (BRIDGE) {
                         if (in_range(x1, am1)) {
@@ -467,22 +514,49 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves; };
+static Tuning g_tuning = {0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+// resident waves of a kernel instantiation on the current device (persistent grid size)
+template <typename K>
+static int resident_waves(K kernel, size_t lds_bytes)
+{
+    int dev = 0, cus = 256, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        static thread_local int cached_dev = -1, cached_cus = 0;
+        if (cached_dev != dev) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { cached_cus = prop.multiProcessorCount; cached_dev = dev; }
+        }
+        if (cached_cus > 0) cus = cached_cus;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds_bytes) != hipSuccess || per_cu < 1)
+        per_cu = 8;
+    if (per_cu > 32) per_cu = 32;
+    return cus * per_cu;
+}
+
 template <int MODEL, bool BRIDGE>
 static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, hipStream_t st)
 {
     const bool cap4 = (A.max_k % 4) == 0;
-    const dim3 grid(n_chunks), block(WAVE);
-    if (fast && cap4)       hipLaunchKernelGGL((sim_kernel<MODEL, true, true, BRIDGE>), grid, block, lds_bytes, st, A);
-    else if (fast)          hipLaunchKernelGGL((sim_kernel<MODEL, true, false, BRIDGE>), grid, block, lds_bytes, st, A);
-    else if (cap4)          hipLaunchKernelGGL((sim_kernel<MODEL, false, true, BRIDGE>), grid, block, lds_bytes, st, A);
-    else                    hipLaunchKernelGGL((sim_kernel<MODEL, false, false, BRIDGE>), grid, block, lds_bytes, st, A);
+    const dim3 block(WAVE);
+    const int over = g_tuning.grid_waves;   // 0 = as many waves as stay resident
+#define NDDM_LAUNCH(KERNEL)                                                                    \
+    do {                                                                                       \
+        int waves = over > 0 ? over : resident_waves(KERNEL, lds_bytes);                       \
+        if (waves > n_chunks) waves = n_chunks;                                                \
+        hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
+    } while (0)
+    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE>));
+    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE>));
+    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE>));
+    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE>));
+#undef NDDM_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return NDDM_OK;
 }
 
-struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks; };
-static Tuning g_tuning = {0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
 static unsigned long long *g_dbg = nullptr;   // nddm_set_debug_counters (profiling aid)
 
 static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
@@ -530,23 +604,40 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     while (ring > 2 && (size_t)ring * n_trials * per_trial > 40 * 1024) ring >>= 1;
     if ((size_t)ring * n_trials * per_trial > 60 * 1024)
         return fail(NDDM_ERR_SHAPE, "n_trials too large for one launch (LDS ring); split the call%s");
-    // chunk: enough trials per wave to amortise the tail, but many more chunks than resident waves
+    // chunk = the unit a wave pulls from the global queue: small (tail of the whole launch <= one chunk), but large
+    // enough that the queue's atomic counter is touched rarely (~ once per 2400+ trials per wave)
     int spc = g_tuning.sets_per_chunk;
     if (!spc) {
-        long long want = (9600 + n_trials - 1) / n_trials;          // ~150 trials per lane
-        long long cap = B / 8192 > 0 ? B / 8192 : 1;                 // keep >= 8192 chunks when B allows
-        spc = (int)(want < cap ? want : cap);
+        spc = (2400 + n_trials - 1) / n_trials;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
     }
-    if ((long long)spc * n_trials >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "chunk too large%s");
+    if (B >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "B must be < 2^31 per launch%s");
     A.sets_per_chunk = spc; A.ring = ring;
     A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : 8;
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (B + spc - 1) / spc;
-    if (n_chunks > 0x7fffffffll) return fail(NDDM_ERR_SHAPE, "too many chunks for one launch%s");
-    const size_t lds = (size_t)spc * P * 4 + (size_t)ring * 4 + (size_t)ring * n_trials * per_trial;
+    A.n_chunks = (int)n_chunks;
+    const size_t lds = (size_t)ring * (P * 4 + 8) + (size_t)ring * n_trials * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // one queue word per launch from a small per-device pool, zeroed on the launch's stream
+    {
+        static std::mutex mu;
+        static unsigned int *pool[64] = {nullptr};
+        static unsigned int next[64] = {0};
+        constexpr unsigned int POOL = 4096;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess || dev < 0 || dev >= 64) return fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+        std::lock_guard<std::mutex> lock(mu);
+        if (!pool[dev]) {
+            e = hipMalloc(reinterpret_cast<void **>(&pool[dev]), POOL * sizeof(unsigned int));
+            if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(queue words): %s", hipGetErrorString(e));
+        }
+        A.chunk_counter = pool[dev] + (next[dev]++ % POOL);
+        e = hipMemsetAsync(A.chunk_counter, 0, sizeof(unsigned int), st);
+        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMemsetAsync(queue word): %s", hipGetErrorString(e));
+    }
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
     switch (model) {
     case NDDM_BASIC_DDM_DC: return launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st);
@@ -596,10 +687,10 @@ int nddm_set_device(int device)
 }
 
 /* benchmarking aid (not part of the drop-in surface): 0 = automatic */
-int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks)
+int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves)
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
-    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks};
+    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves};
     return NDDM_OK;
 }
 

@@ -117,12 +117,12 @@ def test_geometry_independence():
     p = prior_util.basic_prior(300, 99)
     base = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
     try:
-        for tune in [(1, 2, 1, 1), (7, 4, 64, 3), (64, 64, 8, 16), (3, 8, 200, 2)]:
+        for tune in [(1, 2, 1, 1, 1), (7, 4, 64, 3, 5), (64, 64, 8, 16, 0), (3, 8, 200, 2, 1000), (1, 4, 8, 16, 64)]:
             _lib.check(_lib.lib().nddm_set_tuning(*tune))
             t = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
             assert np.array_equal(t.view(np.uint32), base.view(np.uint32)), tune
     finally:
-        _lib.lib().nddm_set_tuning(0, 0, 0, 0)
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0)
     parts = [engine.simulate(0, p[a:b], 180, dt=0.01, max_steps=400, seed=5, set_offset=1000 + a, fast=False)["trials"].cpu().numpy()
              for a, b in [(0, 75), (75, 150), (150, 151), (151, 300)]]
     assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))

@@ -21,7 +21,14 @@ COST = {"v_mad_u64_u32": 4.67, "v_xor_b32": 2.32, "v_cvt_f32_u32": 4.12, "v_cvt_
         "v_lshrrev_b32": 2.32, "v_lshlrev_b32": 2.32, "v_and_b32": 2.32, "v_or_b32": 2.32, "v_alignbit_b32": 2.32,
         "v_cndmask_b32": 2.32, "v_add3_u32": 2.35, "v_mov_b32": 2.32, "v_cmp": 4.13, "v_mul_lo_u32": 4.23,
         "v_mul_hi_u32": 4.26, "v_bfe_u32": 2.32, "v_and_or_b32": 2.32, "v_floor_f32": 2.3, "v_cvt_i32_f32": 4.12,
-        "v_lshl_add_u32": 2.35, "v_addc_co_u32": 2.35, "v_max_f32": 2.26, "v_min_f32": 2.26, "v_med3_f32": 3.77}
+        "v_lshl_add_u32": 4.2, "v_addc_co_u32": 4.2, "v_max_f32": 2.26, "v_min_f32": 2.26, "v_med3_f32": 3.77}
+# measured: a VOP2 integer/float op that reads an SGPR (or VCC) operand, and the 3-operand integer VOP3 forms, issue at
+# ~4.2 cycles instead of ~2.3 (profiles/r1_ubench_valu.txt rows "v_xor_b32 (sgpr)", v_add3_u32, v_alignbit_b32,
+# "v_cndmask_e64 (s)")
+COST.update({"v_add3_u32": 4.22, "v_alignbit_b32": 4.15, "v_cndmask_b32": 4.22})
+SGPR_OPERAND_COST = 4.16
+FULL_RATE = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_add_f32", "v_sub_f32",
+             "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"}
 DEFAULT = 2.4
 
 
@@ -58,12 +65,16 @@ def main():
         if op.startswith("v_cmp"):
             op = "v_cmp"
         op = re.sub(r"_e(32|64)$", "", op)
+        if op in FULL_RATE and re.search(r"\bs\d+\b|s\[|vcc|exec", " ".join(t[2:])):
+            op = op + " (sgpr)"
         tally[op] += 1
     valu = {k: v for k, v in tally.items() if k.startswith("v_")}
-    cyc = sum(COST.get(k, DEFAULT) * v for k, v in valu.items())
+    def cost(k):
+        return SGPR_OPERAND_COST if k.endswith(" (sgpr)") else COST.get(k, DEFAULT)
+    cyc = sum(cost(k) * v for k, v in valu.items())
     print(f"kernel {want}: innermost step loop = {len(best)} lines")
-    for k, v in sorted(valu.items(), key=lambda kv: -COST.get(kv[0], DEFAULT) * kv[1]):
-        print(f"  {k:18s} x{v:3d}  {COST.get(k, DEFAULT):5.2f} cyc  = {COST.get(k, DEFAULT) * v:7.1f}" + ("" if k in COST else "   (default cost)"))
+    for k, v in sorted(valu.items(), key=lambda kv: -cost(kv[0]) * kv[1]):
+        print(f"  {k:22s} x{v:3d}  {cost(k):5.2f} cyc  = {cost(k) * v:7.1f}" + ("" if (k in COST or k.endswith(" (sgpr)")) else "   (default cost)"))
     print(f"VALU instructions per block: {sum(valu.values())}; SALU: {sum(v for k, v in tally.items() if k.startswith('s_'))}")
     print(f"VALU issue cycles per wave64 block (4 steps x 64 lanes): {cyc:.0f}")
     print(f"ceiling at 2.4 GHz x 1024 SIMDs: {1024 * 2.4e9 / cyc * 256 / 1e12:.3f} T E-M steps/s")

@@ -65,6 +65,32 @@ DEF_KERNEL(k_sin, F8, OP8_1("v_sin_f32"), SINKF)
 DEF_KERNEL(k_cos, F8, OP8_1("v_cos_f32"), SINKF)
 DEF_KERNEL(k_rcp, F8, OP8_1("v_rcp_f32"), SINKF)
 DEF_KERNEL(k_cvt_f32_u32, F8, OP8_1("v_cvt_f32_u32"), SINKF)
+#define OP8_S(INS, SV) \
+    asm volatile(INS " %0, %1, %0" : "+v"(a0) : "s"(SV)); asm volatile(INS " %0, %1, %0" : "+v"(a1) : "s"(SV)); \
+    asm volatile(INS " %0, %1, %0" : "+v"(a2) : "s"(SV)); asm volatile(INS " %0, %1, %0" : "+v"(a3) : "s"(SV)); \
+    asm volatile(INS " %0, %1, %0" : "+v"(a4) : "s"(SV)); asm volatile(INS " %0, %1, %0" : "+v"(a5) : "s"(SV)); \
+    asm volatile(INS " %0, %1, %0" : "+v"(a6) : "s"(SV)); asm volatile(INS " %0, %1, %0" : "+v"(a7) : "s"(SV));
+#define OP8_3(INS) \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a0) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a2) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a6) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a7) : "v"(c));
+#define OP8_ALIGN \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a0) : "s"(sk)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a1) : "s"(sk)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a2) : "s"(sk)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a3) : "s"(sk)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a4) : "s"(sk)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a5) : "s"(sk)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a6) : "s"(sk)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a7) : "s"(sk));
+#define OP8_CNDS \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a0) : "v"(c), "s"(sm)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a1) : "v"(c), "s"(sm)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a2) : "v"(c), "s"(sm)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a3) : "v"(c), "s"(sm)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a4) : "v"(c), "s"(sm)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a5) : "v"(c), "s"(sm)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a6) : "v"(c), "s"(sm)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a7) : "v"(c), "s"(sm));
+#define US8 U8; uint32_t sk = __builtin_amdgcn_readfirstlane(blockIdx.x * 2654435761u + 12345u); unsigned long long sm = __builtin_amdgcn_readfirstlane(blockIdx.x) * 0x9E3779B97F4A7C15ull + 77ull
+DEF_KERNEL(k_xor_sgpr, US8, OP8_S("v_xor_b32", sk), SINKU)
+DEF_KERNEL(k_add3, U8, OP8_3("v_add3_u32"), SINKU)
+DEF_KERNEL(k_alignbit, US8, OP8_ALIGN, SINKU)
+DEF_KERNEL(k_cndmask_s, US8, OP8_CNDS, SINKU)
+DEF_KERNEL(k_cmp_e64, U8, asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0" :: "v"(a0), "v"(c) : "s20", "s21", "s22", "s23");, SINKU)
 DEF_KERNEL(k_cmp, F8, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0" :: "v"(a0), "v"(c) : "vcc");, SINKF)
 
 typedef void (*kern_t)(float *, uint64_t *);
@@ -84,7 +110,9 @@ int main(int argc, char **argv)
                   {"v_add_u32", k_add_u32}, {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi},
                   {"v_mul_u32_u24", k_mul_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u24}, {"v_mad_u64_u32", k_mad64},
                   {"v_log_f32", k_log}, {"v_sqrt_f32", k_sqrt}, {"v_sin_f32", k_sin}, {"v_cos_f32", k_cos},
-                  {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}};
+                  {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}, {"v_xor_b32 (sgpr)", k_xor_sgpr},
+                  {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit}, {"v_cndmask_e64 (s)", k_cndmask_s},
+                  {"v_cmp_lt_u32_e64", k_cmp_e64}};
     printf("%-18s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
     printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
