@@ -277,6 +277,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if constexpr (T::HAS_Z) zres[(size_t)slot * N + trial] = zout;
             atomicAdd(&cnt[slot], 1);
             has = false;
+            am1 = 0;             // an idle lane is never in range
         }
         retired += (unsigned long long)__popcll(fin_mask0);
         // ------------------------------------------------------------ flush complete sets, in order (rare path:
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     cb = -2.0f / (sig * sig);
                     if constexpr (FAST) cb = cb * 1.4426950408889634f;     // v_exp_f32 is 2^x
                 }
-                am1 = __float_as_uint(a) - 1u;
+                am1 = invalid ? 0u : __float_as_uint(a) - 1u;
                 x = a * beta;
                 k = 0;
                 jit = 0;
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             }
         }
         // ------------------------------------------------------------ step phase
+        const unsigned long long has_mask = __builtin_amdgcn_ballot_w64(has);
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
             const uint32_t blk = (uint32_t)k >> 2;
@@ -404,14 +406,18 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     }
                     x = x1;
                     k++;
-                    if constexpr (CAP4) active = in_range(x, am1);
-                    else active = in_range(x, am1) && (k < A.max_k);
+                    if (j < 3) {
+                        if constexpr (CAP4) active = in_range(x, am1);
+                        else active = in_range(x, am1) && (k < A.max_k);
+                    }
                 }
             }
-            if constexpr (CAP4) active = active && (k < A.max_k);
+            // one fresh compare for every lane (idle lanes have am1 == 0, finished lanes sit outside their range):
+            // a ballot of a compare is just its SGPR result, a ballot of the loop-carried flag would be rebuilt
+            // through v_cndmask + v_cmp
+            active = in_range(x, am1) && (k < A.max_k);
             const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
-            const unsigned long long fin_mask = __builtin_amdgcn_ballot_w64(has && !active);
-            if (act_mask == 0ull || __popcll(fin_mask) >= A.refill_thresh) break;
+            if (act_mask == 0ull || __popcll(has_mask & ~act_mask) >= A.refill_thresh) break;
         }
     }
     if (A.dbg && lane == 0) {
@@ -605,10 +611,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if ((size_t)ring * n_trials * per_trial > 60 * 1024)
         return fail(NDDM_ERR_SHAPE, "n_trials too large for one launch (LDS ring); split the call%s");
     // chunk = the unit a wave pulls from the global queue: small (tail of the whole launch <= one chunk), but large
-    // enough that the queue's atomic counter is touched rarely (~ once per 2400+ trials per wave)
+    // enough that the queue's atomic counter is touched rarely (~ once per 1200+ trials per wave)
     int spc = g_tuning.sets_per_chunk;
     if (!spc) {
-        spc = (2400 + n_trials - 1) / n_trials;
+        spc = (1200 + n_trials - 1) / n_trials;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
     }

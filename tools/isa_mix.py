@@ -33,7 +33,7 @@ DEFAULT = 2.4
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "sim_kernelILi0ELb1ELb1ELb0EE"
+    want = sys.argv[1] if len(sys.argv) > 1 else "sim_kernelILi0ELb1ELb1ELb0ELb0EE"
     src = os.path.join(ROOT, "bayesflow_nddms_amd", "csrc", "nddm_kernels.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -44,17 +44,25 @@ def main():
     start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4nddm") and want in l and l.rstrip().endswith(":") or (want in l and ": " in l and l.startswith("_ZN4nddm")))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
-    # innermost loop with the most v_mad_u64_u32: find back-edge label blocks
-    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
-    best = None
+    # group basic blocks by the loop LLVM's asm comments assign them to ("in Loop: Header=BBx_y" / "Inner Loop Header");
+    # the step loop is the INNERMOST-loop group holding the Philox multiplies
+    groups, cur, headers = collections.defaultdict(list), None, set()
     for i, l in enumerate(body):
-        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.search(r"s_branch\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            seg = body[labels[m.group(1)]:i + 1]
-            nmad = sum("v_mad_u64_u32" in x for x in seg)
-            if nmad >= 16 and (best is None or len(seg) < len(best)):
-                best = seg
-    if best is None:
+        if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+            nxt = body[i + 1] if i + 1 < len(body) else ""
+            m = re.search(r"Header=(BB\d+_\d+)", l)
+            if l.startswith(".LBB") and "Inner Loop Header" in (l + nxt):
+                cur = l.split(":")[0][2:]
+                headers.add(cur)
+            elif m:
+                cur = m.group(1)
+            else:
+                cur = None
+        if cur is not None:
+            groups[cur].append(l)
+    inner = {h: seg for h, seg in groups.items() if h in headers}
+    best = max(inner.values(), key=lambda seg: sum("v_mad_u64_u32" in x for x in seg), default=None)
+    if best is None or sum("v_mad_u64_u32" in x for x in best) < 16:
         sys.exit("step loop not found")
     tally = collections.Counter()
     for l in best:
