@@ -56,6 +56,9 @@ def lib():
             raise NddmLibraryError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch (the plumbing for device memory / streams) bundles its own ROCm runtime: it must be the first HIP
+        # runtime loaded into the process, otherwise torch and this library end up on different libamdhip64 copies
+        import torch  # noqa: F401
         try:
             L = ctypes.CDLL(SO_PATH)
         except OSError as e:   # e.g. libamdhip64 not found

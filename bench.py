@@ -39,6 +39,22 @@ VALU_MODEL = {
 }
 
 
+def pmc_traffic(B, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc.json, made by tools/gpu_profile.sh + tools/summarize_profile.py): WRITE_SIZE is exact for streaming
+    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if no matching profile."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d["sets_per_gpu"] == B and d["n_trials"] == N and "WRITE_SIZE" in d["pmc_per_launch"]:
+                c = d["pmc_per_launch"]
+                return {"bytes": (2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, "source": os.path.basename(path)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +232,10 @@ def main():
             "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
             "p_missing": p_missing,
         }
+        tr = None if a.summary_only else pmc_traffic(B, N)
+        if tr:
+            res["roofline"]["traffic"] = tr["bytes"]
+            res["roofline"]["traffic_source"] = tr["source"]
         cpb = VALU_MODEL["cycles_per_block_fast" if fast else "cycles_per_block_exact"]
         if cpb:
             # a wave64 advances 64 lanes x 4 steps per block; ceiling assumes every lane useful

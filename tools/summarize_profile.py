@@ -35,4 +35,9 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
     for k, v in pmc.items():
         f.write(f"| {k} | {sum(v)/len(v):.6g} |\n")
     f.write("\nbench line of the traced run:\n\n```json\n" + json.dumps(bench) + "\n```\n")
+with open(os.path.join("profiles", f"{tag}_pmc.json"), "w") as f:
+    json.dump({"command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ks", "kernel": sim["Name"],
+               "kernel_avg_ms_rocprof": float(sim["AverageNs"]) / 1e6, "kernel_avg_ms_bench_events": bench["roofline"]["kernel_ms"],
+               "sets_per_gpu": bench["config"]["sets_per_gpu"], "n_trials": bench["config"]["n_trials"],
+               "pmc_per_launch": {k: sum(v) / len(v) for k, v in pmc.items()}}, f, indent=1)
 print(open(os.path.join("profiles", f"{tag}_summary.md")).read())
