@@ -197,9 +197,9 @@ __device__ __forceinline__ bool in_range(float x, uint32_t a_bits_m1)
 // points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
 // the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
 // generator is an exact first-passage sampler.
-// KEYS_V (Philox round keys in VGPRs): measured neutral on MI355X -- the ~35 issue cycles it saves per block are
-// paid back by the drop from 7 to 5 resident waves per SIMD -- so it stays off.
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool KEYS_V = false>
+// (Tried and dropped: Philox round keys in VGPRs.  A VOP2 xor that reads an SGPR issues at ~4.2 instead of ~2.3
+// cycles on gfx950, but the 20 extra VGPRs cut residency from 7 to 5 waves per SIMD and the net was neutral.)
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -258,9 +258,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     };
     open_tiles();
     __syncthreads();
-
-    PhiloxKeys PK;
-    if constexpr (KEYS_V) PK.init(A.k0, A.k1);
 
     while (true) {
         // ------------------------------------------------------------ retire finished trials
@@ -367,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
             const uint32_t blk = (uint32_t)k >> 2;
-            const u32x4 rb = KEYS_V ? philox4x32_10(blk, trial, set_lo, c3, PK) : philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
+            const u32x4 rb = philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
             float inc[4];
             {
                 float r, cs, sn;

@@ -34,38 +34,6 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return {c0, c1, c2, c3};
 }
 
-// Round keys held in VGPRs.  On gfx950 a VOP2 op that reads an SGPR operand issues at ~4.2 cycles per wave64
-// instead of ~2.3 (tools/ubench_valu), and half of Philox's 40 xors per block are with the (wave-uniform) round
-// keys: keeping the 20 key words in vector registers trades 20 VGPRs for ~35 issue cycles per block.
-struct PhiloxKeys {
-    uint32_t a[10], b[10];
-    __device__ __forceinline__ void init(uint32_t k0, uint32_t k1)
-    {
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            // the empty asm makes the value opaque, so the compiler cannot fold it back into an SGPR
-            uint32_t va = k0 + (uint32_t)r * 0x9E3779B9u, vb = k1 + (uint32_t)r * 0xBB67AE85u;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(a[r]) : "s"(va));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(b[r]) : "s"(vb));
-        }
-    }
-};
-
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const PhiloxKeys &K)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ K.a[r];
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ K.b[r];
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    }
-    return {c0, c1, c2, c3};
-}
-
 // ---------------------------------------------------------------- exact transform
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, every rounding spelled out.
 __device__ __forceinline__ float exact_logf(float u)

@@ -110,6 +110,29 @@ def test_ragged_trial_counts(N):
     assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
 
 
+def test_maximum_sizes():
+    """Largest n_trials one launch takes (LDS ring of 2 slots), the error beyond it, and a batch far larger than
+    the persistent grid with a short trial count."""
+    from bayesflow_nddms_amd import engine
+    p, g, o = _run_both("basic", B=6, N=7600, dt=0.01, max_steps=400.0, seed=21)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+    p, g, o = _run_both("single", B=3, N=3800, dt=0.01, max_steps=400.0, seed=22)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    with pytest.raises(ValueError, match="n_trials too large"):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 20000)
+    # 2M sets x 8 trials: many more sets than resident waves; compare a few scattered rows with single-row launches
+    B = 2_000_000
+    pp = prior_util.basic_prior(B, 5)
+    r = engine.simulate(0, pp, 8, dt=0.01, max_steps=400, seed=9, set_offset=0, fast=False)
+    t = r["trials"].cpu().numpy()
+    s = r["summary"].cpu().numpy()
+    assert np.all(s[:, :3].sum(axis=1) == 8)
+    for row in (0, 1, 777_777, B - 1):
+        one = engine.simulate(0, pp[row:row + 1], 8, dt=0.01, max_steps=400, seed=9, set_offset=row, fast=False)
+        assert np.array_equal(one["trials"].cpu().numpy()[0].view(np.uint32), t[row].view(np.uint32))
+
+
 def test_geometry_independence():
     """Output is a pure function of (seed, set index, trial): chunking / ring / refill policy do not matter,
     and shards with set_offset reproduce the unsharded batch (the multi-GPU contract)."""

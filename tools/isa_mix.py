@@ -33,7 +33,7 @@ DEFAULT = 2.4
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "sim_kernelILi0ELb1ELb1ELb0ELb0EE"
+    want = sys.argv[1] if len(sys.argv) > 1 else "sim_kernelILi0ELb1ELb1ELb0EE"
     src = os.path.join(ROOT, "bayesflow_nddms_amd", "csrc", "nddm_kernels.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
