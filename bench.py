@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.001)
     ap.add_argument("--max-steps", type=float, default=4000.0)
     ap.add_argument("--gauss", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--model", choices=["basic", "single", "alpha_ns", "alpha_ns_bridge"], default="basic",
+                    help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns* = configs[2]")
     ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
     ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,8 +170,13 @@ def main():
 
     B, N = a.sets, a.trials
     fast = a.gauss == "fast"
-    # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80), default_rng(2023 + rank), resident in HBM
-    p_host = prior_util.basic_prior(B, 2023 + rank)
+    # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
+    # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
+    model_id = {"basic": engine.BASIC_DDM_DC, "single": engine.SINGLE_TRIAL, "alpha_ns": engine.ALPHA_NOT_SCALED,
+                "alpha_ns_bridge": engine.ALPHA_NOT_SCALED}[a.model]
+    bridge = a.model == "alpha_ns_bridge"
+    p_host = {"basic": prior_util.basic_prior, "single": prior_util.single_prior,
+              "alpha_ns": prior_util.alpha_ns_prior, "alpha_ns_bridge": prior_util.alpha_ns_prior}[a.model](B, 2023 + rank)
     p_dev = torch.as_tensor(p_host).to(dev)
     out_trials = None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev)
     out_summary = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
@@ -180,9 +187,9 @@ def main():
 
     def step(i):
         # every step is a fresh batch: global set index = (i*world + rank)*B + row, one seed
-        engine.simulate(engine.BASIC_DDM_DC, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
+        engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
                         set_offset=(i * world + rank) * B, fast=fast, out_trials=out_trials, out_summary=out_summary,
-                        want_trials=not a.summary_only)
+                        want_trials=not a.summary_only, bridge=bridge)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, out_summary if a.gather == "summary" else out_trials)
 
@@ -211,6 +218,8 @@ def main():
     # executed Euler-Maruyama steps of the last step, from the fused summaries (exact integer sums)
     s = out_summary.double()
     tau = p_dev[:, 3].double()
+    if bridge:
+        tau = tau - 0.5 * a.dt      # RTs carry a uniform sub-step jitter in bridge mode (mean -dt/2)
     n_resp = s[:, 0] + s[:, 1]
     max_k = engine.max_k_of(a.max_steps)
     mean_k = torch.where(n_resp > 0, (s[:, 3] - tau) / a.dt, torch.zeros_like(tau))
@@ -220,41 +229,41 @@ def main():
     if rank == 0:
         trials_per_step = world * B * N
         value = trials_per_step * a.steps / elapsed
-        alg_bytes = B * N * (0 if a.summary_only else 8) + B * (5 * 4 + engine.SUMMARY_K * 4)
+        alg_bytes = B * N * (0 if a.summary_only else 8) + B * (p_host.shape[1] * 4 + engine.SUMMARY_K * 4)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         res = {
-            "metric": "simulated DDM trials/sec at n_trials=300 dt=0.001 (basic_ddm_dc, max_steps=4000)",
+            "metric": f"simulated DDM trials/sec at n_trials={N} dt={a.dt:g} ({a.model if a.model != 'basic' else 'basic_ddm_dc'}, max_steps={a.max_steps:g})",
             "value": value, "unit": "trials/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"basic_ddm_dc HIP simulator, {B} parameter sets x {N} trials per GPU per step, "
+            "config": {"workload": f"{'basic_ddm_dc' if a.model == 'basic' else a.model} HIP simulator, {B} parameter sets x {N} trials per GPU per step, "
                                    f"dt={a.dt}, max_steps={a.max_steps:g}, params ~ reference prior (default_rng 2023)",
                        "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
                        "gauss": a.gauss, "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
                        "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "nddm::sim_kernel<NDDM_BASIC_DDM_DC, %s>" % ("fast" if fast else "exact"),
+                         "kernel": "nddm::sim_kernel<%s, %s>" % (a.model, "fast" if fast else "exact"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
             "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
             "p_missing": p_missing,
         }
-        tr = None if a.summary_only else pmc_traffic(B, N)
+        tr = None if (a.summary_only or a.model != "basic") else pmc_traffic(B, N)
         if tr:
             res["roofline"]["traffic"] = tr["bytes"]
             res["roofline"]["traffic_source"] = tr["source"]
         cpb = VALU_MODEL["cycles_per_block_fast" if fast else "cycles_per_block_exact"]
-        if cpb:
+        if cpb and a.model == "basic":
             # a wave64 advances 64 lanes x 4 steps per block; ceiling assumes every lane useful
             peak_steps = VALU_MODEL["simds"] * VALU_MODEL["clock_ghz"] * 1e9 / cpb * 64 * 4
             res["roofline_valu"] = {"bound": "valu", "achieved": em_steps / (kern_ms * 1e-3) / 1e9,
                                     "peak": peak_steps / 1e9, "unit": "G E-M steps/s",
                                     "frac": em_steps / (kern_ms * 1e-3) / peak_steps,
                                     "issue_cycles_per_block": cpb, "clock_ghz": VALU_MODEL["clock_ghz"]}
-        if world == 1 and not a.no_ks:
+        if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model == "basic":
             res["cpu_baseline"] = cpu_baseline(p_host, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)

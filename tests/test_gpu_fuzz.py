@@ -1,0 +1,58 @@
+"""Randomised parity: random model / batch / trial count / dt / cap / seed / offset / tuning, GPU exact mode vs the
+oracle, every bit (trials, summaries, external datum).  Deterministic (seeded) so a failure is reproducible."""
+import numpy as np
+import pytest
+
+import prior_util
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    model = int(rng.integers(0, 5))
+    B = int(rng.integers(1, 70))
+    N = int(rng.choice([1, 2, 7, 31, 64, 100, 180, 300, 513]))
+    dt = float(rng.choice([0.01, 0.001, 0.004, 0.0025]))
+    max_steps = float(rng.choice([0, 1, 3, 10, 400, 401, 1000, 4000]))
+    seed = int(rng.integers(0, 2**63))
+    off = int(rng.choice([0, 1, 2**31 - 5, 2**32 - 3, 2**40 + 17]))
+    tune = (int(rng.integers(0, 9)), int(rng.choice([0, 2, 4, 8, 16])), int(rng.integers(0, 70)), int(rng.integers(0, 20)),
+            int(rng.choice([0, 1, 3, 64, 5000])))
+    bridge = bool(model == 3 and rng.random() < 0.5 and max_steps < 2**22)
+    return model, B, N, dt, max_steps, seed, off, tune, bridge
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_fuzz_bit_parity(chunk):
+    import oracle
+    from bayesflow_nddms_amd import _lib, engine
+    rng = np.random.default_rng(1000 + chunk)
+    try:
+        for _ in range(10):
+            model, B, N, dt, max_steps, seed, off, tune, bridge = _case(rng)
+            pseed = int(rng.integers(0, 10**6))
+            if model == 0:
+                p = prior_util.basic_prior(B, pseed)
+            elif model in (1, 2):
+                p = prior_util.single_prior(B, pseed, gamma=float(rng.choice([1.0, 2.0, 0.3])))
+                if model == 2:
+                    p[:, 4] = np.minimum(p[:, 4], 1.0)
+            elif model == 3:
+                p = prior_util.alpha_ns_prior(B, pseed)
+            else:
+                p = prior_util.basic_prior(B, pseed)[:, [0, 2, 3, 4]]
+            bounds = np.abs(rng.normal(1.2, 0.5, size=(B, N))).astype(np.float32) if model == 4 else None
+            _lib.check(_lib.lib().nddm_set_tuning(*tune))
+            g = engine.simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, fast=False,
+                                bounds=bounds, ext_sigma=0.2, ext_mode=int(rng.integers(0, 2)) if False else 0,
+                                want_ext=(model == 3), bridge=bridge)
+            o = oracle.philox_simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, bounds=bounds,
+                                       ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge, threads=8)
+            ctx = (model, B, N, dt, max_steps, seed, off, tune, bridge)
+            assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32)), ctx
+            assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32),
+                                  np.nan_to_num(o["summary"]).view(np.uint32)), ctx
+            if model == 3:
+                assert np.array_equal(g["ext"].cpu().numpy().view(np.uint32), o["ext"].view(np.uint32)), ctx
+    finally:
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0)
