@@ -25,7 +25,7 @@ def _declare(L):
     L.nddm_set_device.argtypes = [c.c_int]
     L.nddm_summary_k.restype = c.c_int
     L.nddm_model_nparams.argtypes = [c.c_int]
-    L.nddm_set_tuning.argtypes = [c.c_int] * 5
+    L.nddm_set_tuning.argtypes = [c.c_int] * 6
     L.nddm_set_debug_counters.argtypes = [c.c_void_p]
     common = [c.c_int64, c.c_int32, c.c_float, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32]
     for name in ("nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate", "nddm_single_trial_alt_simulate"):

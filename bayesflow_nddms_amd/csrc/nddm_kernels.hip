@@ -51,7 +51,10 @@ struct SimArgs {
     float *out_ext;           // [B] or null
     long long B;
     unsigned long long set_offset;
-    int n_trials;
+    int n_trials;             // trials per TILE (a set is split into tiles_per_set tiles when it does not fit the LDS ring)
+    int n_total;              // trials per set (row stride of out_trials / bounds)
+    int tiles_per_set;
+    long long *partials;      // [B * tiles_per_set, 9] integer partial sums when tiles_per_set > 1, else null
     int max_k;
     float dt;
     float sqrt_dt;
@@ -103,19 +106,53 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// The fused epilogue of one parameter set: coalesced (col0, col1) stores + summary reduction.
+__device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, int n_miss, unsigned long long sk,
+                                                 unsigned long long sk2, unsigned long long sk_up,
+                                                 unsigned long long sk2_up, long long sz, long long szz, int n_total,
+                                                 float tscale, float tau)
+{
+    const double dtd = (double)tscale, taud = (double)tau;
+    const double n_resp = (double)(n_up + n_lo);
+    o[0] = (float)n_up; o[1] = (float)n_lo; o[2] = (float)n_miss;
+    if (n_resp > 0) {
+        const double mk = (double)sk / n_resp;
+        const double vk = (double)sk2 / n_resp - mk * mk;
+        o[3] = (float)(taud + dtd * mk);
+        o[4] = (float)(dtd * dtd * vk);
+    } else { o[3] = __builtin_nanf(""); o[4] = __builtin_nanf(""); }
+    if (n_up > 0) {
+        const double nu = (double)n_up;
+        const double mk = (double)sk_up / nu;
+        const double vk = (double)sk2_up / nu - mk * mk;
+        o[5] = (float)(taud + dtd * mk);
+        o[6] = (float)(dtd * dtd * vk);
+    } else { o[5] = __builtin_nanf(""); o[6] = __builtin_nanf(""); }
+    const double Nd = (double)n_total;
+    const double mz = ((double)sz / 4294967296.0) / Nd;
+    const double vz = ((double)szz / 16777216.0) / Nd - mz * mz;
+    o[7] = (float)mz;
+    o[8] = (float)vz;
+    o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
+}
+
+// The fused epilogue of one tile (= one parameter set unless the set is split): coalesced (col0, col1) stores +
+// summary reduction.  vset = set * tiles_per_set + tile.
 template <int MODEL, bool FAST>
-__device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long set_in_call, const float *pp,
+__device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long vset, const float *pp,
                                           const uint32_t *res, const float *zres)
 {
     using T = ModelTraits<MODEL>;
     const int N = A.n_trials;
+    const int TPS = A.tiles_per_set;
+    const long long set_in_call = TPS == 1 ? vset : vset / TPS;
+    const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
+    const int n_here = (A.n_total - t0) < N ? (A.n_total - t0) : N;           // the last tile may be padded
     const float tau = pp[T::TAU];
     int n_up = 0, n_lo = 0, n_miss = 0;
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
     long long sz = 0, szz = 0;
-    float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set_in_call * N : nullptr;
-    for (int j = lane; j < N; j += WAVE) {
+    float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set_in_call * A.n_total + t0 : nullptr;
+    for (int j = lane; j < n_here; j += WAVE) {
         const uint32_t v = res[j];
         const uint32_t k = v & 0x3fffffffu;                  // time in units of A.tscale (step index, or 1/256 step)
         const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
@@ -151,33 +188,18 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
             szz = (long long)wave_sum((unsigned long long)szz);
         }
         if (lane == 0) {
-            float *o = A.out_summary + set_in_call * NDDM_SUMMARY_K;
-            const double dtd = (double)A.tscale, taud = (double)tau;
-            const double n_resp = (double)(n_up + n_lo);
-            o[0] = (float)n_up; o[1] = (float)n_lo; o[2] = (float)n_miss;
-            if (n_resp > 0) {
-                const double mk = (double)sk / n_resp;
-                const double vk = (double)sk2 / n_resp - mk * mk;
-                o[3] = (float)(taud + dtd * mk);
-                o[4] = (float)(dtd * dtd * vk);
-            } else { o[3] = __builtin_nanf(""); o[4] = __builtin_nanf(""); }
-            if (n_up > 0) {
-                const double nu = (double)n_up;
-                const double mk = (double)sk_up / nu;
-                const double vk = (double)sk2_up / nu - mk * mk;
-                o[5] = (float)(taud + dtd * mk);
-                o[6] = (float)(dtd * dtd * vk);
-            } else { o[5] = __builtin_nanf(""); o[6] = __builtin_nanf(""); }
-            const double Nd = (double)N;
-            const double mz = ((double)sz / 4294967296.0) / Nd;
-            const double vz = ((double)szz / 16777216.0) / Nd - mz * mz;
-            o[7] = (float)mz;
-            o[8] = (float)vz;
-            o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
+            if (TPS == 1) {
+                finalize_summary(A.out_summary + set_in_call * NDDM_SUMMARY_K, n_up, n_lo, n_miss, sk, sk2, sk_up, sk2_up,
+                                 sz, szz, A.n_total, A.tscale, tau);
+            } else {          // integer partial sums of this tile; combine_partials_kernel adds the tiles up
+                long long *q = A.partials + vset * 9;
+                q[0] = n_up; q[1] = n_lo; q[2] = n_miss; q[3] = (long long)sk; q[4] = (long long)sk2;
+                q[5] = (long long)sk_up; q[6] = (long long)sk2_up; q[7] = sz; q[8] = szz;
+            }
         }
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-        if (A.out_ext && lane == 0) {
+        if (A.out_ext && lane == 0 && t0 == 0) {
             AuxStream<FAST> aux(A.k0, A.k1, A.set_offset + (unsigned long long)set_in_call, 0xffffffffu);
             const float loc = (A.ext_mode == 0) ? pp[1] : 1.0f;
             A.out_ext[set_in_call] = __builtin_fmaf(A.ext_sigma, aux.normal(0), loc);
@@ -222,7 +244,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     float x = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;
     uint32_t am1 = 0;        // bits(boundary) - 1
     int k = 0;
-    uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;
+    uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
+    uint32_t ltrial = 0;     // index within the tile (LDS slot position)
     int tile = 0;            // wave-local sequence number of the set this lane works on
     bool has = false, active = false, invalid = false;
 
@@ -251,7 +274,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 chunk_left = (int)(left < A.sets_per_chunk ? left : A.sets_per_chunk);
             }
             const int slot = tile_open & ring_mask;
-            if (lane < P) lp[slot * P + lane] = A.params[(long long)chunk_set * P + lane];
+            const long long prow = A.tiles_per_set == 1 ? (long long)chunk_set : (long long)(chunk_set / A.tiles_per_set);
+            if (lane < P) lp[slot * P + lane] = A.params[prow * P + lane];
             if (lane == 0) { slot_set[slot] = chunk_set; cnt[slot] = 0; }
             chunk_set++; chunk_left--; tile_open++;
         }
@@ -270,8 +294,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
-            res[(size_t)slot * N + trial] = tfix | (code << 30);
-            if constexpr (T::HAS_Z) zres[(size_t)slot * N + trial] = zout;
+            res[(size_t)slot * N + ltrial] = tfix | (code << 30);
+            if constexpr (T::HAS_Z) zres[(size_t)slot * N + ltrial] = zout;
             atomicAdd(&cnt[slot], 1);
             has = false;
             am1 = 0;             // an idle lane is never in range
@@ -309,9 +333,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (ok) {
                 tile = tl;
                 trial = (uint32_t)tr;
+                ltrial = (uint32_t)tr;
                 const int slot = tl & ring_mask;
                 const float *pp = lp + slot * P;
-                const long long set_in_call = (long long)slot_set[slot];
+                const int vset = slot_set[slot];
+                const long long set_in_call = A.tiles_per_set == 1 ? (long long)vset : (long long)(vset / A.tiles_per_set);
+                if (A.tiles_per_set != 1) trial += (uint32_t)((vset - (int)set_in_call * A.tiles_per_set) * N);   // global trial index
                 const unsigned long long gset = A.set_offset + (unsigned long long)set_in_call;
                 set_lo = (uint32_t)gset;
                 c3 = (uint32_t)(gset >> 32) & 0x0fffffffu;
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     a = pp[1]; beta = pp[2]; sig_c = pp[5];
                 } else {   // NDDM_EXPLICIT_BOUNDARY
                     drift = pp[0]; beta = pp[1]; sig_c = pp[3];
-                    a = A.bounds[set_in_call * N + trial];
+                    a = trial < (uint32_t)A.n_total ? A.bounds[set_in_call * A.n_total + trial] : 1.0f;   // padded trial of a last tile
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                 }
@@ -424,6 +451,25 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         atomicAdd(A.dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0));
         atomicAdd(A.dbg + 4, 1ull);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sets split into several tiles: add the tiles' integer partial sums up and finalise the summary row (one thread per
+// set; exact integer arithmetic, so the result equals the single-tile path bit for bit)
+__global__ void combine_partials_kernel(const long long *partials, const float *params, int P, int tau_idx,
+                                        long long B, int tiles_per_set, int n_total, float tscale, float *out_summary)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    long long a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < tiles_per_set; ++t) {
+        const long long *q = partials + (b * tiles_per_set + t) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] += q[i];
+    }
+    finalize_summary(out_summary + b * NDDM_SUMMARY_K, (int)a[0], (int)a[1], (int)a[2], (unsigned long long)a[3],
+                     (unsigned long long)a[4], (unsigned long long)a[5], (unsigned long long)a[6], a[7], a[8], n_total,
+                     tscale, params[b * P + tau_idx]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,8 +563,8 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves; };
-static Tuning g_tuning = {0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials; };
+static Tuning g_tuning = {0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
 // resident waves of a kernel instantiation on the current device (persistent grid size)
 template <typename K>
 static int resident_waves(K kernel, size_t lds_bytes)
@@ -599,29 +645,39 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
     A.dbg = g_dbg;
 
+    // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
+    // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
+    const size_t per_trial = has_z ? 8 : 4;
+    int tiles = g_tuning.tile_trials > 0 ? (n_trials + g_tuning.tile_trials - 1) / g_tuning.tile_trials
+                                         : (n_trials <= 1024 ? 1 : (n_trials + 511) / 512);
+    const int tile_n = (n_trials + tiles - 1) / tiles;
+    tiles = (n_trials + tile_n - 1) / tile_n;
+    const long long vB = B * (long long)tiles;
+    if (vB >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
+    if ((long long)tile_n * tiles >= (1ll << 30) || n_trials >= (1 << 30))
+        return fail(NDDM_ERR_SHAPE, "n_trials must be < 2^30%s");
+    A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles; A.B = vB;
     // geometry: ring slots so that >= ~4 wavefronts' worth of trials can be in flight per wave window
-    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((256 + n_trials - 1) / n_trials);
+    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((256 + tile_n - 1) / tile_n);
     if (ring < 4) ring = 4;
     if (ring > 64) ring = 64;
-    const size_t per_trial = has_z ? 8 : 4;
-    while (ring > 2 && (size_t)ring * n_trials * per_trial > 40 * 1024) ring >>= 1;
-    if ((size_t)ring * n_trials * per_trial > 60 * 1024)
-        return fail(NDDM_ERR_SHAPE, "n_trials too large for one launch (LDS ring); split the call%s");
+    while (ring > 2 && (size_t)ring * tile_n * per_trial > 40 * 1024) ring >>= 1;
+    if ((size_t)ring * tile_n * per_trial > 60 * 1024)
+        return fail(NDDM_ERR_SHAPE, "tile too large for the LDS ring (tuning override?)%s");
     // chunk = the unit a wave pulls from the global queue: small (tail of the whole launch <= one chunk), but large
     // enough that the queue's atomic counter is touched rarely (~ once per 1200+ trials per wave)
     int spc = g_tuning.sets_per_chunk;
     if (!spc) {
-        spc = (1200 + n_trials - 1) / n_trials;
+        spc = (1200 + tile_n - 1) / tile_n;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
     }
-    if (B >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "B must be < 2^31 per launch%s");
     A.sets_per_chunk = spc; A.ring = ring;
     A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : 8;
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
-    const long long n_chunks = (B + spc - 1) / spc;
+    const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
-    const size_t lds = (size_t)ring * (P * 4 + 8) + (size_t)ring * n_trials * per_trial;
+    const size_t lds = (size_t)ring * (P * 4 + 8) + (size_t)ring * tile_n * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
     {
@@ -642,15 +698,35 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMemsetAsync(queue word): %s", hipGetErrorString(e));
     }
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
-    switch (model) {
-    case NDDM_BASIC_DDM_DC: return launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_SINGLE_TRIAL: return launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_SINGLE_TRIAL_ALT: return launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st);
-    case NDDM_ALPHA_NOT_SCALED:
-        return bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
-                      : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
-    default: return launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st);
+    // split sets: the tiles leave integer partial sums in a stream-ordered scratch buffer
+    A.partials = nullptr;
+    if (tiles > 1 && out_summary) {
+        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&A.partials), (size_t)vB * 9 * sizeof(long long), st);
+        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
     }
+    int rc;
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st); break;
+    case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st); break;
+    case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st); break;
+    case NDDM_ALPHA_NOT_SCALED:
+        rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
+                    : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
+        break;
+    default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st); break;
+    }
+    if (A.partials) {
+        if (rc == NDDM_OK) {
+            const int tau_idx = model == NDDM_EXPLICIT_BOUNDARY ? 2 : 3;
+            const int threads = 256;
+            hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st,
+                               A.partials, params, P, tau_idx, (long long)B, tiles, n_trials, A.tscale, out_summary);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
+        }
+        hipFreeAsync(A.partials, st);
+    }
+    return rc;
 }
 
 }  // namespace nddm
@@ -690,10 +766,10 @@ int nddm_set_device(int device)
 }
 
 /* benchmarking aid (not part of the drop-in surface): 0 = automatic */
-int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves)
+int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves, int tile_trials)
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
-    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves};
+    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials};
     return NDDM_OK;
 }
 

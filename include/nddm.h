@@ -59,7 +59,7 @@ enum nddm_model {
 enum nddm_status {
     NDDM_OK = 0,
     NDDM_ERR_NULL = 1,        /* a required pointer is NULL */
-    NDDM_ERR_SHAPE = 2,       /* B < 0, n_trials <= 0, max_steps < 0, n_trials too large for one launch */
+    NDDM_ERR_SHAPE = 2,       /* B < 0, n_trials <= 0, max_steps < 0, or B * ceil(n_trials / 512) >= 2^31 */
     NDDM_ERR_PARAM = 3,       /* non-finite or non-positive dt; unknown model / flag */
     NDDM_ERR_HIP = 4,         /* a HIP runtime call failed; text in nddm_last_error() */
     NDDM_ERR_NO_DEVICE = 5
@@ -87,7 +87,8 @@ int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
  * Common arguments:
  *   params      device f32 [B, P]
  *   B           number of parameter sets (rows)
- *   n_trials    trials per set (the batch-shared N of basic_ddm_dc.py:50-52, 131)
+ *   n_trials    trials per set (the batch-shared N of basic_ddm_dc.py:50-52, 131); any size: sets with more than
+ *               1024 trials are split into tiles internally, with results independent of the split
  *   dt          Euler-Maruyama step (reference default .01, basic_ddm_dc.py:87; fine study .001, single_trial_alpha_not_scaled.py:1719)
  *   max_steps   step cap (reference default 400; 4000 in the fine study)
  *   seed        64-bit stream key

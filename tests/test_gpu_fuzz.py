@@ -17,7 +17,7 @@ def _case(rng):
     seed = int(rng.integers(0, 2**63))
     off = int(rng.choice([0, 1, 2**31 - 5, 2**32 - 3, 2**40 + 17]))
     tune = (int(rng.integers(0, 9)), int(rng.choice([0, 2, 4, 8, 16])), int(rng.integers(0, 70)), int(rng.integers(0, 20)),
-            int(rng.choice([0, 1, 3, 64, 5000])))
+            int(rng.choice([0, 1, 3, 64, 5000])), int(rng.choice([0, 0, 0, 5, 33, 64, 200])))
     bridge = bool(model == 3 and rng.random() < 0.5 and max_steps < 2**22)
     return model, B, N, dt, max_steps, seed, off, tune, bridge
 
@@ -55,4 +55,4 @@ def test_fuzz_bit_parity(chunk):
             if model == 3:
                 assert np.array_equal(g["ext"].cpu().numpy().view(np.uint32), o["ext"].view(np.uint32)), ctx
     finally:
-        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0)
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)

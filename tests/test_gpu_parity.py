@@ -119,8 +119,16 @@ def test_maximum_sizes():
     assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
     p, g, o = _run_both("single", B=3, N=3800, dt=0.01, max_steps=400.0, seed=22)
     assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
-    with pytest.raises(ValueError, match="n_trials too large"):
-        engine.simulate(0, prior_util.basic_prior(2, 1), 20000)
+    # beyond the ring a set is split into tiles (and the summaries combined from integer partial sums): same bits
+    for model, N in (("basic", 20000), ("single", 5001), ("alpha_ns", 1025), ("explicit", 2500)):
+        p, g, o = _run_both(model, B=3, N=N, dt=0.01, max_steps=400.0, seed=23)
+        assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32)), model
+        assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32)), model
+    one = engine.simulate(0, prior_util.basic_prior(1, 3), 1_000_000, dt=0.01, max_steps=400, seed=1, fast=True)
+    sm, tr = one["summary"].cpu().numpy()[0], one["trials"].cpu().numpy()[0]
+    resp = tr[:, 1] != 0
+    assert sm[:3].sum() == 1_000_000 and sm[0] == (tr[:, 1] == 1).sum()
+    assert abs(sm[3] - tr[resp, 0].astype(np.float64).mean()) < 1e-5
     # 2M sets x 8 trials: many more sets than resident waves; compare a few scattered rows with single-row launches
     B = 2_000_000
     pp = prior_util.basic_prior(B, 5)
@@ -140,12 +148,13 @@ def test_geometry_independence():
     p = prior_util.basic_prior(300, 99)
     base = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
     try:
-        for tune in [(1, 2, 1, 1, 1), (7, 4, 64, 3, 5), (64, 64, 8, 16, 0), (3, 8, 200, 2, 1000), (1, 4, 8, 16, 64)]:
+        for tune in [(1, 2, 1, 1, 1, 0), (7, 4, 64, 3, 5, 0), (64, 64, 8, 16, 0, 0), (3, 8, 200, 2, 1000, 0), (1, 4, 8, 16, 64, 0),
+                     (0, 0, 0, 0, 0, 64), (2, 4, 0, 0, 0, 7), (0, 0, 0, 0, 0, 179)]:
             _lib.check(_lib.lib().nddm_set_tuning(*tune))
             t = engine.simulate(0, p, 180, dt=0.01, max_steps=400, seed=5, set_offset=1000, fast=False)["trials"].cpu().numpy()
             assert np.array_equal(t.view(np.uint32), base.view(np.uint32)), tune
     finally:
-        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0)
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
     parts = [engine.simulate(0, p[a:b], 180, dt=0.01, max_steps=400, seed=5, set_offset=1000 + a, fast=False)["trials"].cpu().numpy()
              for a, b in [(0, 75), (75, 150), (150, 151), (151, 300)]]
     assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))

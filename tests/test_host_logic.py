@@ -43,8 +43,8 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.nddm_basic_ddm_dc_simulate(None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL
     assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 0, None, None, None) == _lib.NDDM_ERR_NULL
     assert L.nddm_explicit_boundary_simulate(dummy, None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL
-    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 100000, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
-    assert b"n_trials too large" in L.nddm_last_error()
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 2**30, 100000, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
+    assert b"< 2^31" in L.nddm_last_error()
     assert L.nddm_basic_ddm_dc_simulate(dummy, 0, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_OK  # empty batch
     with pytest.raises(ValueError):
         _lib.check(_lib.NDDM_ERR_SHAPE)

@@ -37,14 +37,14 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
     steps = float(((s[:, 3] - p[:, 3 if model != 4 else 2]) / dt * nresp)[nresp > 0].sum() + s[:, 2].sum() * int(ms)) if not bridge else float("nan")
     cyc = best * 1e-3 * 2.35e9 * 1024 / (steps / 256) if steps == steps else float("nan")
     print(f"model={model} B={B} N={N} dt={dt} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge}: {best:.2f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  ~{cyc:.0f} SIMD-cycles/wave-block@2.35GHz | lane-eff {steps/(d[0]*256):.3f} blocks/refill {d[0]/d[1]:.1f} clock {d[2]/d[3]*0.1:.3f} GHz", flush=True)
-    _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0)
+    _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-    run(40000, 300, 0.001, 4000, True, (1, 0, 64, 64, 0), lockstep=True)
+    run(40000, 300, 0.001, 4000, True, (1, 0, 64, 64, 0, 0), lockstep=True)
     run(B, 300, 0.001, 4000, True)
     run(B, 300, 0.001, 4000, False)
-    for tune in [(4, 0, 0, 0, 0), (0, 0, 6, 0, 0), (0, 0, 12, 0, 0), (0, 8, 6, 0, 0)]:
+    for tune in [(4, 0, 0, 0, 0, 0), (0, 0, 6, 0, 0, 0), (0, 0, 12, 0, 0, 0), (0, 8, 6, 0, 0, 0)]:
         run(B, 300, 0.001, 4000, True, tune)
     run(B, 300, 0.01, 400, True)
     run(B, 300, 0.001, 4000, True, model=1)
