@@ -86,3 +86,34 @@ class DevicePrior:
         gamma = -1.0 if self.model == "scale" else 1.0
         out = engine.draw_prior_device(engine.SINGLE_TRIAL, batch_size, seed=seed, set_offset=off, gamma=gamma)
         return out[:, :self._NCOLS[self.model]].contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Vectorised host draws of the same marginals (one SciPy call per column instead of three per parameter set):
+# synthetic parameter matrices for benchmarks, tests and bulk simulation.  Same distributions as draw_prior_*,
+# but a different (seeded, default_rng) stream -- use the call-for-call functions above for reference-identical draws.
+def _tn_vec(rng, mean, sd, low, upp, size):
+    return truncnorm.rvs((low - mean) / sd, (upp - mean) / sd, loc=mean, scale=sd, size=size, random_state=rng)
+
+
+def basic_prior_matrix(B, seed=2023):
+    """float32 [B, 5]: drift, boundary, beta, tau, dc  (basic_ddm_dc.py:62-80)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.normal(0.0, 2.0, B), _tn_vec(rng, 1.0, .5, 0.0, 10.0, B), rng.beta(2.0, 2.0, B),
+                     _tn_vec(rng, .5, .25, 0.0, 1.5, B), _tn_vec(rng, 1.0, .5, 0.0, 10.0, B)], axis=1).astype(np.float32)
+
+
+def single_prior_matrix(B, seed=2023, gamma=1.0):
+    """float32 [B, 8]: drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, gamma  (single_trial_alpha_not_scaled.py:78-102)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.normal(0.0, 2.0, B), _tn_vec(rng, 1.0, .5, 0.0, 10.0, B), rng.beta(2.0, 2.0, B),
+                     _tn_vec(rng, .5, .25, 0.0, 1.5, B), _tn_vec(rng, 1.0, .5, 0.0, 3.0, B),
+                     _tn_vec(rng, 1.0, .5, 0.0, 10.0, B), rng.uniform(0.0, 5.0, B), np.full(B, gamma)],
+                    axis=1).astype(np.float32)
+
+
+def alpha_ns_prior_matrix(B, seed=2021):
+    """float32 [B, 6]: Nu, Alpha, Beta, Tau, Eta, Varsigma  (alpha_not_scaled.py:66-72)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-4, 4, B), rng.uniform(.8, 1.4, B), rng.uniform(.3, .7, B), rng.uniform(.15, .6, B),
+                     rng.uniform(0, 2, B), rng.uniform(.8, 1.4, B)], axis=1).astype(np.float32)

@@ -27,7 +27,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU ceiling model: issue cycles per wave64 for one Philox block = 4 E-M steps, fast Gaussian
@@ -166,7 +165,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     from bayesflow_nddms_amd import engine
-    import prior_util
+    from bayesflow_nddms_amd import priors as prior_util
 
     B, N = a.sets, a.trials
     fast = a.gauss == "fast"
@@ -175,8 +174,8 @@ def main():
     model_id = {"basic": engine.BASIC_DDM_DC, "single": engine.SINGLE_TRIAL, "alpha_ns": engine.ALPHA_NOT_SCALED,
                 "alpha_ns_bridge": engine.ALPHA_NOT_SCALED}[a.model]
     bridge = a.model == "alpha_ns_bridge"
-    p_host = {"basic": prior_util.basic_prior, "single": prior_util.single_prior,
-              "alpha_ns": prior_util.alpha_ns_prior, "alpha_ns_bridge": prior_util.alpha_ns_prior}[a.model](B, 2023 + rank)
+    p_host = {"basic": prior_util.basic_prior_matrix, "single": prior_util.single_prior_matrix,
+              "alpha_ns": prior_util.alpha_ns_prior_matrix, "alpha_ns_bridge": prior_util.alpha_ns_prior_matrix}[a.model](B, 2023 + rank)
     p_dev = torch.as_tensor(p_host).to(dev)
     out_trials = None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev)
     out_summary = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
@@ -195,7 +194,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if a.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -268,7 +270,7 @@ def main():
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
