@@ -59,6 +59,9 @@ SLICES = {
     "imputation_sim": ("imputation_from_stahl_not_scaled.py", 120, 148),
     # exact first-passage sampler
     "ratcliff": ("pyhddmjagsutils.py", 47, 176),
+    # alpha_not_scaled.py participant-level draws: seed + uniform draws (:63-72) and the fixed participant (:82-88)
+    "alpha_ns_draws": ("alpha_not_scaled.py", 63, 72),
+    "alpha_ns_fixed": ("alpha_not_scaled.py", 82, 88),
 }
 
 
@@ -186,6 +189,14 @@ def make_kat():
     conf = c["configurator"](sim)
     out["conf_direct_conditions"] = conf["direct_conditions"]
     out["conf_summary_dtype_is_f32"] = np.array(int(conf["summary_conditions"].dtype == np.float32))
+
+    # alpha_not_scaled.py:63-72, 82-88: participant-level parameters (seed 2021, nparts = 100)
+    ns = load_slice("alpha_ns_draws", extra={"nparts": 100})
+    fname, lo, hi = SLICES["alpha_ns_fixed"]
+    with open(os.path.join(REF, fname)) as f:
+        exec(compile(textwrap.dedent("".join(f.readlines()[lo - 1:hi])), "<alpha_ns_fixed>", "exec"), ns)
+    for key in ("ndt", "alpha", "beta", "delta", "varsigma", "deltatrialsd"):
+        out[f"alpha_ns_part_{key}"] = ns[key]
 
     out["basic_sets"] = BASIC_SETS
     out["single_sets"] = SINGLE_SETS

@@ -166,6 +166,15 @@ def test_host_priors_bit_exact():
     assert priors.draw_prior_scale().shape == (8,)
 
 
+def test_alpha_not_scaled_participants_bit_exact(kat):
+    """alpha_not_scaled.py:63-72, 82-88: participant-level parameters on the global NumPy stream, seed 2021."""
+    from bayesflow_nddms_amd import alpha_not_scaled
+    par = alpha_not_scaled.draw_participants(100, seed=2021)
+    for key in ("ndt", "alpha", "beta", "delta", "varsigma", "deltatrialsd"):
+        assert np.array_equal(par[key], kat[f"alpha_ns_part_{key}"]), key
+    assert alpha_not_scaled.SIGMA_OF_TEST == {1: .5, 2: .1, 3: .01, 4: .2}
+
+
 def test_diagnostics_ks():
     from bayesflow_nddms_amd import diagnostics as dg
     rng = np.random.default_rng(0)
