@@ -15,7 +15,6 @@ BayesFlow/TensorFlow are not installable here, so parity with BayesFlow's networ
 the dictionary contract on both sides ('summary_conditions', 'direct_conditions', 'parameters').  This module is
 plain PyTorch (no custom kernels): the data-parallel hot path of the repository is the simulator that feeds it.
 """
-import math
 import os
 import pickle
 

@@ -44,7 +44,7 @@ def test_fuzz_bit_parity(chunk):
             bounds = np.abs(rng.normal(1.2, 0.5, size=(B, N))).astype(np.float32) if model == 4 else None
             _lib.check(_lib.lib().nddm_set_tuning(*tune))
             g = engine.simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, fast=False,
-                                bounds=bounds, ext_sigma=0.2, ext_mode=int(rng.integers(0, 2)) if False else 0,
+                                bounds=bounds, ext_sigma=0.2, ext_mode=0,
                                 want_ext=(model == 3), bridge=bridge)
             o = oracle.philox_simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, bounds=bounds,
                                        ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge, threads=8)

@@ -1,5 +1,5 @@
 """Developer aid: time the basic_ddm_dc kernel at a few sizes / tunings (not the bench contract)."""
-import sys, time
+import sys
 import numpy as np
 import torch
 import os
