@@ -724,7 +724,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
         }
-        hipFreeAsync(A.partials, st);
+        (void)hipFreeAsync(A.partials, st);
     }
     return rc;
 }
