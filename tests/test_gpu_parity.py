@@ -61,6 +61,28 @@ def test_normals_bit_exact(oracle_mod):
     assert abs(ref.mean()) < 0.02 and abs(ref.std() - 1.0) < 0.02
 
 
+def test_fast_normals_are_standard_normal():
+    """The product default (fast transform): 4e6 draws against N(0,1) -- KS, moments up to kurtosis, tail mass,
+    no NaN/inf, and no correlation between the cos / sin members of a pair or successive blocks."""
+    from scipy import stats
+    from bayesflow_nddms_amd import engine
+    n = 1_000_000
+    ctr = np.zeros((n, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(n) % 1000          # block index
+    ctr[:, 1] = np.arange(n) // 1000         # trial index
+    ctr[:, 2] = 12345
+    z = engine.debug_normals(ctr, 2023, 7, fast=True).astype(np.float64)
+    assert np.all(np.isfinite(z))
+    flat = z.ravel()
+    assert stats.kstest(flat[::4], "norm").statistic < 0.002
+    assert abs(flat.mean()) < 2e-3 and abs(flat.var() - 1) < 3e-3
+    assert abs(stats.skew(flat)) < 5e-3 and abs(stats.kurtosis(flat)) < 1e-2
+    for thr, p in ((3.0, 2.6998e-3), (4.0, 6.334e-5)):
+        assert abs((np.abs(flat) > thr).mean() / p - 1) < 0.15
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 4e-3 and abs(np.corrcoef(z[:, 1], z[:, 2])[0, 1]) < 4e-3
+    assert abs(np.corrcoef(z[:-1, 3], z[1:, 0])[0, 1]) < 4e-3
+
+
 @pytest.mark.parametrize("model", list(MODELS))
 @pytest.mark.parametrize("dt,max_steps", [(0.01, 400.0), (0.001, 4000.0)])
 def test_exact_mode_bit_parity(model, dt, max_steps):
