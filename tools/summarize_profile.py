@@ -34,6 +34,26 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
     f.write(f"Dispatch: {meta}\n\n| counter (per launch, mean of {len(next(iter(pmc.values())))} launches) | value |\n|---|---|\n")
     for k, v in pmc.items():
         f.write(f"| {k} | {sum(v)/len(v):.6g} |\n")
+    m = {k: sum(v) / len(v) for k, v in pmc.items()}
+    dur = float(sim["AverageNs"]) * 1e-9
+    if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
+        clock = m["GRBM_GUI_ACTIVE"] / 8 / dur            # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+        useful_blocks = bench["em_steps_per_trial"] * bench["config"]["sets_per_gpu"] * bench["config"]["n_trials"] / 256.0
+        f.write("\nDerived (per launch):\n\n")
+        f.write(f"* effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {clock/1e9:.3f} GHz\n")
+        f.write(f"* VALU wave-instructions per useful wave-block (64 lanes x 4 E-M steps) = {m['SQ_INSTS_VALU']/useful_blocks:.1f} "
+                f"(step-loop body: see tools/isa_mix.py); SALU = {m['SQ_INSTS_SALU']/useful_blocks:.1f}\n")
+        f.write(f"* VALU issue rate = {m['SQ_INSTS_VALU']/dur/1024/clock:.3f} wave-instructions per SIMD-cycle "
+                f"(a full-rate VGPR-only op takes ~2.3 cycles, the kernel's mix averages ~3.9)\n")
+        if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+            f.write(f"* exec-mask utilisation of VALU instructions = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = "
+                    f"{m['SQ_THREAD_CYCLES_VALU']/(64*m['SQ_ACTIVE_INST_VALU']):.3f}\n")
+        if "SQ_WAVE_CYCLES" in m:
+            f.write(f"* mean resident waves per SIMD = 4 x SQ_WAVE_CYCLES / (1024 x kernel cycles) = "
+                    f"{4*m['SQ_WAVE_CYCLES']/(1024*clock*dur):.2f}\n")
+        if "WRITE_SIZE" in m:
+            f.write(f"* HBM traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB = {(2*m.get('FETCH_SIZE',0)+m['WRITE_SIZE'])*1024/1e9:.3f} GB "
+                    f"vs algorithmic {bench['roofline']['algorithmic_bytes_per_launch']/1e9:.3f} GB\n")
     f.write("\nbench line of the traced run:\n\n```json\n" + json.dumps(bench) + "\n```\n")
 with open(os.path.join("profiles", f"{tag}_pmc.json"), "w") as f:
     json.dump({"command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ks", "kernel": sim["Name"],
