@@ -234,7 +234,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     // LDS carve-up, one ring slot per in-flight parameter set ("tile"):
     //   raw parameter row | in-call set index | retire counter | packed results | z column
-    float *lp = reinterpret_cast<float *>(lds_raw);
+    // bytes [0, 80): the ten Philox round-key pairs (philox4x32_10_ldskeys)
+    if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
+    uint32_t kbase;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(kbase));
+    float *lp = reinterpret_cast<float *>(lds_raw + 20);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
     uint32_t *res = reinterpret_cast<uint32_t *>(cnt + ring);
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
     int tile = 0;            // wave-local sequence number of the set this lane works on
     bool has = false, active = false, invalid = false;
+    PathCtr pc = {0u, 0u, 0u};
 
     // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
     int tile_open = 0;       // tiles whose parameters are staged in LDS
@@ -378,6 +383,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     cb = -2.0f / (sig * sig);
                     if constexpr (FAST) cb = cb * 1.4426950408889634f;     // v_exp_f32 is 2^x
                 }
+                pc.init(trial, set_lo, c3, A.k0, A.k1);
                 am1 = invalid ? 0u : __float_as_uint(a) - 1u;
                 x = a * beta;
                 k = 0;
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
             const uint32_t blk = (uint32_t)k >> 2;
-            const u32x4 rb = philox4x32_10(blk, trial, set_lo, c3, A.k0, A.k1);
+            const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
             float inc[4];
             {
                 float r, cs, sn;
@@ -677,7 +683,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
-    const size_t lds = (size_t)ring * (P * 4 + 8) + (size_t)ring * tile_n * per_trial;
+    const size_t lds = 80 + (size_t)ring * (P * 4 + 8) + (size_t)ring * tile_n * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
     {

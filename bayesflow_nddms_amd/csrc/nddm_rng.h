@@ -34,6 +34,50 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return {c0, c1, c2, c3};
 }
 
+// The path stream's Philox block with (a) the round keys fetched from LDS and (b) round 0 partly precomputed.
+// (a) On gfx950 a VOP2 xor that reads an SGPR issues at ~4.2 cycles, a VGPR-only one at ~2.3; the LDS pipe is otherwise
+//     idle in the step loop, so it delivers the (wave-uniform) keys as broadcast reads, prefetched one round ahead.
+//     LDS bytes [0, 80) hold key pair r at 8r; kbase is a VGPR holding LDS byte address 0.
+// (b) Within one trial only the block index changes, so round 0's M1*set_lo product and both key xors are per-trial
+//     constants: PathCtr carries them instead of (trial, set_lo, set_hi).
+struct PathCtr {
+    uint32_t n0, n1, c3k;    // hi(M1*set_lo) ^ trial ^ k0 ; lo(M1*set_lo) ; (set_hi | stream tag) ^ k1
+    __device__ __forceinline__ void init(uint32_t trial, uint32_t set_lo, uint32_t c3, uint32_t k0, uint32_t k1)
+    {
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * set_lo;
+        n0 = (uint32_t)(p1 >> 32) ^ trial ^ k0;
+        n1 = (uint32_t)p1;
+        c3k = c3 ^ k1;
+    }
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t blk, const PathCtr &pc, uint32_t kbase)
+{
+    uint32_t ka, kb;
+    uint64_t kn;
+    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(kn) : "v"(kbase));          // keys of round 1
+    const uint64_t q0 = (uint64_t)0xD2511F53u * blk;                                 // round 0
+    uint32_t c0 = pc.n0, c1 = pc.n1, c2 = (uint32_t)(q0 >> 32) ^ pc.c3k, c3 = (uint32_t)q0;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+    ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32);
+#define NDDM_ROUND(NEXT_OFF, LAST)                                                                        \
+    {                                                                                                     \
+        if (!(LAST)) asm volatile("ds_read_b64 %0, %1 offset:" #NEXT_OFF : "=v"(kn) : "v"(kbase));        \
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;                                                   \
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;                                                   \
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;                                               \
+        const uint32_t n1 = (uint32_t)p1;                                                                 \
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;                                               \
+        const uint32_t n3 = (uint32_t)p0;                                                                 \
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
+        if (!(LAST)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn)); ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32); } \
+    }
+    NDDM_ROUND(16, false) NDDM_ROUND(24, false) NDDM_ROUND(32, false) NDDM_ROUND(40, false) NDDM_ROUND(48, false)
+    NDDM_ROUND(56, false) NDDM_ROUND(64, false) NDDM_ROUND(72, false) NDDM_ROUND(0, true)
+#undef NDDM_ROUND
+    return {c0, c1, c2, c3};
+}
+
 // ---------------------------------------------------------------- exact transform
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, every rounding spelled out.
 __device__ __forceinline__ float exact_logf(float u)
