@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_MODEL = {
     "clock_ghz": 2.4, "simds": 1024,
     # python tools/isa_mix.py: instruction mix of the step loop x per-instruction issue cost (profiles/r1_ubench_valu.txt)
-    "cycles_per_block_fast": 371.0, "cycles_per_block_exact": 670.0,
+    "cycles_per_block_fast": 338.0, "cycles_per_block_exact": 636.0,
 }
 
 
