@@ -44,7 +44,8 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
         f.write(f"* VALU wave-instructions per useful wave-block (64 lanes x 4 E-M steps) = {m['SQ_INSTS_VALU']/useful_blocks:.1f} "
                 f"(step-loop body: see tools/isa_mix.py); SALU = {m['SQ_INSTS_SALU']/useful_blocks:.1f}\n")
         f.write(f"* VALU issue rate = {m['SQ_INSTS_VALU']/dur/1024/clock:.3f} wave-instructions per SIMD-cycle "
-                f"(a full-rate VGPR-only op takes ~2.3 cycles, the kernel's mix averages ~3.9)\n")
+                f"= {1024*clock*dur/m['SQ_INSTS_VALU']:.2f} SIMD-cycles per VALU instruction (a full-rate VGPR-only op takes ~2.3; "
+                f"tools/isa_mix.py gives the loop's mix average)\n")
         if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
             f.write(f"* exec-mask utilisation of VALU instructions = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = "
                     f"{m['SQ_THREAD_CYCLES_VALU']/(64*m['SQ_ACTIVE_INST_VALU']):.3f}\n")
