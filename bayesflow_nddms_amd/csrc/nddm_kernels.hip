@@ -236,8 +236,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     //   raw parameter row | in-call set index | retire counter | packed results | z column
     // bytes [0, 80): the ten Philox round-key pairs (philox4x32_10_ldskeys)
     if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
+    // LDS byte address of the key table in a VGPR (the low 32 bits of a flat LDS address are the LDS offset); the asm
+    // keeps it opaque so that every ds_read in the step loop uses this one register + an immediate offset
     uint32_t kbase;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(kbase));
+    {
+        const uint32_t off = (uint32_t)(size_t)lds_raw;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
+    }
     float *lp = reinterpret_cast<float *>(lds_raw + 20);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
