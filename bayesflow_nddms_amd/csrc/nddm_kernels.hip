@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             }
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
-                const u32x4 u4 = philox4x32_10(blk, trial, set_lo, c3 | 0x30000000u, A.k0, A.k1);   // stream 3
+                const u32x4 u4 = philox4x32_10_lds(blk, trial, set_lo, c3 | 0x30000000u, kbase);   // stream 3
                 ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
             }
 #pragma unroll

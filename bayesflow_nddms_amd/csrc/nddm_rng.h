@@ -78,6 +78,32 @@ __device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t blk, const PathCtr 
     return {c0, c1, c2, c3};
 }
 
+// General counter, all ten key pairs from LDS (bridge-correction uniforms)
+__device__ __forceinline__ u32x4 philox4x32_10_lds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t kbase)
+{
+    uint32_t ka, kb;
+    uint64_t kn;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(kn) : "v"(kbase));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+    ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32);
+#define NDDM_ROUND(NEXT_OFF, LAST)                                                                        \
+    {                                                                                                     \
+        if (!(LAST)) asm volatile("ds_read_b64 %0, %1 offset:" #NEXT_OFF : "=v"(kn) : "v"(kbase));        \
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;                                                   \
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;                                                   \
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;                                               \
+        const uint32_t n1 = (uint32_t)p1;                                                                 \
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;                                               \
+        const uint32_t n3 = (uint32_t)p0;                                                                 \
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
+        if (!(LAST)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn)); ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32); } \
+    }
+    NDDM_ROUND(8, false) NDDM_ROUND(16, false) NDDM_ROUND(24, false) NDDM_ROUND(32, false) NDDM_ROUND(40, false)
+    NDDM_ROUND(48, false) NDDM_ROUND(56, false) NDDM_ROUND(64, false) NDDM_ROUND(72, false) NDDM_ROUND(0, true)
+#undef NDDM_ROUND
+    return {c0, c1, c2, c3};
+}
+
 // ---------------------------------------------------------------- exact transform
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, every rounding spelled out.
 __device__ __forceinline__ float exact_logf(float u)
