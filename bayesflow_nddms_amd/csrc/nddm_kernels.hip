@@ -684,7 +684,11 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (spc > 64) spc = 64;
     }
     A.sets_per_chunk = spc; A.ring = ring;
-    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : 8;
+    // refill threshold: a refill costs ~170 issue cycles whatever the number of lanes it serves, a waiting lane wastes
+    // its share of every block; with lambda completions per block the optimum is ~sqrt(61 lambda) finished lanes:
+    // 8 when trials last ~64 blocks (dt=.001, cap 4000), ~16-24 when they last ~7 (the reference default dt=.01, cap
+    // 400).  The cap is the only hint the host has about trial length.
+    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : (max_steps <= 1000 ? 16 : 8);
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
