@@ -660,7 +660,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
     const size_t per_trial = has_z ? 8 : 4;
     int tiles = g_tuning.tile_trials > 0 ? (n_trials + g_tuning.tile_trials - 1) / g_tuning.tile_trials
-                                         : (n_trials <= 1024 ? 1 : (n_trials + 511) / 512);
+                                         : (n_trials <= 512 ? 1 : (n_trials + 511) / 512);
     const int tile_n = (n_trials + tiles - 1) / tiles;
     tiles = (n_trials + tile_n - 1) / tile_n;
     const long long vB = B * (long long)tiles;
@@ -668,8 +668,9 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if ((long long)tile_n * tiles >= (1ll << 30) || n_trials >= (1 << 30))
         return fail(NDDM_ERR_SHAPE, "n_trials must be < 2^30%s");
     A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles; A.B = vB;
-    // geometry: ring slots so that >= ~4 wavefronts' worth of trials can be in flight per wave window
-    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((256 + tile_n - 1) / tile_n);
+    // geometry: ring slots so that the wave's window spans >= ~1024 trials (16 per lane): sets are flushed in order, so
+    // a straggler trial in the oldest set must not stall the lanes that are ahead of it
+    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((1024 + tile_n - 1) / tile_n);
     if (ring < 4) ring = 4;
     if (ring > 64) ring = 64;
     while (ring > 2 && (size_t)ring * tile_n * per_trial > 40 * 1024) ring >>= 1;

@@ -88,7 +88,7 @@ int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
  *   params      device f32 [B, P]
  *   B           number of parameter sets (rows)
  *   n_trials    trials per set (the batch-shared N of basic_ddm_dc.py:50-52, 131); any size: sets with more than
- *               1024 trials are split into tiles internally, with results independent of the split
+ *               512 trials are split into tiles internally, with results independent of the split
  *   dt          Euler-Maruyama step (reference default .01, basic_ddm_dc.py:87; fine study .001, single_trial_alpha_not_scaled.py:1719)
  *   max_steps   step cap (reference default 400; 4000 in the fine study)
  *   seed        64-bit stream key

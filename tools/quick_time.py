@@ -41,12 +41,8 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-    run(40000, 300, 0.001, 4000, True, (1, 0, 64, 64, 0, 0), lockstep=True)
     run(B, 300, 0.001, 4000, True)
-    run(B, 300, 0.001, 4000, False)
-    for tune in [(4, 0, 0, 0, 0, 0), (0, 0, 6, 0, 0, 0), (0, 0, 12, 0, 0, 0), (0, 8, 6, 0, 0, 0)]:
-        run(B, 300, 0.001, 4000, True, tune)
-    run(B, 300, 0.01, 400, True)
+    run(B // 4, 1000, 0.001, 4000, True)
+    run(B // 4, 600, 0.001, 4000, True)
+    run(B, 512, 0.001, 4000, True)
     run(B, 300, 0.001, 4000, True, model=1)
-    run(B, 300, 0.001, 4000, True, model=3)
-    run(B, 300, 0.001, 4000, True, model=3, bridge=True)
