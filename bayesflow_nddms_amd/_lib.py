@@ -32,6 +32,7 @@ def _declare(L):
         getattr(L, name).argtypes = [fp] + common + [fp, fp, vp]
     L.nddm_alpha_not_scaled_simulate.argtypes = [fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_explicit_boundary_simulate.argtypes = [fp, fp] + common + [fp, fp, vp]
+    L.nddm_simulate.argtypes = [c.c_int32, fp, fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_draw_prior.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, c.c_float, fp, vp]
     L.nddm_debug_normals.argtypes = [fp, c.c_int64, c.c_uint32, c.c_uint32, c.c_uint32, fp, vp]
     for name in EXPORTS:
@@ -44,7 +45,7 @@ EXPORTS = [
     "nddm_abi_version", "nddm_last_error", "nddm_device_count", "nddm_set_device", "nddm_summary_k",
     "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
-    "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_counters",
+    "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_counters",
 ]
 
 

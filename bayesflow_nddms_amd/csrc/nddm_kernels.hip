@@ -840,6 +840,15 @@ int nddm_explicit_boundary_simulate(const float *params, const float *bounds, in
                           flags, 0.0f, 0, out_trials, out_summary, nullptr, stream);
 }
 
+int nddm_simulate(int32_t model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
+                  int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma, int32_t ext_mode,
+                  float *out_trials, float *out_summary, float *out_extdata, void *stream)
+{
+    return nddm::simulate(model, params, model == NDDM_EXPLICIT_BOUNDARY ? bounds : nullptr, B, n_trials, dt, max_steps,
+                          seed, set_offset, flags, ext_sigma, ext_mode, out_trials, out_summary,
+                          model == NDDM_ALPHA_NOT_SCALED ? out_extdata : nullptr, stream);
+}
+
 int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
                     void *stream)
 {

@@ -136,6 +136,12 @@ int nddm_explicit_boundary_simulate(const float *params, const float *bounds, in
                                     float dt, int32_t max_steps, uint64_t seed, uint64_t set_offset,
                                     uint32_t flags, float *out_trials, float *out_summary, void *stream);
 
+/* generic dispatcher over enum nddm_model (the superset of the arguments above; `bounds` is read only by
+ * NDDM_EXPLICIT_BOUNDARY, `ext_sigma` / `ext_mode` / `out_extdata` only by NDDM_ALPHA_NOT_SCALED) */
+int nddm_simulate(int32_t model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
+                  int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma, int32_t ext_mode,
+                  float *out_trials, float *out_summary, float *out_extdata, void *stream);
+
 /* ---- prior / context samplers (basic_ddm_dc.py:50-80, single_trial_alpha_not_scaled.py:66-102) -------
  * On-device batched draw_prior(): out device f32 [B, P] in the model's parameter order
  * (P = nddm_model_nparams; gamma column of the single-trial family is filled with `gamma`).

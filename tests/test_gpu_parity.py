@@ -182,6 +182,23 @@ def test_geometry_independence():
     assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))
 
 
+def test_generic_dispatcher_matches_named_entries():
+    """nddm_simulate(model, ...) == the per-model entry points (raw C ABI call with torch device pointers)."""
+    import torch
+    from bayesflow_nddms_amd import _lib, engine
+    L = _lib.lib()
+    p = torch.as_tensor(prior_util.basic_prior(40, 2)).cuda()
+    ref = engine.simulate(0, p, 100, dt=0.01, max_steps=400, seed=3, set_offset=9, fast=True)
+    out = torch.empty((40, 100, 2), dtype=torch.float32, device="cuda")
+    summ = torch.empty((40, 10), dtype=torch.float32, device="cuda")
+    rc = L.nddm_simulate(0, p.data_ptr(), None, 40, 100, 0.01, 400, 3, 9, 1, 0.0, 0, out.data_ptr(), summ.data_ptr(), None,
+                         torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref["trials"]) and torch.equal(torch.nan_to_num(summ), torch.nan_to_num(ref["summary"]))
+    assert L.nddm_simulate(9, p.data_ptr(), None, 40, 100, 0.01, 400, 3, 9, 1, 0.0, 0, out.data_ptr(), None, None, None) == _lib.NDDM_ERR_PARAM
+
+
 def test_edge_cases():
     from bayesflow_nddms_amd import engine
     # timeouts are data: choice 0, rt = max_steps*dt + tau
