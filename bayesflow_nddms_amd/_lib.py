@@ -54,6 +54,12 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO_PATH):
+            try:                       # a fresh checkout: compile the HIP extension in-tree (hipcc, gfx950)
+                from .build import build_hip
+                build_hip()
+            except Exception:          # noqa: BLE001 -- reported just below
+                pass
+        if not os.path.exists(SO_PATH):
             raise NddmLibraryError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
