@@ -182,6 +182,22 @@ def test_geometry_independence():
     assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))
 
 
+def test_rejection_cap_fallback():
+    """Per-trial latent N(mu, std) > 0 with mu far below 0: the rejection loop hits its 64-draw cap and falls back to
+    |last draw| -- identically on the device and in the oracle (and the kernel terminates)."""
+    import oracle
+    from bayesflow_nddms_amd import engine
+    p = np.array([[1.0, -3.0, 0.5, 0.3, 0.5, 1.0, 0.2, 1.0]] * 3, dtype=np.float32)      # P(accept) ~ 1e-9 per draw
+    for model in (1, 2):
+        q = p.copy()
+        if model == 2:
+            q[:, 1], q[:, 5] = 1.0, -3.0          # alt: the latent is the diffusion coefficient (mu_dc at index 5)
+        g = engine.simulate(model, q, 70, dt=0.01, max_steps=400, seed=4, set_offset=0, fast=False)
+        o = oracle.philox_simulate(model, q, 70, dt=0.01, max_steps=400, seed=4, set_offset=0)
+        assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32))
+        assert np.all(np.isfinite(o["trials"]))
+
+
 def test_generic_dispatcher_matches_named_entries():
     """nddm_simulate(model, ...) == the per-model entry points (raw C ABI call with torch device pointers)."""
     import torch
