@@ -198,6 +198,29 @@ def test_rejection_cap_fallback():
         assert np.all(np.isfinite(o["trials"]))
 
 
+def test_device_resident_garbage_cannot_hang():
+    """Inputs that bypass host validation (device tensors): a negative / NaN explicit boundary marks that trial NaN
+    (the reference raises ValueError there), non-finite parameters give garbage rows -- and every launch terminates."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    b = torch.full((2, 40), 1.0, device="cuda")
+    b[0, 3], b[1, 7] = -0.5, float("nan")
+    r = engine.simulate(4, torch.tensor([[1.0, .5, .3, 1.0]] * 2, device="cuda"), 40, bounds=b, seed=1, set_offset=0)
+    t = r["trials"].cpu().numpy()
+    assert np.isnan(t[0, 3, 0]) and np.isnan(t[1, 7, 0]) and np.isfinite(np.delete(t[0, :, 0], 3)).all()
+    bad = torch.tensor([[float("nan"), 1.0, .5, .3, 1.0], [1.0, -1.0, .5, .3, 1.0], [1.0, 1.0, .5, .3, float("inf")],
+                        [1.0, 1.0, .5, .3, 0.0], [1.0, 0.0, .5, .3, 1.0]], device="cuda")
+    r = engine.simulate(0, bad, 64, dt=0.001, max_steps=4000, seed=1, set_offset=0)
+    torch.cuda.synchronize()
+    assert tuple(r["trials"].shape) == (5, 64, 2)
+    for model, P in ((1, 8), (2, 8), (3, 6)):
+        junk = torch.full((3, P), float("nan"), device="cuda")
+        junk[1] = -1.0
+        junk[2] = 1e30
+        engine.simulate(model, junk, 64, dt=0.001, max_steps=4000, seed=1, set_offset=0, bridge=(model == 3))
+        torch.cuda.synchronize()
+
+
 def test_generic_dispatcher_matches_named_entries():
     """nddm_simulate(model, ...) == the per-model entry points (raw C ABI call with torch device pointers)."""
     import torch
