@@ -21,6 +21,8 @@ Outputs (all under tests/golden/):
                 for dt=.01/max 400 (reference default) and dt=.001/max 4000
   ratcliff.npz  simulratcliff (exact first-passage sampler) quantile tables for
                 the alpha_not_scaled parameter ranges
+  mixture.npz   2000 parameter sets drawn from the basic_ddm_dc prior x 200 reference trials each, pooled
+                histogram of the signed step index (both dt configurations)
 
 Usage:  python tests/golden/make_golden.py [--kat] [--ks] [--ratcliff] [--priors] [--procs 8]
 This only runs in the build container (it needs /root/reference); the GPU box
@@ -299,6 +301,54 @@ def make_ks(procs):
     print("ks_hist.npz written", time.time() - t0, "s")
 
 
+# ---------------------------------------------------------------------------
+# prior-mixture tier: many parameter sets drawn from the prior, pooled distribution of the signed step index
+# ---------------------------------------------------------------------------
+def mixture_params(n_sets=2000, seed=99):
+    from scipy.stats import truncnorm
+    rng = np.random.default_rng(seed)
+    tn = lambda m, sd, lo, up: truncnorm.rvs((lo - m) / sd, (up - m) / sd, loc=m, scale=sd, size=n_sets, random_state=rng)
+    return np.stack([rng.normal(0.0, 2.0, n_sets), tn(1.0, .5, 0.0, 10.0), rng.beta(2.0, 2.0, n_sets),
+                     tn(.5, .25, 0.0, 1.5), tn(1.0, .5, 0.0, 10.0)], axis=1).astype(np.float32).astype(np.float64)
+
+
+def _mixture_chunk(job):
+    ci, lo, hi, n = job
+    dt, ms = DT_CONFIGS[ci]
+    K = int(ms)
+    if "basic" not in _NS:
+        _NS["basic"] = load_slice("basic_sim")
+    ns = _NS["basic"]
+    P = mixture_params()
+    hist = np.zeros((3, K + 1), dtype=np.int64)
+    np.random.seed(700_000 + 10_000 * ci + lo)
+    for b in range(lo, hi):
+        p = P[b]
+        for _ in range(n):
+            rt, ch = _basic_trial(ns, p, dt, ms)
+            k = int(round((rt - p[3]) / dt))
+            hist[0 if ch == 1 else (1 if ch == -1 else 2), k] += 1
+    return ci, hist
+
+
+def make_mixture(procs, n_per_set=200, step=25):
+    P = mixture_params()
+    jobs = [(ci, lo, min(lo + step, len(P)), n_per_set) for ci in (1, 0) for lo in range(0, len(P), step)]
+    acc = {}
+    t0 = time.time()
+    with Pool(procs) as pool:
+        for done, (ci, h) in enumerate(pool.imap_unordered(_mixture_chunk, jobs, chunksize=1)):
+            acc[ci] = acc.get(ci, 0) + h
+            if done % 20 == 0:
+                print(f"mixture: {done}/{len(jobs)} chunks, {time.time()-t0:.0f}s", flush=True)
+    out = {"params": P.astype(np.float32), "n_per_set": np.array(n_per_set), "dt": np.array([c[0] for c in DT_CONFIGS]),
+           "max_steps": np.array([c[1] for c in DT_CONFIGS])}
+    for ci, h in acc.items():
+        out[f"hist_c{ci}"] = h.astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "mixture.npz"), **out)
+    print("mixture.npz written", time.time() - t0, "s")
+
+
 def _ratcliff_chunk(job):
     si, chunk_id, n = job
     if "ratcliff" not in _NS:
@@ -338,16 +388,19 @@ if __name__ == "__main__":
     ap.add_argument("--priors", action="store_true")
     ap.add_argument("--ks", action="store_true")
     ap.add_argument("--ratcliff", action="store_true")
+    ap.add_argument("--mixture", action="store_true")
     ap.add_argument("--procs", type=int, default=8)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}; fixtures can only be regenerated in the build container")
-    everything = not (a.kat or a.priors or a.ks or a.ratcliff)
+    everything = not (a.kat or a.priors or a.ks or a.ratcliff or a.mixture)
     if a.kat or everything:
         make_kat()
     if a.priors or everything:
         make_priors()
     if a.ratcliff or everything:
         make_ratcliff(a.procs)
+    if a.mixture or everything:
+        make_mixture(a.procs)
     if a.ks or everything:
         make_ks(a.procs)

@@ -48,6 +48,25 @@ def test_ks_basic_vs_reference(ci, fast):
 
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("ci", [0, 1])
+def test_ks_prior_mixture_vs_reference(ci, fast):
+    """2000 parameter sets drawn from the prior x 200 trials each (4e5 per side): the pooled distribution of the
+    signed step index vs the same sets run through the reference's NumPy simulator (tests/golden/mixture.npz)."""
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("mixture.npz")
+    dt, ms = float(gold["dt"][ci]), float(gold["max_steps"][ci])
+    p = gold["params"]
+    r = engine.simulate(engine.BASIC_DDM_DC, p, int(gold["n_per_set"]), dt=dt, max_steps=ms, seed=45, set_offset=0,
+                        fast=fast, want_summary=False)
+    h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), p[:, 3], dt, int(ms))
+    g = gold[f"hist_c{ci}"]
+    assert h.sum() == g.sum()
+    assert dg.ks_signed(h, g) < KS_BAR, dg.ks_signed(h, g)
+    assert np.max(np.abs(dg.choice_probs(h) - dg.choice_probs(g))) < KS_BAR
+    assert dg.ks_conditional(h, g, 0) < KS_BAR and dg.ks_conditional(h, g, 1) < KS_BAR
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("ci", [0, 1])
 def test_ks_single_trial_vs_reference(ci, fast):
     from bayesflow_nddms_amd import diagnostics as dg, engine
     gold = _gold("ks_hist.npz")
