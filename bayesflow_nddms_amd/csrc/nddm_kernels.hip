@@ -661,8 +661,17 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
     const size_t per_trial = has_z ? 8 : 4;
+    // small launches (fewer trials than ~2 per lane of a full persistent grid) are latency-bound: cut the sets into
+    // tiles of as few as 64 trials so that the work spreads over as many waves as it can
+    const long long total_trials = B * (long long)n_trials;
+    const long long grid_lanes = 64ll * 7168;
+    int tile_cap = 512;
+    if (total_trials <= 8 * grid_lanes) {
+        tile_cap = 64;
+        while (tile_cap < 512 && (long long)tile_cap * 7168 < total_trials) tile_cap <<= 1;
+    }
     int tiles = g_tuning.tile_trials > 0 ? (n_trials + g_tuning.tile_trials - 1) / g_tuning.tile_trials
-                                         : (n_trials <= 512 ? 1 : (n_trials + 511) / 512);
+                                         : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
     const int tile_n = (n_trials + tiles - 1) / tiles;
     tiles = (n_trials + tile_n - 1) / tile_n;
     const long long vB = B * (long long)tiles;
@@ -685,6 +694,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         spc = (1200 + tile_n - 1) / tile_n;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
+        while (spc > 1 && vB / spc < 7168) spc >>= 1;     // never starve the grid for the sake of fewer queue pulls
     }
     A.sets_per_chunk = spc; A.ring = ring;
     // refill threshold: a refill costs ~170 issue cycles whatever the number of lanes it serves, a waiting lane wastes
