@@ -57,6 +57,8 @@ struct SimArgs {
     int n_total;              // trials per set (row stride of out_trials / bounds)
     int tiles_per_set;
     long long *partials;      // [B * tiles_per_set, 9] integer partial sums when tiles_per_set > 1, else null
+    const int *order;         // [B] processing order of the sets (longest expected trials first) or null = as given
+    const float *params_q;    // [B, P] parameter rows gathered into that order (sequential reads when a tile opens)
     int max_k;
     float dt;
     float sqrt_dt;
@@ -66,6 +68,7 @@ struct SimArgs {
     int n_chunks;
     unsigned int *chunk_counter;   // device word, zeroed before the launch: the next chunk to hand out
     int ring;                 // LDS ring slots (power of two)
+    int open_ahead;           // tiles staged ahead of the one being handed out (0 when work is scarce, else 1)
     float ext_sigma;
     int ext_mode;
     unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
@@ -272,9 +275,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     unsigned long long dbg_blocks = 0, dbg_refills = 0, dbg_t0 = 0, dbg_r0 = 0;
     if (A.dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
 
-    // open tiles while ring slots are free: fetch chunk ids dynamically, stage the parameter row of each new tile
+    // open tiles (fetch chunk ids from the global queue, stage the parameter row of each new tile) while ring slots
+    // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
+    // sets its neighbours could be working on (with an eager ring fill, 10,000 sets ended up on 2,500 of the
+    // 7,168 waves: 6x slower for mid-size batches)
     auto open_tiles = [&]() {
-        while (tile_open < flushed + ring) {
+        while (tile_open < flushed + ring && tile_open <= next_tile + A.open_ahead) {
             if (chunk_left == 0) {
                 if (!more) break;
                 unsigned int c = 0;
@@ -286,9 +292,17 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 chunk_left = (int)(left < A.sets_per_chunk ? left : A.sets_per_chunk);
             }
             const int slot = tile_open & ring_mask;
-            const long long prow = A.tiles_per_set == 1 ? (long long)chunk_set : (long long)(chunk_set / A.tiles_per_set);
-            if (lane < P) lp[slot * P + lane] = A.params[prow * P + lane];
-            if (lane == 0) { slot_set[slot] = chunk_set; cnt[slot] = 0; }
+            // queue position -> virtual set (set * tiles_per_set + tile), through the longest-first order if present
+            int vset = chunk_set, prow = chunk_set;
+            if (A.tiles_per_set != 1) prow = chunk_set / A.tiles_per_set;
+            const float *row = A.params + (long long)prow * P;
+            if (A.order) {
+                const int qt = chunk_set - prow * A.tiles_per_set;      // tile within the set (0 when not tiled)
+                row = A.params_q + (long long)prow * P;                 // rows are stored in queue order: sequential
+                vset = A.order[prow] * A.tiles_per_set + qt;
+            }
+            if (lane < P) lp[slot * P + lane] = row[lane];
+            if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; }
             chunk_set++; chunk_left--; tile_open++;
         }
     };
@@ -333,6 +347,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         }
         if (flushed == tile_open && !more && chunk_left == 0) break;
         // ------------------------------------------------------------ hand out new trials
+        if (tile_open <= next_tile + A.open_ahead && tile_open < flushed + ring && (more || chunk_left > 0)) {
+            open_tiles();
+            __syncthreads();
+        }
         {
             const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(!has);
             int tr = next_trial + (int)lane_rank(want_mask);
@@ -467,6 +485,77 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Longest-first scheduling.  Expected trial length differs by two orders of magnitude across the prior (a set of
+// wide-boundary, zero-drift trials keeps a wave busy ~100x longer than a fast one), so pulling sets in the given order
+// leaves a long tail at the end of a launch and mixes fast and slow trials in one wave.  A counting sort by the
+// expected number of Euler-Maruyama steps (closed-form mean first-passage time of the DDM, half-octave buckets,
+// slowest bucket first) removes both: +8 % at 1M sets, +40 % at 100k.  Only the ORDER of processing changes; outputs
+// stay at their set's position and do not depend on it.
+constexpr int ORDER_BUCKETS = 32;
+
+__device__ __forceinline__ int duration_bucket(int model, const float *p, float dt, int max_k)
+{
+    float v, a, beta, sg;
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: v = p[0]; a = p[1]; beta = p[2]; sg = p[4]; break;
+    case NDDM_SINGLE_TRIAL: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
+    case NDDM_SINGLE_TRIAL_ALT: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
+    case NDDM_ALPHA_NOT_SCALED: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
+    default: v = p[0]; a = 1.0f; beta = p[1]; sg = p[3]; break;
+    }
+    const float s2 = sg * sg, av = fabsf(v);
+    const float z = v >= 0.0f ? a * beta : a - a * beta;   // mirror negative drift: same mean time, no exp overflow
+    float et;                                           // mean first-passage time, seconds
+    if (av * a < 1e-3f * s2) et = z * (a - z) / s2;
+    else et = (a * (1.0f - __expf(-2.0f * av * z / s2)) / (1.0f - __expf(-2.0f * av * a / s2)) - z) / av;
+    float steps = et / dt;
+    if (!(steps >= 1.0f)) steps = 1.0f;                 // also catches NaN
+    if (steps > (float)max_k) steps = (float)max_k;
+    int b = (int)(2.0f * __log2f(steps));               // half-octave buckets
+    b = b < 0 ? 0 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
+    return ORDER_BUCKETS - 1 - b;                       // bucket 0 = slowest
+}
+
+// ws[0..31] histogram, ws[32..63] cursors (both zeroed before the launch)
+__global__ void order_hist_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws)
+{
+    __shared__ int h[ORDER_BUCKETS];
+    if (threadIdx.x < ORDER_BUCKETS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x)
+        atomicAdd(&h[duration_bucket(model, params + (long long)i * P, dt, max_k)], 1);
+    __syncthreads();
+    if (threadIdx.x < ORDER_BUCKETS && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void order_scatter_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws, int *order,
+                                     float *params_q)
+{
+    __shared__ int start[ORDER_BUCKETS], lh[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += ws[b]; } }
+    for (int base = blockIdx.x * blockDim.x; base < B; base += gridDim.x * blockDim.x) {
+        if (threadIdx.x < ORDER_BUCKETS) lh[threadIdx.x] = 0;
+        __syncthreads();
+        const int i = base + threadIdx.x;
+        int b = -1, r = 0;
+        if (i < B) {
+            b = duration_bucket(model, params + (long long)i * P, dt, max_k);
+            r = atomicAdd(&lh[b], 1);                   // rank within this block's share of the bucket (LDS)
+        }
+        __syncthreads();
+        if (threadIdx.x < ORDER_BUCKETS && lh[threadIdx.x])     // one global cursor bump per bucket per block
+            lbase[threadIdx.x] = atomicAdd(&ws[ORDER_BUCKETS + threadIdx.x], lh[threadIdx.x]);
+        __syncthreads();
+        if (i < B) {
+            const int q = start[b] + lbase[b] + r;
+            order[q] = i;
+            for (int j = 0; j < P; ++j) params_q[(long long)q * P + j] = params[(long long)i * P + j];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // sets split into several tiles: add the tiles' integer partial sums up and finalise the summary row (one thread per
 // set; exact integer arithmetic, so the result equals the single-tile path bit for bit)
 __global__ void combine_partials_kernel(const long long *partials, const float *params, int P, int tau_idx,
@@ -576,8 +665,8 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials; };
-static Tuning g_tuning = {0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order; };
+static Tuning g_tuning = {0, 0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
 // resident waves of a kernel instantiation on the current device (persistent grid size)
 template <typename K>
 static int resident_waves(K kernel, size_t lds_bytes)
@@ -661,15 +750,12 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
     const size_t per_trial = has_z ? 8 : 4;
-    // small launches (fewer trials than ~2 per lane of a full persistent grid) are latency-bound: cut the sets into
-    // tiles of as few as 64 trials so that the work spreads over as many waves as it can
+    // small and mid-size launches are bound by latency / by the slowest set (a set of 300 slow trials keeps one wave
+    // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
+    // wave to balance; from ~30M trials on, one tile of up to 512 trials per set is the efficient shape
     const long long total_trials = B * (long long)n_trials;
-    const long long grid_lanes = 64ll * 7168;
-    int tile_cap = 512;
-    if (total_trials <= 8 * grid_lanes) {
-        tile_cap = 64;
-        while (tile_cap < 512 && (long long)tile_cap * 7168 < total_trials) tile_cap <<= 1;
-    }
+    int tile_cap = 64;
+    while (tile_cap < 512 && (long long)tile_cap * 7168 * 8 < total_trials) tile_cap <<= 1;
     int tiles = g_tuning.tile_trials > 0 ? (n_trials + g_tuning.tile_trials - 1) / g_tuning.tile_trials
                                          : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
     const int tile_n = (n_trials + tiles - 1) / tiles;
@@ -694,7 +780,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         spc = (1200 + tile_n - 1) / tile_n;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
-        while (spc > 1 && vB / spc < 7168) spc >>= 1;     // never starve the grid for the sake of fewer queue pulls
+        while (spc > 1 && vB / spc < 32 * 7168) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
     }
     A.sets_per_chunk = spc; A.ring = ring;
     // refill threshold: a refill costs ~170 issue cycles whatever the number of lanes it serves, a waiting lane wastes
@@ -705,6 +791,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
+    A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
     const size_t lds = 80 + (size_t)ring * (P * 4 + 8) + (size_t)ring * tile_n * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
@@ -718,6 +805,13 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (e != hipSuccess || dev < 0 || dev >= 64) return fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
         std::lock_guard<std::mutex> lock(mu);
         if (!pool[dev]) {
+            // the stream-ordered scratch buffers (processing order, partial sums) come from the device's default memory
+            // pool: keep freed blocks cached instead of handing them back to the OS at every synchronisation
+            hipMemPool_t mp;
+            if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess) {
+                uint64_t keep = UINT64_MAX;
+                (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
+            }
             e = hipMalloc(reinterpret_cast<void **>(&pool[dev]), POOL * sizeof(unsigned int));
             if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(queue words): %s", hipGetErrorString(e));
         }
@@ -726,11 +820,34 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMemsetAsync(queue word): %s", hipGetErrorString(e));
     }
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
+    // longest-first processing order (stream-ordered scratch: 64 counters + B indices + the gathered parameter rows)
+    A.order = nullptr;
+    int *order_ws = nullptr;
+    if (B >= 2048 && g_tuning.no_order == 0) {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&order_ws), (size_t)(64 + B + B * P) * sizeof(int), st);
+        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(order): %s", hipGetErrorString(e));
+        e = hipMemsetAsync(order_ws, 0, 64 * sizeof(int), st);
+        if (e != hipSuccess) { (void)hipFreeAsync(order_ws, st); return fail(NDDM_ERR_HIP, "hipMemsetAsync(order): %s", hipGetErrorString(e)); }
+        const int threads = 256;
+        long long blocks = (B + threads - 1) / threads;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
+                           (int)max_steps, order_ws);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
+                           (int)max_steps, order_ws, order_ws + 64, reinterpret_cast<float *>(order_ws + 64 + B));
+        e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFreeAsync(order_ws, st); return fail(NDDM_ERR_HIP, "order kernels: %s", hipGetErrorString(e)); }
+        A.order = order_ws + 64;
+        A.params_q = reinterpret_cast<const float *>(order_ws + 64 + B);
+    }
     // split sets: the tiles leave integer partial sums in a stream-ordered scratch buffer
     A.partials = nullptr;
     if (tiles > 1 && out_summary) {
         const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&A.partials), (size_t)vB * 9 * sizeof(long long), st);
-        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
+        if (e != hipSuccess) {
+            if (order_ws) (void)hipFreeAsync(order_ws, st);
+            return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
+        }
     }
     int rc;
     switch (model) {
@@ -743,6 +860,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         break;
     default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st); break;
     }
+    if (order_ws) (void)hipFreeAsync(order_ws, st);
     if (A.partials) {
         if (rc == NDDM_OK) {
             const int tau_idx = model == NDDM_EXPLICIT_BOUNDARY ? 2 : 3;
@@ -797,7 +915,15 @@ int nddm_set_device(int device)
 int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves, int tile_trials)
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
-    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials};
+    const int no_order = nddm::g_tuning.no_order;
+    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order};
+    return NDDM_OK;
+}
+
+/* benchmarking aid: 1 = process the sets in the given order (no longest-first sort) */
+int nddm_set_ordering(int enabled)
+{
+    nddm::g_tuning.no_order = enabled ? 0 : 1;
     return NDDM_OK;
 }
 

@@ -10,8 +10,30 @@ from bayesflow_nddms_amd import engine, _lib
 
 def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockstep=False, bridge=False):
     p = {0: prior_util.basic_prior, 1: prior_util.single_prior, 3: prior_util.alpha_ns_prior}[model](B, 2023)
-    if lockstep:   # every trial runs to the cap: all lanes busy, no refill -> pure step-loop cost
+    if lockstep == 'typical':   # identical, typical parameters: no slow sets
+        p[:] = np.array([1.5, 1.2, 0.5, 0.35, 1.0], dtype=np.float32)
+    elif lockstep:   # every trial runs to the cap: all lanes busy, no refill -> pure step-loop cost
         p[:] = np.array([0.0, 50.0, 0.5, 0.3, 1.0], dtype=np.float32)
+    if os.environ.get('NDDM_SORT'):
+        v, a, z, s = p[:, 0].astype(np.float64), p[:, 1].astype(np.float64), (p[:, 1] * p[:, 2]).astype(np.float64), p[:, 4].astype(np.float64)
+        with np.errstate(all='ignore'):
+            et = np.where(np.abs(v) < 1e-3, z * (a - z) / s**2, -z / v + (a / v) * (1 - np.exp(-2 * v * z / s**2)) / (1 - np.exp(-2 * v * a / s**2)))
+        et = np.nan_to_num(et, nan=4.0, posinf=4.0)
+        order = np.argsort(-np.minimum(et, 4.0), kind='stable')
+        if os.environ['NDDM_SORT'] == 'dev':
+            v32, a32, be32, s32 = p[:, 0], p[:, 1], p[:, 2], p[:, 4]
+            z32 = a32 * be32; s2 = s32 * s32
+            with np.errstate(all='ignore'):
+                et32 = np.where(np.abs(v32) * a32 < 1e-3 * s2, z32 * (a32 - z32) / s2, (-z32 + a32 * (1 - np.exp(-2 * v32 * z32 / s2)) / (1 - np.exp(-2 * v32 * a32 / s2))) / v32)
+            st = et32 / np.float32(dt)
+            st = np.where(st >= 1, st, 1).astype(np.float32)
+            st = np.minimum(st, ms)
+            bk = np.clip((2 * np.log2(st)).astype(np.int32), 0, 31)
+            order = np.argsort(-bk, kind='stable')
+            print('bucket histogram (slowest first):', np.bincount(31 - bk, minlength=32))
+        if os.environ['NDDM_SORT'] == 'bucket':
+            order = np.argsort(-np.floor(np.log2(np.maximum(np.minimum(et, 4.0), 1e-3)) * 2), kind='stable')
+        p = p[order]
     pd = torch.as_tensor(p).cuda()
     if tune:
         _lib.check(_lib.lib().nddm_set_tuning(*tune))
@@ -40,9 +62,12 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
     _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 if __name__ == "__main__":
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-    run(B, 300, 0.001, 4000, True)
-    run(B // 4, 1000, 0.001, 4000, True)
-    run(B // 4, 600, 0.001, 4000, True)
-    run(B, 512, 0.001, 4000, True)
-    run(B, 300, 0.001, 4000, True, model=1)
+    for B in (1000, 3000, 10000, 30000, 100000, 300000, 1000000, 3000000):
+        run(B, 300, 0.001, 4000, True, reps=3)
+    run(1000000, 300, 0.01, 400, True, reps=3)
+    run(1000000, 300, 0.001, 4000, False, reps=3)
+    run(1000000, 300, 0.001, 4000, True, model=1, reps=3)
+    run(1000000, 300, 0.001, 4000, True, model=3, reps=3)
+    run(1000000, 300, 0.001, 4000, True, model=3, bridge=True, reps=3)
+    run(1000000, 60, 0.001, 4000, True, reps=3)
+    run(1000000, 180, 0.001, 4000, True, reps=3)
