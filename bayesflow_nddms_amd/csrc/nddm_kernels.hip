@@ -76,20 +76,29 @@ struct SimArgs {
     int max_blocks;           // ... or after this many Philox blocks (4 steps each)
 };
 
-// auxiliary normal `a` of (set, trial): stream 1
+// auxiliary normal `a` of (set, trial): stream 1.  One Philox block serves normals 4b..4b+3; each Box-Muller pair is
+// evaluated only when one of its two normals is asked for (the common case needs a = 0 and a = 1: one pair).
 template <bool FAST>
 struct AuxStream {
-    uint32_t k0, k1, trial, set_lo, c3, blk;
+    uint32_t trial, set_lo, c3, blk, kbase;
+    u32x4 x;
     float z[4];
-    __device__ __forceinline__ AuxStream(uint32_t k0_, uint32_t k1_, uint64_t set, uint32_t trial_)
-        : k0(k0_), k1(k1_), trial(trial_), set_lo((uint32_t)set),
-          c3(((uint32_t)(set >> 32) & 0x0fffffffu) | 0x10000000u), blk(0xffffffffu) {}
+    bool have01, have23;
+    __device__ __forceinline__ AuxStream(uint32_t kbase_, uint64_t set, uint32_t trial_)
+        : trial(trial_), set_lo((uint32_t)set), c3(((uint32_t)(set >> 32) & 0x0fffffffu) | 0x10000000u),
+          blk(0xffffffffu), kbase(kbase_), have01(false), have23(false) {}
     __device__ __forceinline__ float normal(uint32_t a)
     {
         const uint32_t b = a >> 2;
-        if (b != blk) { normals4<FAST>(b, trial, set_lo, c3, k0, k1, z); blk = b; }
+        if (b != blk) { x = philox4x32_10_lds(b, trial, set_lo, c3, kbase); blk = b; have01 = false; have23 = false; }
         const uint32_t j = a & 3u;
-        return j == 0 ? z[0] : (j == 1 ? z[1] : (j == 2 ? z[2] : z[3]));
+        const float sc = radius_scale<FAST>(1.0f);
+        if (j < 2u) {
+            if (!have01) { float r, cs, sn; polar_pair<FAST>(x.x, x.y, sc, r, cs, sn); z[0] = r * cs; z[1] = r * sn; have01 = true; }
+            return j == 0u ? z[0] : z[1];
+        }
+        if (!have23) { float r, cs, sn; polar_pair<FAST>(x.z, x.w, sc, r, cs, sn); z[2] = r * cs; z[3] = r * sn; have23 = true; }
+        return j == 2u ? z[2] : z[3];
     }
 };
 
@@ -141,10 +150,12 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
 }
 
 // The fused epilogue of one tile (= one parameter set unless the set is split): coalesced (col0, col1) stores +
-// summary reduction.  vset = set * tiles_per_set + tile.
+// summary reduction.  vset = set * tiles_per_set + tile.  Models with an external datum (z1 / the explicit boundary)
+// wrote column 1 straight to HBM when each trial retired and keep only integer sums of it in LDS (zsum), so that their
+// LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
 template <int MODEL, bool FAST>
 __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long vset, const float *pp,
-                                          const uint32_t *res, const float *zres)
+                                          const uint32_t *res, const long long *zsum, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
     const int N = A.n_trials;
@@ -163,35 +174,28 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
         const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
         const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
         const float rt = __builtin_fmaf((float)k, A.tscale, tau);
-        float zval = 0.0f;
-        if constexpr (T::HAS_Z) zval = zres[j];
         float2 o;
         if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
         else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
-        else { o.x = ch * rt; o.y = zval; }
+        else { o.x = ch * rt; o.y = 0.0f; }
         if (code == 3u) o.x = __builtin_nanf("");
-        if (out) out[j] = o;
+        if (out) {
+            if constexpr (T::HAS_Z) reinterpret_cast<float *>(out)[2 * j] = o.x;     // column 1 is already in place
+            else out[j] = o;
+        }
         if (A.out_summary) {
             const unsigned long long kk = (unsigned long long)k * k;
             if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
             else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
             else n_miss++;
-            if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                double zd = (double)zval;
-                zd = zd > 1.0e6 ? 1.0e6 : zd;
-                zd = zd < -1.0e6 ? -1.0e6 : zd;
-                sz += (long long)(zd * 4294967296.0);
-                szz += (long long)((zd * zd) * 16777216.0);
-            }
         }
+    }
+    if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
+        if (lane == 0) { sz = zsum[0]; szz = zsum[1]; }
     }
     if (A.out_summary) {
         n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
         sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-        if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-            sz = (long long)wave_sum((unsigned long long)sz);
-            szz = (long long)wave_sum((unsigned long long)szz);
-        }
         if (lane == 0) {
             if (TPS == 1) {
                 finalize_summary(A.out_summary + set_in_call * NDDM_SUMMARY_K, n_up, n_lo, n_miss, sk, sk2, sk_up, sk2_up,
@@ -205,7 +209,7 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
         if (A.out_ext && lane == 0 && t0 == 0) {
-            AuxStream<FAST> aux(A.k0, A.k1, A.set_offset + (unsigned long long)set_in_call, 0xffffffffu);
+            AuxStream<FAST> aux(kbase, A.set_offset + (unsigned long long)set_in_call, 0xffffffffu);
             const float loc = (A.ext_mode == 0) ? pp[1] : 1.0f;
             A.out_ext[set_in_call] = __builtin_fmaf(A.ext_sigma, aux.normal(0), loc);
         }
@@ -251,8 +255,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     float *lp = reinterpret_cast<float *>(lds_raw + 20);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
-    uint32_t *res = reinterpret_cast<uint32_t *>(cnt + ring);
-    float *zres = reinterpret_cast<float *>(res + (size_t)ring * N);
+    long long *zsum = reinterpret_cast<long long *>(cnt + ring);      // [ring][2]: fixed-point sums of z and z^2
+    uint32_t *res = reinterpret_cast<uint32_t *>(zsum + 2 * ring);
 
     // per-lane trial state
     float x = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 vset = A.order[prow] * A.tiles_per_set + qt;
             }
             if (lane < P) lp[slot * P + lane] = row[lane];
-            if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; }
+            if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; zsum[2 * slot] = 0; zsum[2 * slot + 1] = 0; }
             chunk_set++; chunk_left--; tile_open++;
         }
     };
@@ -321,7 +325,26 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
             res[(size_t)slot * N + ltrial] = tfix | (code << 30);
-            if constexpr (T::HAS_Z) zres[(size_t)slot * N + ltrial] = zout;
+            if constexpr (T::HAS_Z) {
+                if (trial < (uint32_t)A.n_total) {           // not a padding trial of a split set's last tile
+                    if (A.out_trials) {
+                        const int vs = slot_set[slot];
+                        const long long sic = A.tiles_per_set == 1 ? (long long)vs : (long long)(vs / A.tiles_per_set);
+                        A.out_trials[(sic * A.n_total + trial) * 2 + 1] = zout;
+                    }
+                    if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
+                        if (A.out_summary) {
+                            double zd = (double)zout;
+                            zd = zd > 1.0e6 ? 1.0e6 : zd;
+                            zd = zd < -1.0e6 ? -1.0e6 : zd;
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]),
+                                      (unsigned long long)(long long)(zd * 4294967296.0));
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]),
+                                      (unsigned long long)(long long)((zd * zd) * 16777216.0));
+                        }
+                    }
+                }
+            }
             atomicAdd(&cnt[slot], 1);
             has = false;
             am1 = 0;             // an idle lane is never in range
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
                 flush_set<MODEL, FAST>(A, lane, (long long)set_in_call, lp + slot * P, res + (size_t)slot * N,
-                                       zres + (size_t)slot * N);
+                                       zsum + 2 * slot, kbase);
                 flushed++;
                 gate += (unsigned long long)N;
             }
@@ -379,20 +402,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     drift = pp[0]; a = pp[1]; beta = pp[2]; sig_c = pp[4];
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     drift = pp[0]; beta = pp[2]; sig_c = pp[5];
-                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    AuxStream<FAST> aux(kbase, gset, trial);
                     uint32_t ai = 1;
                     do { a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]); ai++; } while (!(a > 0.0f) && ai <= MAX_REJECT);
                     if (!(a > 0.0f)) a = fabsf(a);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * a);
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     drift = pp[0]; a = pp[1]; beta = pp[2];
-                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    AuxStream<FAST> aux(kbase, gset, trial);
                     uint32_t ai = 1;
                     do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    AuxStream<FAST> aux(A.k0, A.k1, gset, trial);
+                    AuxStream<FAST> aux(kbase, gset, trial);
                     drift = __builtin_fmaf(pp[4], aux.normal(0), pp[0]);
                     a = pp[1]; beta = pp[2]; sig_c = pp[5];
                 } else {   // NDDM_EXPLICIT_BOUNDARY
@@ -749,7 +772,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
 
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
-    const size_t per_trial = has_z ? 8 : 4;
+    const size_t per_trial = 4;   // packed (time | choice) word; z columns go straight to HBM
+    (void)has_z;
     // small and mid-size launches are bound by latency / by the slowest set (a set of 300 slow trials keeps one wave
     // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
     // wave to balance; from ~30M trials on, one tile of up to 512 trials per set is the efficient shape
@@ -768,7 +792,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // geometry: ring slots so that the wave's window spans >= ~1024 trials (16 per lane): sets are flushed in order, so
     // a straggler trial in the oldest set must not stall the lanes that are ahead of it
     int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((1024 + tile_n - 1) / tile_n);
-    if (ring < 4) ring = 4;
+    if (ring < 4 && !g_tuning.ring) ring = 4;
+    if (ring < 2) ring = 2;
     if (ring > 64) ring = 64;
     while (ring > 2 && (size_t)ring * tile_n * per_trial > 40 * 1024) ring >>= 1;
     if ((size_t)ring * tile_n * per_trial > 60 * 1024)
@@ -792,7 +817,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
     A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
-    const size_t lds = 80 + (size_t)ring * (P * 4 + 8) + (size_t)ring * tile_n * per_trial;
+    const size_t lds = 80 + (size_t)ring * (P * 4 + 8 + 16) + (size_t)ring * tile_n * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
     {

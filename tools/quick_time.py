@@ -62,10 +62,6 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
     _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 if __name__ == "__main__":
-    run(1000000, 300, 0.001, 4000, False, reps=3)
-    run(1000000, 300, 0.01, 400, True, reps=3)
     run(1000000, 300, 0.001, 4000, True, model=1, reps=3)
-    run(1000000, 300, 0.001, 4000, True, model=3, reps=3)
-    run(1000000, 300, 0.001, 4000, True, model=3, bridge=True, reps=3)
-    for B in (3000000, 300000, 100000, 30000, 10000):
-        run(B, 300, 0.001, 4000, True, reps=3)
+    run(1000000, 300, 0.001, 4000, True, model=1, reps=3, trials_out=False)
+    run(1000000, 300, 0.001, 4000, True, reps=3)
