@@ -182,6 +182,25 @@ def test_geometry_independence():
     assert np.array_equal(np.concatenate(parts).view(np.uint32), base.view(np.uint32))
 
 
+def test_ordering_with_split_sets_and_models():
+    """Longest-first scheduling is active from 2048 sets on: combine it with split sets (n_trials > 512) and with every
+    model; output must stay a pure function of (seed, set, trial)."""
+    for model, B, N in (("basic", 2500, 700), ("single", 2100, 64), ("alpha_ns", 2048, 130), ("explicit", 2300, 50),
+                        ("alt", 2200, 33)):
+        p, g, o = _run_both(model, B=B, N=N, dt=0.01, max_steps=400.0, seed=31)
+        assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32)), model
+        assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32)), model
+    from bayesflow_nddms_amd import _lib, engine
+    p = prior_util.basic_prior(5000, 8)
+    a = engine.simulate(0, p, 100, dt=0.01, max_steps=400, seed=2, set_offset=0, fast=True)["trials"].cpu().numpy()
+    try:
+        _lib.lib().nddm_set_ordering(0)
+        b = engine.simulate(0, p, 100, dt=0.01, max_steps=400, seed=2, set_offset=0, fast=True)["trials"].cpu().numpy()
+    finally:
+        _lib.lib().nddm_set_ordering(1)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_rejection_cap_fallback():
     """Per-trial latent N(mu, std) > 0 with mu far below 0: the rejection loop hits its 64-draw cap and falls back to
     |last draw| -- identically on the device and in the oracle (and the kernel terminates)."""
