@@ -9,6 +9,9 @@
 //   * one 64-lane wavefront per workgroup, PERSISTENT grid (as many waves as stay resident);
 //     a wave pulls CHUNKS of consecutive parameter sets from a device-wide atomic counter and
 //     streams through them without draining between chunks.
+//   * sets are pulled longest-expected-duration first (a counting sort by the DDM's closed-form
+//     mean first-passage time runs ahead of the simulator), so the launch has no slow-set tail and
+//     the lanes of a wave work on trials of similar length.
 //   * one lane = one trial at a time.  Trial length is heavy-tailed (median 107, p99 2243
 //     steps at dt=.001), so lanes are PERSISTENT: a lane whose trial has ended retires it and
 //     takes the next unassigned (set, trial) of the wave's stream in order (wave ballot +
