@@ -25,7 +25,8 @@ COST = {"v_mad_u64_u32": 4.67, "v_xor_b32": 2.32, "v_cvt_f32_u32": 4.12, "v_cvt_
 # measured: a VOP2 integer/float op that reads an SGPR (or VCC) operand, and the 3-operand integer VOP3 forms, issue at
 # ~4.2 cycles instead of ~2.3 (profiles/r1_ubench_valu.txt rows "v_xor_b32 (sgpr)", v_add3_u32, v_alignbit_b32,
 # "v_cndmask_e64 (s)")
-COST.update({"v_add3_u32": 4.22, "v_alignbit_b32": 4.15, "v_cndmask_b32": 4.22})
+COST.update({"v_add3_u32": 4.22, "v_alignbit_b32": 4.15, "v_cndmask_b32": 4.22, "v_pk_fma_f32": 4.19, "v_pk_mul_f32": 4.19,
+             "v_pk_add_f32": 4.20})
 SGPR_OPERAND_COST = 4.16
 FULL_RATE = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_add_f32", "v_sub_f32",
              "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"}

@@ -91,6 +91,21 @@ DEF_KERNEL(k_add3, U8, OP8_3("v_add3_u32"), SINKU)
 DEF_KERNEL(k_alignbit, US8, OP8_ALIGN, SINKU)
 DEF_KERNEL(k_cndmask_s, US8, OP8_CNDS, SINKU)
 DEF_KERNEL(k_cmp_e64, U8, asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0\n v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cmp_lt_u32_e64 s[22:23], %1, %0" :: "v"(a0), "v"(c) : "s20", "s21", "s22", "s23");, SINKU)
+#define P8 double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; double c = 1.0001
+#define SINKP out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7)
+#define OP8_PK(INS) \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a0) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a2) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1, %1" : "+v"(a6) : "v"(c)); asm volatile(INS " %0, %0, %1, %1" : "+v"(a7) : "v"(c));
+#define OP8_PK2(INS) \
+    asm volatile(INS " %0, %0, %1" : "+v"(a0) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a2) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a6) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a7) : "v"(c));
+DEF_KERNEL(k_pk_fma, P8, OP8_PK("v_pk_fma_f32"), SINKP)
+DEF_KERNEL(k_pk_mul, P8, OP8_PK2("v_pk_mul_f32"), SINKP)
+DEF_KERNEL(k_pk_add, P8, OP8_PK2("v_pk_add_f32"), SINKP)
 DEF_KERNEL(k_cmp, F8, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0" :: "v"(a0), "v"(c) : "vcc");, SINKF)
 
 typedef void (*kern_t)(float *, uint64_t *);
@@ -112,7 +127,8 @@ int main(int argc, char **argv)
                   {"v_log_f32", k_log}, {"v_sqrt_f32", k_sqrt}, {"v_sin_f32", k_sin}, {"v_cos_f32", k_cos},
                   {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}, {"v_xor_b32 (sgpr)", k_xor_sgpr},
                   {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit}, {"v_cndmask_e64 (s)", k_cndmask_s},
-                  {"v_cmp_lt_u32_e64", k_cmp_e64}};
+                  {"v_cmp_lt_u32_e64", k_cmp_e64}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
+                  {"v_pk_add_f32", k_pk_add}};
     printf("%-18s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
     printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
