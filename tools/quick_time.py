@@ -14,26 +14,6 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
         p[:] = np.array([1.5, 1.2, 0.5, 0.35, 1.0], dtype=np.float32)
     elif lockstep:   # every trial runs to the cap: all lanes busy, no refill -> pure step-loop cost
         p[:] = np.array([0.0, 50.0, 0.5, 0.3, 1.0], dtype=np.float32)
-    if os.environ.get('NDDM_SORT'):
-        v, a, z, s = p[:, 0].astype(np.float64), p[:, 1].astype(np.float64), (p[:, 1] * p[:, 2]).astype(np.float64), p[:, 4].astype(np.float64)
-        with np.errstate(all='ignore'):
-            et = np.where(np.abs(v) < 1e-3, z * (a - z) / s**2, -z / v + (a / v) * (1 - np.exp(-2 * v * z / s**2)) / (1 - np.exp(-2 * v * a / s**2)))
-        et = np.nan_to_num(et, nan=4.0, posinf=4.0)
-        order = np.argsort(-np.minimum(et, 4.0), kind='stable')
-        if os.environ['NDDM_SORT'] == 'dev':
-            v32, a32, be32, s32 = p[:, 0], p[:, 1], p[:, 2], p[:, 4]
-            z32 = a32 * be32; s2 = s32 * s32
-            with np.errstate(all='ignore'):
-                et32 = np.where(np.abs(v32) * a32 < 1e-3 * s2, z32 * (a32 - z32) / s2, (-z32 + a32 * (1 - np.exp(-2 * v32 * z32 / s2)) / (1 - np.exp(-2 * v32 * a32 / s2))) / v32)
-            st = et32 / np.float32(dt)
-            st = np.where(st >= 1, st, 1).astype(np.float32)
-            st = np.minimum(st, ms)
-            bk = np.clip((2 * np.log2(st)).astype(np.int32), 0, 31)
-            order = np.argsort(-bk, kind='stable')
-            print('bucket histogram (slowest first):', np.bincount(31 - bk, minlength=32))
-        if os.environ['NDDM_SORT'] == 'bucket':
-            order = np.argsort(-np.floor(np.log2(np.maximum(np.minimum(et, 4.0), 1e-3)) * 2), kind='stable')
-        p = p[order]
     pd = torch.as_tensor(p).cuda()
     if tune:
         _lib.check(_lib.lib().nddm_set_tuning(*tune))
@@ -62,6 +42,15 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
     _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 if __name__ == "__main__":
-    run(1000000, 300, 0.001, 4000, True, model=1, reps=3)
-    run(1000000, 300, 0.001, 4000, True, model=1, reps=3, trials_out=False)
-    run(1000000, 300, 0.001, 4000, True, reps=3)
+    # usage: python tools/quick_time.py [sets]   -- throughput sweep over models / step sizes / batch sizes
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    run(B, 300, 0.001, 4000, True)
+    run(B, 300, 0.001, 4000, False)
+    run(B, 300, 0.01, 400, True)
+    run(B, 300, 0.001, 4000, True, model=1)
+    run(B, 300, 0.001, 4000, True, model=3)
+    run(B, 300, 0.001, 4000, True, model=3, bridge=True)
+    run(B, 60, 0.001, 4000, True)
+    for b in (3000000, 300000, 100000, 30000, 10000, 1000):
+        run(b, 300, 0.001, 4000, True)
+    run(40000, 300, 0.001, 4000, True, (1, 0, 64, 64, 0, 0), lockstep=True)     # every lane busy: pure step-loop cost
