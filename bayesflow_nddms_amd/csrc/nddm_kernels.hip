@@ -268,7 +268,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
     int tile = 0;            // wave-local sequence number of the set this lane works on
-    bool has = false, active = false, invalid = false;
+    bool invalid = false;
+    // which lanes hold a trial / are still stepping: wave-uniform lane masks kept in SGPRs (a per-lane bool that is
+    // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
+    unsigned long long has_m = 0ull, act_m = 0ull;
     PathCtr pc = {0u, 0u, 0u};
 
     // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
@@ -318,10 +321,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     while (true) {
         // ------------------------------------------------------------ retire finished trials
-        const bool fin = has && !active;
-        const unsigned long long fin_mask0 = __builtin_amdgcn_ballot_w64(fin);
+        const unsigned long long fin_mask0 = has_m & ~act_m;
         dbg_refills++;
-        if (fin) {
+        if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
             const float a = __uint_as_float(am1 + 1u);
             const uint32_t code = invalid ? 3u : (x >= a ? 1u : (x <= 0.0f ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
@@ -349,9 +351,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 }
             }
             atomicAdd(&cnt[slot], 1);
-            has = false;
-            am1 = 0;             // an idle lane is never in range
         }
+        has_m &= ~fin_mask0;
         retired += (unsigned long long)__popcll(fin_mask0);
         // ------------------------------------------------------------ flush complete sets, in order (rare path:
         // only entered when enough trials have retired for the oldest tile to possibly be complete)
@@ -378,15 +379,15 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             __syncthreads();
         }
         {
-            const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(!has);
+            const unsigned long long want_mask = ~has_m;
             int tr = next_trial + (int)lane_rank(want_mask);
             int tl = next_tile;
             while (tr >= N) { tr -= N; tl++; }
-            const bool ok = !has && tl < tile_open;
-            const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(ok);
+            const unsigned long long ok_mask = want_mask & __builtin_amdgcn_ballot_w64(tl < tile_open);
             next_trial += (int)__popcll(ok_mask);
             while (next_trial >= N) { next_trial -= N; next_tile++; }
-            if (ok) {
+            has_m |= ok_mask;
+            if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
                 tile = tl;
                 trial = (uint32_t)tr;
                 ltrial = (uint32_t)tr;
@@ -439,14 +440,15 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 x = a * beta;
                 k = 0;
                 jit = 0;
-                has = true;
-                active = !invalid && in_range(x, am1) && (0 < A.max_k);
             }
+            // fresh compares over all lanes (an invalid trial has am1 == 0 and is never in range; lanes without a trial
+            // are masked by has_m)
+            act_m = __builtin_amdgcn_ballot_w64(in_range(x, am1)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
-        const unsigned long long has_mask = __builtin_amdgcn_ballot_w64(has);
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
+            bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
             const uint32_t blk = (uint32_t)k >> 2;
             const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
             float inc[4];
@@ -493,12 +495,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     }
                 }
             }
-            // one fresh compare for every lane (idle lanes have am1 == 0, finished lanes sit outside their range):
-            // a ballot of a compare is just its SGPR result, a ballot of the loop-carried flag would be rebuilt
-            // through v_cndmask + v_cmp
-            active = in_range(x, am1) && (k < A.max_k);
-            const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
-            if (act_mask == 0ull || __popcll(has_mask & ~act_mask) >= A.refill_thresh) break;
+            // fresh compares for every lane, combined as SGPR masks: a ballot of a compare is just its SGPR result, a
+            // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
+            act_m = __builtin_amdgcn_ballot_w64(in_range(x, am1)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
         }
     }
     if (A.dbg && lane == 0) {

@@ -108,6 +108,16 @@ DEF_KERNEL(k_pk_mul, P8, OP8_PK2("v_pk_mul_f32"), SINKP)
 DEF_KERNEL(k_pk_add, P8, OP8_PK2("v_pk_add_f32"), SINKP)
 DEF_KERNEL(k_cmp, F8, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0\n v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %0" :: "v"(a0), "v"(c) : "vcc");, SINKF)
 
+// mixed streams: does the transcendental pipe overlap with ordinary VALU issue?  (2 trans + 6 simple per 8)
+#define M8 float f0 = threadIdx.x + 2.f, f1 = f0 + 1.f; uint32_t a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13; uint32_t c = 0xD2511F53u
+#define SINKM out[blockIdx.x * blockDim.x + threadIdx.x] = f0 + f1 + (float)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5)
+#define OP8_MIX(T, INS) \
+    asm volatile(T " %0, %0" : "+v"(f0)); asm volatile(INS " %0, %0, %1" : "+v"(a0) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a2) : "v"(c)); asm volatile(T " %0, %0" : "+v"(f1)); asm volatile(INS " %0, %0, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile(INS " %0, %0, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a5) : "v"(c));
+DEF_KERNEL(k_mix_log_xor, M8, OP8_MIX("v_log_f32", "v_xor_b32"), SINKM)
+DEF_KERNEL(k_mix_sin_mullo, M8, OP8_MIX("v_sin_f32", "v_mul_lo_u32"), SINKM)
+
 typedef void (*kern_t)(float *, uint64_t *);
 struct Entry { const char *name; kern_t k; };
 
@@ -128,7 +138,8 @@ int main(int argc, char **argv)
                   {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}, {"v_xor_b32 (sgpr)", k_xor_sgpr},
                   {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit}, {"v_cndmask_e64 (s)", k_cndmask_s},
                   {"v_cmp_lt_u32_e64", k_cmp_e64}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
-                  {"v_pk_add_f32", k_pk_add}};
+                  {"v_pk_add_f32", k_pk_add}, {"2 log + 6 xor", k_mix_log_xor},
+                  {"2 sin + 6 mul_lo", k_mix_sin_mullo}};
     printf("%-18s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
     printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
