@@ -219,11 +219,11 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     }
 }
 
-// (x > 0) && (x < a) for finite a > 0 as ONE unsigned compare on the float bits: positive floats order like their
-// bit patterns, +0 wraps to 0xffffffff, negatives (sign bit) and NaN land above every finite positive bound.
-__device__ __forceinline__ bool in_range(float x, uint32_t a_bits_m1)
+// The evidence is carried CENTRED: w = x - a/2, h = a/2, so that (x > 0) && (x < a) is the single compare |w| < h
+// (v_cmp_lt_f32 with the |.| source modifier; false for NaN and for h == 0).
+__device__ __forceinline__ bool in_range(float w, float h)
 {
-    return (__float_as_uint(x) - 1u) < a_bits_m1;
+    return __builtin_fabsf(w) < h;
 }
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
@@ -262,8 +262,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     uint32_t *res = reinterpret_cast<uint32_t *>(zsum + 2 * ring);
 
     // per-lane trial state
-    float x = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;
-    uint32_t am1 = 0;        // bits(boundary) - 1
+    float w = 0.0f, h = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;   // w: centred evidence, h: boundary / 2
     int k = 0;
     uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
@@ -324,8 +323,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const unsigned long long fin_mask0 = has_m & ~act_m;
         dbg_refills++;
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
-            const float a = __uint_as_float(am1 + 1u);
-            const uint32_t code = invalid ? 3u : (x >= a ? 1u : (x <= 0.0f ? 2u : 0u));
+            const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
@@ -436,14 +434,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     if constexpr (FAST) cb = cb * 1.4426950408889634f;     // v_exp_f32 is 2^x
                 }
                 pc.init(trial, set_lo, c3, A.k0, A.k1);
-                am1 = invalid ? 0u : __float_as_uint(a) - 1u;
-                x = a * beta;
+                h = invalid ? 0.0f : 0.5f * a;
+                w = a * beta - h;
                 k = 0;
                 jit = 0;
             }
-            // fresh compares over all lanes (an invalid trial has am1 == 0 and is never in range; lanes without a trial
+            // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
             // are masked by has_m)
-            act_m = __builtin_amdgcn_ballot_w64(in_range(x, am1)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
         for (int it = 0; it < A.max_blocks; ++it) {
@@ -472,32 +470,31 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
                     // each on gfx950) cost more VALU issue than the predicated add / count they would replace
                     asm volatile("" ::: "memory");
-                    float x1 = x + inc[j];
+                    float w1 = w + inc[j];
                     if constexpr (BRIDGE) {
-                        if (in_range(x1, am1)) {
-                            const float a = __uint_as_float(am1 + 1u);
-                            const float eu = cb * ((a - x) * (a - x1));
-                            const float el = cb * (x * x1);
+                        if (in_range(w1, h)) {
+                            const float eu = cb * ((h - w) * (h - w1));      // distances to the upper boundary
+                            const float el = cb * ((h + w) * (h + w1));      // ... and to the lower one
                             float pu, pl;
                             if constexpr (FAST) { pu = __builtin_amdgcn_exp2f(eu); pl = __builtin_amdgcn_exp2f(el); }
                             else { pu = exact_expf_neg(eu); pl = exact_expf_neg(el); }
                             const float uu = (float)(ub[j] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
-                            if (uu < pu) x1 = a;
-                            else if (uu >= 1.0f - pl) x1 = 0.0f;
+                            if (uu < pu) w1 = h;
+                            else if (uu >= 1.0f - pl) w1 = -h;
                         }
                         jit = ub[j] & 0xffu;
                     }
-                    x = x1;
+                    w = w1;
                     k++;
                     if (j < 3) {
-                        if constexpr (CAP4) active = in_range(x, am1);
-                        else active = in_range(x, am1) && (k < A.max_k);
+                        if constexpr (CAP4) active = in_range(w, h);
+                        else active = in_range(w, h) && (k < A.max_k);
                     }
                 }
             }
             // fresh compares for every lane, combined as SGPR masks: a ballot of a compare is just its SGPR result, a
             // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
-            act_m = __builtin_amdgcn_ballot_w64(in_range(x, am1)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
         }
     }
