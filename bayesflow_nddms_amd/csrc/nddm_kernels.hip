@@ -449,16 +449,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
             const uint32_t blk = (uint32_t)k >> 2;
             const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
-            float inc[4];
-            {
-                float r, cs, sn;
-                polar_pair<FAST>(rb.x, rb.y, rscale, r, cs, sn);
-                inc[0] = __builtin_fmaf(r, cs, mu_dt);
-                inc[1] = __builtin_fmaf(r, sn, mu_dt);
-                polar_pair<FAST>(rb.z, rb.w, rscale, r, cs, sn);
-                inc[2] = __builtin_fmaf(r, cs, mu_dt);
-                inc[3] = __builtin_fmaf(r, sn, mu_dt);
-            }
+            // noise of the four steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
+            // v_fmac_f32 + v_add_f32 (2.3 issue cycles each; a three-address v_fma_f32 costs 3.8)
+            float rr[4], tt[4];
+            polar_pair<FAST>(rb.x, rb.y, rscale, rr[0], tt[0], tt[1]);
+            polar_pair<FAST>(rb.z, rb.w, rscale, rr[2], tt[2], tt[3]);
+            rr[1] = rr[0]; rr[3] = rr[2];
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
                 const u32x4 u4 = philox4x32_10_lds(blk, trial, set_lo, c3 | 0x30000000u, kbase);   // stream 3
@@ -470,7 +466,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
                     // each on gfx950) cost more VALU issue than the predicated add / count they would replace
                     asm volatile("" ::: "memory");
-                    float w1 = w + inc[j];
+                    float w1 = __builtin_fmaf(rr[j], tt[j], w) + mu_dt;
                     if constexpr (BRIDGE) {
                         if (in_range(w1, h)) {
                             const float eu = cb * ((h - w) * (h - w1));      // distances to the upper boundary

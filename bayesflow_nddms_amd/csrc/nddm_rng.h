@@ -34,6 +34,15 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return {c0, c1, c2, c3};
 }
 
+// a ^ b ^ c in one instruction: gfx950's v_bitop3_b32 with truth table 0x96 (3.8 issue cycles against 2 x 2.3 for two
+// v_xor_b32; profiles/r1_ubench_valu.txt).  All three operands must be VGPRs here.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // The path stream's Philox block with (a) the round keys fetched from LDS and (b) round 0 partly precomputed.
 // (a) On gfx950 a VOP2 xor that reads an SGPR issues at ~4.2 cycles, a VGPR-only one at ~2.3; the LDS pipe is otherwise
 //     idle in the step loop, so it delivers the (wave-uniform) keys as broadcast reads, prefetched one round ahead.
@@ -65,9 +74,9 @@ __device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t blk, const PathCtr 
         if (!(LAST)) asm volatile("ds_read_b64 %0, %1 offset:" #NEXT_OFF : "=v"(kn) : "v"(kbase));        \
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;                                                   \
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;                                                   \
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;                                               \
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, ka);                                           \
         const uint32_t n1 = (uint32_t)p1;                                                                 \
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;                                               \
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, kb);                                           \
         const uint32_t n3 = (uint32_t)p0;                                                                 \
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
         if (!(LAST)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn)); ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32); } \
@@ -91,9 +100,9 @@ __device__ __forceinline__ u32x4 philox4x32_10_lds(uint32_t c0, uint32_t c1, uin
         if (!(LAST)) asm volatile("ds_read_b64 %0, %1 offset:" #NEXT_OFF : "=v"(kn) : "v"(kbase));        \
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;                                                   \
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;                                                   \
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;                                               \
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, ka);                                           \
         const uint32_t n1 = (uint32_t)p1;                                                                 \
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;                                               \
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, kb);                                           \
         const uint32_t n3 = (uint32_t)p0;                                                                 \
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
         if (!(LAST)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn)); ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32); } \

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # measured on MI355X (profiles/r1_ubench_valu.txt), cycles per wave64 instruction per SIMD at 8 waves/SIMD
 COST = {"v_mad_u64_u32": 4.67, "v_xor_b32": 2.32, "v_cvt_f32_u32": 4.12, "v_cvt_f32_i32": 4.12, "v_log_f32": 8.17,
         "v_sqrt_f32": 8.19, "v_sin_f32": 8.14, "v_cos_f32": 8.15, "v_exp_f32": 8.15, "v_rcp_f32": 8.14,
-        "v_fma_f32": 3.77, "v_fmamk_f32": 3.77, "v_fmac_f32": 3.77, "v_fmaak_f32": 3.77, "v_add_f32": 2.26,
+        "v_fma_f32": 3.77, "v_fmamk_f32": 3.77, "v_fmac_f32": 2.34, "v_fmaak_f32": 3.77, "v_add_f32": 2.26,
         "v_sub_f32": 2.26, "v_mul_f32": 2.24, "v_add_u32": 2.35, "v_sub_u32": 2.35, "v_subrev_u32": 2.35,
         "v_lshrrev_b32": 2.32, "v_lshlrev_b32": 2.32, "v_and_b32": 2.32, "v_or_b32": 2.32, "v_alignbit_b32": 2.32,
         "v_cndmask_b32": 2.32, "v_add3_u32": 2.35, "v_mov_b32": 2.32, "v_cmp": 4.13, "v_mul_lo_u32": 4.23,
@@ -26,7 +26,7 @@ COST = {"v_mad_u64_u32": 4.67, "v_xor_b32": 2.32, "v_cvt_f32_u32": 4.12, "v_cvt_
 # ~4.2 cycles instead of ~2.3 (profiles/r1_ubench_valu.txt rows "v_xor_b32 (sgpr)", v_add3_u32, v_alignbit_b32,
 # "v_cndmask_e64 (s)")
 COST.update({"v_add3_u32": 4.22, "v_alignbit_b32": 4.15, "v_cndmask_b32": 4.22, "v_pk_fma_f32": 4.19, "v_pk_mul_f32": 4.19,
-             "v_pk_add_f32": 4.20})
+             "v_pk_add_f32": 4.20, "v_bitop3_b32": 3.84, "v_add_co_u32": 4.23})
 SGPR_OPERAND_COST = 4.16
 FULL_RATE = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_add_f32", "v_sub_f32",
              "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"}

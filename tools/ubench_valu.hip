@@ -117,6 +117,14 @@ DEF_KERNEL(k_cmp, F8, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc,
     asm volatile(INS " %0, %0, %1" : "+v"(a4) : "v"(c)); asm volatile(INS " %0, %0, %1" : "+v"(a5) : "v"(c));
 DEF_KERNEL(k_mix_log_xor, M8, OP8_MIX("v_log_f32", "v_xor_b32"), SINKM)
 DEF_KERNEL(k_mix_sin_mullo, M8, OP8_MIX("v_sin_f32", "v_mul_lo_u32"), SINKM)
+#define OP8_B3 \
+    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a0) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a1) : "v"(c)); \
+    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a2) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a3) : "v"(c)); \
+    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a4) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a5) : "v"(c)); \
+    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a6) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a7) : "v"(c));
+DEF_KERNEL(k_bitop3, U8, OP8_B3, SINKU)
+DEF_KERNEL(k_fmac, F8, OP8("v_fmac_f32"), SINKF)
+DEF_KERNEL(k_add_co, U8, asm volatile("v_add_co_u32_e64 %0, s[20:21], 1, %0\n v_add_co_u32_e64 %1, s[22:23], 1, %1\n v_add_co_u32_e64 %2, s[20:21], 1, %2\n v_add_co_u32_e64 %3, s[22:23], 1, %3\n v_add_co_u32_e64 %4, s[20:21], 1, %4\n v_add_co_u32_e64 %5, s[22:23], 1, %5\n v_add_co_u32_e64 %6, s[20:21], 1, %6\n v_add_co_u32_e64 %7, s[22:23], 1, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20", "s21", "s22", "s23");, SINKU)
 
 typedef void (*kern_t)(float *, uint64_t *);
 struct Entry { const char *name; kern_t k; };
@@ -138,7 +146,8 @@ int main(int argc, char **argv)
                   {"v_rcp_f32", k_rcp}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cmp_lt_f32", k_cmp}, {"v_xor_b32 (sgpr)", k_xor_sgpr},
                   {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit}, {"v_cndmask_e64 (s)", k_cndmask_s},
                   {"v_cmp_lt_u32_e64", k_cmp_e64}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
-                  {"v_pk_add_f32", k_pk_add}, {"2 log + 6 xor", k_mix_log_xor},
+                  {"v_pk_add_f32", k_pk_add}, {"v_bitop3_b32 (xor3)", k_bitop3}, {"v_fmac_f32", k_fmac}, {"v_add_co_u32_e64", k_add_co},
+                  {"2 log + 6 xor", k_mix_log_xor},
                   {"2 sin + 6 mul_lo", k_mix_sin_mullo}};
     printf("%-18s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
