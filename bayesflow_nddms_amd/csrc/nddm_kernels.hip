@@ -87,8 +87,8 @@ struct AuxStream {
     u32x4 x;
     float z[4];
     bool have01, have23;
-    __device__ __forceinline__ AuxStream(uint32_t kbase_, uint64_t set, uint32_t trial_)
-        : trial(trial_), set_lo((uint32_t)set), c3(((uint32_t)(set >> 32) & 0x0fffffffu) | 0x10000000u),
+    __device__ __forceinline__ AuxStream(uint32_t kbase_, uint32_t set_lo_, uint32_t set_hi28, uint32_t trial_)
+        : trial(trial_), set_lo(set_lo_), c3(set_hi28 | 0x10000000u),
           blk(0xffffffffu), kbase(kbase_), have01(false), have23(false) {}
     __device__ __forceinline__ float normal(uint32_t a)
     {
@@ -212,7 +212,8 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
         if (A.out_ext && lane == 0 && t0 == 0) {
-            AuxStream<FAST> aux(kbase, A.set_offset + (unsigned long long)set_in_call, 0xffffffffu);
+            const unsigned long long gset = A.set_offset + (unsigned long long)set_in_call;
+            AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
             const float loc = (A.ext_mode == 0) ? pp[1] : 1.0f;
             A.out_ext[set_in_call] = __builtin_fmaf(A.ext_sigma, aux.normal(0), loc);
         }
@@ -225,6 +226,13 @@ __device__ __forceinline__ bool in_range(float w, float h)
 {
     return __builtin_fabsf(w) < h;
 }
+
+// Per-set constants of the trial hand-out, computed ONCE when a tile opens (a hand-out then costs three LDS reads and an
+// xor instead of ~15 VALU instructions per refill): dword index into the tile's DV-dword LDS record.
+enum { D_MU = 0, D_RS = 1, D_H = 2, D_W0 = 3,        // drift*dt, radius scale, boundary/2, centred start point
+       D_N1 = 4, D_HIK = 5, D_C3K = 6, D_SETLO = 7,  // Philox round-0 constants of the set (PathCtr), low set word
+       D_C3 = 8, D_CB = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), bridge coefficient, first trial of the
+       DV = 12 };                                    // tile within its set, in-call set index
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
 // once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     const int ring = A.ring, ring_mask = A.ring - 1;
 
     // LDS carve-up, one ring slot per in-flight parameter set ("tile"):
-    //   raw parameter row | in-call set index | retire counter | packed results | z column
+    //   per-set constants of the hand-out | raw parameter row | in-call set index | retire counter | z sums | packed results
     // bytes [0, 80): the ten Philox round-key pairs (philox4x32_10_ldskeys)
     if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
     // LDS byte address of the key table in a VGPR (the low 32 bits of a flat LDS address are the LDS offset); the asm
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t off = (uint32_t)(size_t)lds_raw;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
     }
-    float *lp = reinterpret_cast<float *>(lds_raw + 20);
+    uint32_t *dv = lds_raw + 20;                                       // [ring][DV], 16-byte aligned
+    float *lp = reinterpret_cast<float *>(dv + ring * DV);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
     long long *zsum = reinterpret_cast<long long *>(cnt + ring);      // [ring][2]: fixed-point sums of z and z^2
@@ -312,6 +321,41 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             }
             if (lane < P) lp[slot * P + lane] = row[lane];
             if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; zsum[2 * slot] = 0; zsum[2 * slot + 1] = 0; }
+            {
+                // everything here is wave-uniform (row is a uniform pointer: scalar loads)
+                const int sic = A.tiles_per_set == 1 ? vset : vset / A.tiles_per_set;
+                const unsigned long long gset = A.set_offset + (unsigned long long)sic;
+                const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
+                const uint64_t p1 = (uint64_t)0xCD9E8D57u * s_lo;
+                float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 0.0f;       // the per-SET ones of the model
+                if constexpr (MODEL == NDDM_BASIC_DDM_DC) { drift = row[0]; a = row[1]; beta = row[2]; sig_c = row[4]; }
+                else if constexpr (MODEL == NDDM_SINGLE_TRIAL) { drift = row[0]; beta = row[2]; sig_c = row[5]; }
+                else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) { drift = row[0]; a = row[1]; beta = row[2]; }
+                else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { a = row[1]; beta = row[2]; sig_c = row[5]; }
+                else { drift = row[0]; beta = row[1]; sig_c = row[3]; }
+                const float sig = A.sqrt_dt * sig_c;
+                float cbv = 0.0f;
+                if constexpr (BRIDGE) {
+                    cbv = -2.0f / (sig * sig);
+                    if constexpr (FAST) cbv = cbv * 1.4426950408889634f;     // v_exp_f32 is 2^x
+                }
+                const float hv = 0.5f * a;
+                if (lane == 0) {
+                    uint32_t *d = dv + slot * DV;
+                    d[D_MU] = __float_as_uint(drift * A.dt);
+                    d[D_RS] = __float_as_uint(radius_scale<FAST>(sig));
+                    d[D_H] = __float_as_uint(hv);
+                    d[D_W0] = __float_as_uint(a * beta - hv);
+                    d[D_N1] = (uint32_t)p1;
+                    d[D_HIK] = (uint32_t)(p1 >> 32) ^ A.k0;
+                    d[D_C3K] = s_hi ^ A.k1;
+                    d[D_SETLO] = s_lo;
+                    d[D_C3] = s_hi;
+                    d[D_CB] = __float_as_uint(cbv);
+                    d[D_TBASE] = (uint32_t)((vset - sic * A.tiles_per_set) * N);
+                    d[D_SIC] = (uint32_t)sic;
+                }
+            }
             chunk_set++; chunk_left--; tile_open++;
         }
     };
@@ -331,8 +375,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if constexpr (T::HAS_Z) {
                 if (trial < (uint32_t)A.n_total) {           // not a padding trial of a split set's last tile
                     if (A.out_trials) {
-                        const int vs = slot_set[slot];
-                        const long long sic = A.tiles_per_set == 1 ? (long long)vs : (long long)(vs / A.tiles_per_set);
+                        const long long sic = (long long)dv[slot * DV + D_SIC];
                         A.out_trials[(sic * A.n_total + trial) * 2 + 1] = zout;
                     }
                     if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
@@ -387,55 +430,57 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             has_m |= ok_mask;
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
                 tile = tl;
-                trial = (uint32_t)tr;
                 ltrial = (uint32_t)tr;
                 const int slot = tl & ring_mask;
                 const float *pp = lp + slot * P;
-                const int vset = slot_set[slot];
-                const long long set_in_call = A.tiles_per_set == 1 ? (long long)vset : (long long)(vset / A.tiles_per_set);
-                if (A.tiles_per_set != 1) trial += (uint32_t)((vset - (int)set_in_call * A.tiles_per_set) * N);   // global trial index
-                const unsigned long long gset = A.set_offset + (unsigned long long)set_in_call;
-                set_lo = (uint32_t)gset;
-                c3 = (uint32_t)(gset >> 32) & 0x0fffffffu;
-                float drift, a, beta, sig_c;
+                const uint4 d0 = *reinterpret_cast<const uint4 *>(dv + slot * DV);
+                const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 4);
+                const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 8);
+                trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
+                set_lo = d1.w;
+                c3 = d2.x;
+                mu_dt = __uint_as_float(d0.x);
+                rscale = __uint_as_float(d0.y);
+                h = __uint_as_float(d0.z);
+                w = __uint_as_float(d0.w);
                 invalid = false;
                 zout = 0.0f;
-                if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
-                    drift = pp[0]; a = pp[1]; beta = pp[2]; sig_c = pp[4];
-                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
-                    drift = pp[0]; beta = pp[2]; sig_c = pp[5];
-                    AuxStream<FAST> aux(kbase, gset, trial);
+                if constexpr (BRIDGE) cb = __uint_as_float(d2.y);
+                if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
+                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
+                    float a;
                     uint32_t ai = 1;
                     do { a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]); ai++; } while (!(a > 0.0f) && ai <= MAX_REJECT);
                     if (!(a > 0.0f)) a = fabsf(a);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * a);
+                    h = 0.5f * a;
+                    w = a * pp[2] - h;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                    drift = pp[0]; a = pp[1]; beta = pp[2];
-                    AuxStream<FAST> aux(kbase, gset, trial);
+                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
+                    float sig_c;
                     uint32_t ai = 1;
                     do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
+                    const float sig = A.sqrt_dt * sig_c;
+                    rscale = radius_scale<FAST>(sig);
+                    if constexpr (BRIDGE) {
+                        cb = -2.0f / (sig * sig);
+                        if constexpr (FAST) cb = cb * 1.4426950408889634f;
+                    }
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    AuxStream<FAST> aux(kbase, gset, trial);
-                    drift = __builtin_fmaf(pp[4], aux.normal(0), pp[0]);
-                    a = pp[1]; beta = pp[2]; sig_c = pp[5];
-                } else {   // NDDM_EXPLICIT_BOUNDARY
-                    drift = pp[0]; beta = pp[1]; sig_c = pp[3];
-                    a = trial < (uint32_t)A.n_total ? A.bounds[set_in_call * A.n_total + trial] : 1.0f;   // padded trial of a last tile
+                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
+                    mu_dt = __builtin_fmaf(pp[4], aux.normal(0), pp[0]) * A.dt;
+                } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
+                    const float a = trial < (uint32_t)A.n_total ? A.bounds[(long long)d2.w * A.n_total + trial] : 1.0f;   // padded trial of a last tile
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
+                    h = invalid ? 0.0f : 0.5f * a;
+                    w = a * pp[1] - h;
                 }
-                mu_dt = drift * A.dt;
-                const float sig = A.sqrt_dt * sig_c;
-                rscale = radius_scale<FAST>(sig);
-                if constexpr (BRIDGE) {
-                    cb = -2.0f / (sig * sig);
-                    if constexpr (FAST) cb = cb * 1.4426950408889634f;     // v_exp_f32 is 2^x
-                }
-                pc.init(trial, set_lo, c3, A.k0, A.k1);
-                h = invalid ? 0.0f : 0.5f * a;
-                w = a * beta - h;
+                pc.n0 = d1.y ^ trial;
+                pc.n1 = d1.x;
+                pc.c3k = d1.z;
                 k = 0;
                 jit = 0;
             }
@@ -447,7 +492,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         for (int it = 0; it < A.max_blocks; ++it) {
             dbg_blocks++;
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
-            const uint32_t blk = (uint32_t)k >> 2;
+            // counter word 0 of the path stream = index of the block's first step (a multiple of 4: a lane only starts
+            // a block after taking all four steps of the previous one), so no shift is needed
+            const uint32_t blk = (uint32_t)k;
             const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
             // noise of the four steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
             // v_fmac_f32 + v_add_f32 (2.3 issue cycles each; a three-address v_fma_f32 costs 3.8)
@@ -813,7 +860,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
     A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
-    const size_t lds = 80 + (size_t)ring * (P * 4 + 8 + 16) + (size_t)ring * tile_n * per_trial;
+    const size_t lds = 80 + (size_t)ring * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)ring * tile_n * per_trial;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
     {
