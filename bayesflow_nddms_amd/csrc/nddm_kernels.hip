@@ -95,12 +95,12 @@ struct AuxStream {
         const uint32_t b = a >> 2;
         if (b != blk) { x = philox4x32_10_lds(b, trial, set_lo, c3, kbase); blk = b; have01 = false; have23 = false; }
         const uint32_t j = a & 3u;
-        const float sc = radius_scale<FAST>(1.0f);
+        const float sc = noise_unit<FAST>(1.0f);
         if (j < 2u) {
-            if (!have01) { float r, cs, sn; polar_pair<FAST>(x.x, x.y, sc, r, cs, sn); z[0] = r * cs; z[1] = r * sn; have01 = true; }
+            if (!have01) { float r, cs, sn; polar_pair<FAST>(x.x, x.y, r, cs, sn); r *= sc; z[0] = r * cs; z[1] = r * sn; have01 = true; }
             return j == 0u ? z[0] : z[1];
         }
-        if (!have23) { float r, cs, sn; polar_pair<FAST>(x.z, x.w, sc, r, cs, sn); z[2] = r * cs; z[3] = r * sn; have23 = true; }
+        if (!have23) { float r, cs, sn; polar_pair<FAST>(x.z, x.w, r, cs, sn); r *= sc; z[2] = r * cs; z[3] = r * sn; have23 = true; }
         return j == 2u ? z[2] : z[3];
     }
 };
@@ -229,9 +229,9 @@ __device__ __forceinline__ bool in_range(float w, float h)
 
 // Per-set constants of the trial hand-out, computed ONCE when a tile opens (a hand-out then costs three LDS reads and an
 // xor instead of ~15 VALU instructions per refill): dword index into the tile's DV-dword LDS record.
-enum { D_MU = 0, D_RS = 1, D_H = 2, D_W0 = 3,        // drift*dt, radius scale, boundary/2, centred start point
+enum { D_MU = 0, D_INVS = 1, D_H = 2, D_W0 = 3,      // (in noise units) drift*dt, 1 / unit, boundary/2, centred start point
        D_N1 = 4, D_HIK = 5, D_C3K = 6, D_SETLO = 7,  // Philox round-0 constants of the set (PathCtr), low set word
-       D_C3 = 8, D_CB = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), bridge coefficient, first trial of the
+       D_C3 = 8, D_SPARE = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), -, first trial of the
        DV = 12 };                                    // tile within its set, in-call set index
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     uint32_t *res = reinterpret_cast<uint32_t *>(zsum + 2 * ring);
 
     // per-lane trial state
-    float w = 0.0f, h = 0.0f, mu_dt = 0.0f, rscale = 0.0f, zout = 0.0f, cb = 0.0f;   // w: centred evidence, h: boundary / 2
+    // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
+    float w = 0.0f, h = 0.0f, mu_dt = 0.0f, zout = 0.0f;
     int k = 0;
     uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
@@ -333,25 +334,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) { drift = row[0]; a = row[1]; beta = row[2]; }
                 else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { a = row[1]; beta = row[2]; sig_c = row[5]; }
                 else { drift = row[0]; beta = row[1]; sig_c = row[3]; }
-                const float sig = A.sqrt_dt * sig_c;
-                float cbv = 0.0f;
-                if constexpr (BRIDGE) {
-                    cbv = -2.0f / (sig * sig);
-                    if constexpr (FAST) cbv = cbv * 1.4426950408889634f;     // v_exp_f32 is 2^x
-                }
+                const float inv_s = 1.0f / noise_unit<FAST>(A.sqrt_dt * sig_c);
                 const float hv = 0.5f * a;
                 if (lane == 0) {
                     uint32_t *d = dv + slot * DV;
-                    d[D_MU] = __float_as_uint(drift * A.dt);
-                    d[D_RS] = __float_as_uint(radius_scale<FAST>(sig));
-                    d[D_H] = __float_as_uint(hv);
-                    d[D_W0] = __float_as_uint(a * beta - hv);
+                    d[D_MU] = __float_as_uint((drift * A.dt) * inv_s);
+                    d[D_INVS] = __float_as_uint(inv_s);
+                    d[D_H] = __float_as_uint(hv * inv_s);
+                    d[D_W0] = __float_as_uint((a * beta - hv) * inv_s);
                     d[D_N1] = (uint32_t)p1;
                     d[D_HIK] = (uint32_t)(p1 >> 32) ^ A.k0;
                     d[D_C3K] = s_hi ^ A.k1;
                     d[D_SETLO] = s_lo;
                     d[D_C3] = s_hi;
-                    d[D_CB] = __float_as_uint(cbv);
+                    d[D_SPARE] = 0u;
                     d[D_TBASE] = (uint32_t)((vset - sic * A.tiles_per_set) * N);
                     d[D_SIC] = (uint32_t)sic;
                 }
@@ -440,12 +436,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 set_lo = d1.w;
                 c3 = d2.x;
                 mu_dt = __uint_as_float(d0.x);
-                rscale = __uint_as_float(d0.y);
+                const float inv_s = __uint_as_float(d0.y);       // per-set where the model's noise scale is per set
                 h = __uint_as_float(d0.z);
                 w = __uint_as_float(d0.w);
                 invalid = false;
                 zout = 0.0f;
-                if constexpr (BRIDGE) cb = __uint_as_float(d2.y);
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
                     float a;
@@ -453,8 +448,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     do { a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]); ai++; } while (!(a > 0.0f) && ai <= MAX_REJECT);
                     if (!(a > 0.0f)) a = fabsf(a);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * a);
-                    h = 0.5f * a;
-                    w = a * pp[2] - h;
+                    const float hv = 0.5f * a;
+                    h = hv * inv_s;
+                    w = (a * pp[2] - hv) * inv_s;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
                     float sig_c;
@@ -462,21 +458,21 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
-                    const float sig = A.sqrt_dt * sig_c;
-                    rscale = radius_scale<FAST>(sig);
-                    if constexpr (BRIDGE) {
-                        cb = -2.0f / (sig * sig);
-                        if constexpr (FAST) cb = cb * 1.4426950408889634f;
-                    }
+                    const float inv_t = 1.0f / noise_unit<FAST>(A.sqrt_dt * sig_c);      // per-trial noise scale
+                    const float hv = 0.5f * pp[1];
+                    mu_dt = (pp[0] * A.dt) * inv_t;
+                    h = hv * inv_t;
+                    w = (pp[1] * pp[2] - hv) * inv_t;
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    mu_dt = __builtin_fmaf(pp[4], aux.normal(0), pp[0]) * A.dt;
+                    mu_dt = (__builtin_fmaf(pp[4], aux.normal(0), pp[0]) * A.dt) * inv_s;
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
                     const float a = trial < (uint32_t)A.n_total ? A.bounds[(long long)d2.w * A.n_total + trial] : 1.0f;   // padded trial of a last tile
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
-                    h = invalid ? 0.0f : 0.5f * a;
-                    w = a * pp[1] - h;
+                    const float hv = 0.5f * a;
+                    h = invalid ? 0.0f : hv * inv_s;
+                    w = (a * pp[1] - hv) * inv_s;
                 }
                 pc.n0 = d1.y ^ trial;
                 pc.n1 = d1.x;
@@ -499,8 +495,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             // noise of the four steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
             // v_fmac_f32 + v_add_f32 (2.3 issue cycles each; a three-address v_fma_f32 costs 3.8)
             float rr[4], tt[4];
-            polar_pair<FAST>(rb.x, rb.y, rscale, rr[0], tt[0], tt[1]);
-            polar_pair<FAST>(rb.z, rb.w, rscale, rr[2], tt[2], tt[3]);
+            polar_pair<FAST>(rb.x, rb.y, rr[0], tt[0], tt[1]);
+            polar_pair<FAST>(rb.z, rb.w, rr[2], tt[2], tt[3]);
             rr[1] = rr[0]; rr[3] = rr[2];
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
@@ -516,6 +512,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     float w1 = __builtin_fmaf(rr[j], tt[j], w) + mu_dt;
                     if constexpr (BRIDGE) {
                         if (in_range(w1, h)) {
+                            // P(crossed) = exp(-2 d0 d1 / sigma^2 dt): in noise units the coefficient is a constant
+                            // (exact: -2 with e^x; fast: -2 * 2 ln 2 * log2 e = -4 with v_exp_f32's 2^x)
+                            constexpr float cb = FAST ? -4.0f : -2.0f;
                             const float eu = cb * ((h - w) * (h - w1));      // distances to the upper boundary
                             const float el = cb * ((h + w) * (h + w1));      // ... and to the lower one
                             float pu, pl;

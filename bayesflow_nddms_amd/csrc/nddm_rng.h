@@ -195,29 +195,30 @@ __device__ __forceinline__ float exact_expf_neg(float x)
     return p * __uint_as_float((uint32_t)(n + 127) << 23);
 }
 
-// Per-lane scale of the Gaussian radius: with sigma folded in, one Box-Muller pair is
-//   r = sqrt(scale * log(u)),  scale = -2 sigma^2      (exact: natural log; fast: v_log_f32 is log2, so scale *= ln 2)
-// and an Euler-Maruyama increment is fma(r, cos|sin, mu*dt): no separate multiply by sigma per step.
+// The Box-Muller radius comes out in NOISE UNITS so that no per-pair multiply by sigma is needed: the simulators carry
+// their state divided by  S = noise_unit<FAST>(sigma),
+//   exact: r = sqrt(-2 ln u),  S = sigma                (r * cos is a standard normal)
+//   fast : r = sqrt(-log2 u),  S = sigma * sqrt(2 ln 2) (v_log_f32 is log2; the constant moves into S)
+// and an Euler-Maruyama step is  w = fma(r, cos|sin, w) + mu*dt/S.
 template <bool FAST>
-__device__ __forceinline__ float radius_scale(float sigma)
+__device__ __forceinline__ float noise_unit(float sigma)
 {
-    const float s2 = sigma * sigma;
-    return FAST ? -1.3862943611198906f * s2 : -2.0f * s2;
+    return FAST ? sigma * 1.1774100225154747f : sigma;
 }
 
-// (r, cos, sin) of one Box-Muller pair from two u32
+// (r, cos, sin) of one Box-Muller pair from two u32, radius in noise units
 template <bool FAST>
-__device__ __forceinline__ void polar_pair(uint32_t xa, uint32_t xb, float scale, float &r, float &cs, float &sn)
+__device__ __forceinline__ void polar_pair(uint32_t xa, uint32_t xb, float &r, float &cs, float &sn)
 {
     const float u = __builtin_fmaf((float)xa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);   // (0, 1]
     if constexpr (FAST) {
-        r = __builtin_amdgcn_sqrtf(scale * __builtin_amdgcn_logf(u));
+        r = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
         // v_sin/v_cos take turns and reduce the integer part themselves: feed [1, 2) built from the top 23 bits
         const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, xb, 9u));   // 0x3f800000 | (xb >> 9)
         cs = __builtin_amdgcn_cosf(ang);
         sn = __builtin_amdgcn_sinf(ang);
     } else {
-        r = exact_sqrtf(scale * exact_logf(u));
+        r = exact_sqrtf(-2.0f * exact_logf(u));
         exact_sincos_turn(xb, sn, cs);
     }
 }
@@ -228,11 +229,13 @@ __device__ __forceinline__ void normals4(uint32_t c0, uint32_t c1, uint32_t c2, 
                                          uint32_t k0, uint32_t k1, float (&z)[4])
 {
     const u32x4 x = philox4x32_10(c0, c1, c2, c3, k0, k1);
-    const float sc = radius_scale<FAST>(1.0f);
+    const float sc = noise_unit<FAST>(1.0f);
     float r, cs, sn;
-    polar_pair<FAST>(x.x, x.y, sc, r, cs, sn);
+    polar_pair<FAST>(x.x, x.y, r, cs, sn);
+    r *= sc;
     z[0] = r * cs; z[1] = r * sn;
-    polar_pair<FAST>(x.z, x.w, sc, r, cs, sn);
+    polar_pair<FAST>(x.z, x.w, r, cs, sn);
+    r *= sc;
     z[2] = r * cs; z[3] = r * sn;
 }
 
