@@ -33,8 +33,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # mode, from the ISA of sim_kernel<basic, fast> x the measured per-instruction issue cost (tools/ubench_valu)
 VALU_MODEL = {
     "clock_ghz": 2.4, "simds": 1024,
-    # python tools/isa_mix.py: instruction mix of the step loop x per-instruction issue cost (profiles/r1_ubench_valu.txt)
-    "cycles_per_block_fast": 338.0, "cycles_per_block_exact": 636.0,
+    # SIMD cycles one wave64 needs per Philox block (4 E-M steps x 64 lanes) when EVERY lane is useful: measured with
+    # tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes): 272 cycles per block at
+    # lane efficiency 0.983 (fast), 522 at 0.980 (exact) -- profiles/r1_summary.md.  The sum of the isolated
+    # per-instruction issue costs of the loop (tools/isa_mix.py x profiles/r1_ubench_valu.txt) is 293 / 614: the real
+    # loop issues slightly better than that sum, so the measured figure is the tighter ceiling.
+    "cycles_per_block_fast": 267.0, "cycles_per_block_exact": 512.0,
+    "sum_of_issue_costs_fast": 293.0, "sum_of_issue_costs_exact": 614.0,
 }
 
 
@@ -265,7 +270,10 @@ def main():
             res["roofline_valu"] = {"bound": "valu", "achieved": em_steps / (kern_ms * 1e-3) / 1e9,
                                     "peak": peak_steps / 1e9, "unit": "G E-M steps/s",
                                     "frac": em_steps / (kern_ms * 1e-3) / peak_steps,
-                                    "issue_cycles_per_block": cpb, "clock_ghz": VALU_MODEL["clock_ghz"]}
+                                    "issue_cycles_per_block": cpb, "clock_ghz": VALU_MODEL["clock_ghz"],
+                                    "ceiling": "step loop with every lane useful (measured lockstep run)",
+                                    "sum_of_isolated_issue_costs": VALU_MODEL["sum_of_issue_costs_fast" if fast
+                                                                              else "sum_of_issue_costs_exact"]}
         if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
         if world == 1 and not a.no_cpu_baseline and a.model == "basic":

@@ -25,6 +25,14 @@ for fn in sorted(glob.glob(os.path.join(src, "pmc*", "bench_counter_collection.c
             pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")}
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+if "roofline_valu" in bench:      # re-price against the CURRENT ceiling in bench.py (the traced run may predate a recalibration)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import VALU_MODEL
+    rv = bench["roofline_valu"]
+    cpb = VALU_MODEL["cycles_per_block_fast"]
+    peak = VALU_MODEL["simds"] * VALU_MODEL["clock_ghz"] / cpb * 256
+    rv.update({"peak": peak, "frac": rv["achieved"] / peak, "issue_cycles_per_block": cpb,
+               "sum_of_isolated_issue_costs": VALU_MODEL["sum_of_issue_costs_fast"]})
 sim = [r for r in rows if "sim_kernel" in r["Name"]][0]
 with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}` -- `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ks`\n\n")
