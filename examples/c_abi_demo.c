@@ -1,0 +1,78 @@
+/*
+ * c_abi_demo.c -- the drop-in boundary used from plain C: no Python, no PyTorch, only include/nddm.h and the HIP
+ * runtime API for memory.  It simulates B parameter sets x N trials of basic_ddm_dc (the path of
+ * basic_ddm_dc.py:85-125 in the reference) and writes params, trials and summaries as raw float32 so that
+ * tests/test_gpu_c_abi.py can compare them with the CPU oracle bit for bit.
+ *
+ * Build (done by __graft_entry__.build()):
+ *   gcc -O2 -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_demo.c -o examples/c_abi_demo \
+ *       -Lbayesflow_nddms_amd -lnddm_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../bayesflow_nddms_amd' -Wl,-rpath,/opt/rocm/lib
+ * Run:  examples/c_abi_demo B N dt max_steps seed flags out.bin
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include "nddm.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP: %s (%s:%d)\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define NDDM_CHECK(x) do { int rc_ = (x); if (rc_ != NDDM_OK) { fprintf(stderr, "nddm status %d: %s\n", rc_, nddm_last_error()); return 3; } } while (0)
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 8) { fprintf(stderr, "usage: %s B N dt max_steps seed flags out.bin\n", argv[0]); return 1; }
+    const int64_t B = atoll(argv[1]);
+    const int32_t N = atoi(argv[2]);
+    const float dt = (float)atof(argv[3]);
+    const int32_t max_steps = atoi(argv[4]);
+    const uint64_t seed = strtoull(argv[5], NULL, 10);
+    const uint32_t flags = (uint32_t)strtoul(argv[6], NULL, 10);
+    if (nddm_abi_version() != NDDM_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    int n_dev = 0;
+    if (nddm_device_count(&n_dev) != NDDM_OK || n_dev < 1) { fprintf(stderr, "no device: %s\n", nddm_last_error()); return 1; }
+    NDDM_CHECK(nddm_set_device(0));
+
+    /* parameter rows in the reference's order (basic_ddm_dc.py:118): drift, boundary, beta, tau, dc */
+    const size_t np = (size_t)B * 5, nt = (size_t)B * N * 2, ns = (size_t)B * NDDM_SUMMARY_K;
+    float *p = (float *)malloc(np * sizeof(float));
+    for (int64_t i = 0; i < B; i++) {
+        p[5 * i + 0] = -2.0f + 0.25f * (float)(i % 17);
+        p[5 * i + 1] = 0.8f + 0.2f * (float)(i % 7);
+        p[5 * i + 2] = 0.3f + 0.1f * (float)(i % 5);
+        p[5 * i + 3] = 0.2f + 0.05f * (float)(i % 3);
+        p[5 * i + 4] = 0.8f + 0.1f * (float)(i % 4);
+    }
+    float *d_p, *d_t, *d_s;
+    HIP_OK(hipMalloc((void **)&d_p, np * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_t, nt * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_s, ns * sizeof(float)));
+    HIP_OK(hipMemcpy(d_p, p, np * sizeof(float), hipMemcpyHostToDevice));
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+
+    NDDM_CHECK(nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)st));   /* warm-up */
+    HIP_OK(hipStreamSynchronize(st));
+    const double t0 = now_s();
+    NDDM_CHECK(nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)st));
+    HIP_OK(hipStreamSynchronize(st));
+    const double t1 = now_s();
+
+    float *t = (float *)malloc(nt * sizeof(float)), *s = (float *)malloc(ns * sizeof(float));
+    HIP_OK(hipMemcpy(t, d_t, nt * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(s, d_s, ns * sizeof(float), hipMemcpyDeviceToHost));
+    FILE *f = fopen(argv[7], "wb");
+    if (!f) { perror(argv[7]); return 1; }
+    fwrite(p, sizeof(float), np, f); fwrite(t, sizeof(float), nt, f); fwrite(s, sizeof(float), ns, f);
+    fclose(f);
+
+    /* error convention: a bad shape is a status code + message, not a crash */
+    int rc = nddm_basic_ddm_dc_simulate(d_p, B, 0, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)st);
+    printf("{\"sets\": %lld, \"n_trials\": %d, \"seconds\": %.6f, \"trials_per_s\": %.4e, \"first_rt\": %.6f, \"first_choice\": %.0f, "
+           "\"bad_shape_status\": %d}\n", (long long)B, N, t1 - t0, (double)B * N / (t1 - t0), t[0], t[1], rc);
+    HIP_OK(hipFree(d_p)); HIP_OK(hipFree(d_t)); HIP_OK(hipFree(d_s)); HIP_OK(hipStreamDestroy(st));
+    free(p); free(t); free(s);
+    return 0;
+}
