@@ -854,7 +854,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // its share of every block; with lambda completions per block the optimum is ~sqrt(61 lambda) finished lanes:
     // 8 when trials last ~64 blocks (dt=.001, cap 4000), ~16-24 when they last ~7 (the reference default dt=.01, cap
     // 400).  The cap is the only hint the host has about trial length.
-    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : (max_steps <= 1000 ? 16 : 8);
+    // refill when this many lanes hold a finished trial: 8, or 16 where a refill is dearer relative to the stepping
+    // between two refills (short trials; models whose hand-out draws per-trial auxiliary normals) -- measured +2..5 %
+    const bool aux_handout = model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
+    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
