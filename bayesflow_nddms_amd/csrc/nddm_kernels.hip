@@ -748,6 +748,16 @@ static int resident_waves(K kernel, size_t lds_bytes)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = 8;
     if (per_cu > 32) per_cu = 32;
+    // The occupancy query over-counts on gfx950: measured with the in-kernel wave-lifetime counters, a wave64 kernel with
+    // 65..80 VGPRs keeps 6 waves per SIMD resident, not 512 / 72 = 7 -- registers are handed out in blocks of 16.  A grid
+    // larger than what is resident only adds waves that start when the first ones exit (-6 % on mid-size launches).
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) == hipSuccess && fa.numRegs > 0) {
+        int per_simd = 512 / (((fa.numRegs + 15) / 16) * 16);
+        if (per_simd > 8) per_simd = 8;
+        if (per_simd < 1) per_simd = 1;
+        if (per_cu > 4 * per_simd) per_cu = 4 * per_simd;
+    }
     return cus * per_cu;
 }
 

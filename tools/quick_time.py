@@ -38,7 +38,7 @@ def run(B, N, dt, ms, fast, tune=None, model=0, reps=3, trials_out=True, lockste
     nresp = s[:, 0] + s[:, 1]
     steps = float(((s[:, 3] - p[:, 3 if model != 4 else 2]) / dt * nresp)[nresp > 0].sum() + s[:, 2].sum() * int(ms)) if not bridge else float("nan")
     cyc = best * 1e-3 * 2.35e9 * 1024 / (steps / 256) if steps == steps else float("nan")
-    print(f"model={model} B={B} N={N} dt={dt} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge}: {best:.2f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  ~{cyc:.0f} SIMD-cycles/wave-block@2.35GHz | lane-eff {steps/(d[0]*256):.3f} blocks/refill {d[0]/d[1]:.1f} clock {d[2]/d[3]*0.1:.3f} GHz", flush=True)
+    print(f"model={model} B={B} N={N} dt={dt} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge}: {best:.2f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  ~{cyc:.0f} SIMD-cycles/wave-block@2.35GHz | lane-eff {steps/(d[0]*256):.3f} blocks/refill {d[0]/d[1]:.1f} clock {d[2]/d[3]*0.1:.3f} GHz waves {d[4]:.0f}", flush=True)
     _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 if __name__ == "__main__":
