@@ -188,6 +188,80 @@ def test_full_size_properties():
     assert "trials" not in r3 and torch.equal(torch.nan_to_num(r3["summary"]), torch.nan_to_num(s[:100_000]))
 
 
+def test_full_size_single_trial_with_fused_summaries():
+    """BASELINE.json configs[3]: single-trial model, 1M sets x 300 trials, dt=.001, trials + fused [B,10] summaries.
+    Size-independent properties: value domains of (choicert, z1), the 0-coded timeout, summaries == a torch
+    recomputation (counts exactly, moments to float tolerance, incl. the fixed-point z sums), and re-simulated rows
+    reproduce their bits."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N, dt, ms = 1_000_000, 300, 0.001, 4000
+    p = torch.as_tensor(prior_util.single_prior(B, 2023)).cuda()          # [B, 8] (gamma = 1)
+    r = engine.simulate(engine.SINGLE_TRIAL, p, N, dt=dt, max_steps=ms, seed=99, set_offset=0, fast=True)
+    t, s = r["trials"], r["summary"]
+    y, z = t[..., 0], t[..., 1]
+    ter = p[:, 3:4]
+    assert bool(torch.isfinite(t).all())
+    resp = y != 0
+    assert bool((y.abs()[resp] >= (ter + dt * 0.999).expand_as(y)[resp]).all())      # min |choicert| = ter + dt
+    assert bool((y.abs() <= ter + ms * dt * 1.000001).all())
+    n_up, n_lo, n_miss = (y > 0).sum(1), (y < 0).sum(1), (~resp).sum(1)
+    assert bool((s[:, 0] == n_up).all() and (s[:, 1] == n_lo).all() and (s[:, 2] == n_miss).all())
+    nr = resp.sum(1).clamp(min=1).double()
+    ok = resp.sum(1) > 0
+    mean_rt = (y.abs().double() * resp).sum(1) / nr
+    assert bool(torch.allclose(s[ok, 3].double(), mean_rt[ok], rtol=2e-6, atol=2e-6))
+    mz = z.double().mean(1)
+    vz = ((z.double() - mz[:, None]) ** 2).mean(1)
+    assert bool(torch.allclose(s[:, 7].double(), mz, rtol=1e-5, atol=1e-5))
+    assert bool(torch.allclose(s[:, 8].double(), vz, rtol=2e-3, atol=1e-5))
+    assert bool(torch.allclose(s[:, 9].double(), (0.5 + 0.5 * torch.sign(y.double())).mean(1), atol=1e-6))
+    # z1 ~ N(gamma * a_trial, sigma1) with a_trial ~ N(mu_alpha, std_alpha) truncated to > 0 by rejection
+    # (single_trial_alpha_not_scaled.py:113-116, :134): E[z1 | set] = mu + std * pdf(mu/std) / cdf(mu/std)
+    mu, sd = p[:, 1].double(), p[:, 4].double()
+    nrm = torch.distributions.Normal(0.0, 1.0)
+    ez = mu + sd * torch.exp(nrm.log_prob(mu / sd)) / nrm.cdf(mu / sd)
+    assert abs(float(mz.mean()) - float(ez.mean())) < 2e-3
+    for lo, hi in ((0, 1), (777_777, 777_781), (999_999, 1_000_000)):
+        r2 = engine.simulate(engine.SINGLE_TRIAL, p[lo:hi], N, dt=dt, max_steps=ms, seed=99, set_offset=lo, fast=True)
+        assert torch.equal(r2["trials"], t[lo:hi])
+        assert torch.equal(torch.nan_to_num(r2["summary"]), torch.nan_to_num(s[lo:hi]))
+    r3 = engine.simulate(engine.SINGLE_TRIAL, p[:50_000], N, dt=dt, max_steps=ms, seed=99, set_offset=0, fast=True,
+                         want_trials=False)
+    assert torch.equal(torch.nan_to_num(r3["summary"]), torch.nan_to_num(s[:50_000]))
+
+
+@pytest.mark.parametrize("bridge", [False, True])
+def test_full_size_alpha_not_scaled(bridge):
+    """BASELINE.json configs[2]: alpha_not_scaled as an E-M process, 1M sets x 300 trials, dt=.001 (plain and with the
+    bridge correction): domains of (y = sign * rt, acc), external datum ~ N(Alpha, sigma), accuracy increases with
+    drift, rows re-simulated alone reproduce their bits."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N, dt, ms = 1_000_000, 300, 0.001, 4000
+    p = torch.as_tensor(prior_util.alpha_ns_prior(B, 2021)).cuda()        # Nu, Alpha, Beta, Tau, Eta, Varsigma
+    r = engine.simulate(engine.ALPHA_NOT_SCALED, p, N, dt=dt, max_steps=ms, seed=5, set_offset=0, fast=True,
+                        bridge=bridge, ext_sigma=0.1, want_ext=True)
+    t, s, ext = r["trials"], r["summary"], r["ext"]
+    y, acc = t[..., 0], t[..., 1]
+    assert bool(torch.isfinite(t).all())
+    assert bool(((acc == 1) | (acc == 0) | (acc == 0.5)).all())           # 0.5 codes a timeout (sign 0)
+    assert bool(((y > 0) == (acc == 1)).all() and ((y < 0) == (acc == 0)).all())
+    tau = p[:, 3:4]
+    resp = y != 0
+    lo_bound = tau if bridge else tau + dt * 0.999                       # the bridge jitters the RT below the grid time
+    assert bool((y.abs()[resp] >= lo_bound.expand_as(y)[resp] - 1e-6).all())
+    assert bool((s[:, 0] == (y > 0).sum(1)).all() and (s[:, 1] == (y < 0).sum(1)).all())
+    assert abs(float((ext - p[:, 1]).mean())) < 1e-3 and abs(float((ext - p[:, 1]).std()) - 0.1) < 1e-3
+    up = (y > 0).float().mean(1)
+    hi_drift, lo_drift = p[:, 0] > 2.0, p[:, 0] < -2.0
+    assert float(up[hi_drift].mean()) > 0.85 and float(up[lo_drift].mean()) < 0.15
+    for lo, hi in ((0, 2), (314_159, 314_163), (999_998, 1_000_000)):
+        r2 = engine.simulate(engine.ALPHA_NOT_SCALED, p[lo:hi], N, dt=dt, max_steps=ms, seed=5, set_offset=lo, fast=True,
+                             bridge=bridge, ext_sigma=0.1, want_ext=True)
+        assert torch.equal(r2["trials"], t[lo:hi]) and torch.equal(r2["ext"], ext[lo:hi])
+
+
 def test_drop_in_api_on_device(kat):
     """The reference's call shapes end to end on the GPU: per-set simulator_fun, batched generative model, dict keys,
     configurator, alpha_not_scaled generator, imputation loop."""
