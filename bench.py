@@ -274,6 +274,19 @@ def main():
                                     "ceiling": "step loop with every lane useful (measured lockstep run)",
                                     "sum_of_isolated_issue_costs": VALU_MODEL["sum_of_issue_costs_fast" if fast
                                                                               else "sum_of_issue_costs_exact"]}
+        if world == 1 and "roofline_valu" in res:
+            # steps the lanes actually EXECUTED (incl. lanes idling on a finished trial until the next refill): one more
+            # launch of the last batch, outside the timed region, with the kernel's debug counters switched on
+            from bayesflow_nddms_amd import _lib
+            dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+            _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
+            step(a.warmup + a.steps - 1)
+            torch.cuda.synchronize()
+            _lib.lib().nddm_set_debug_counters(None)
+            d = dbg.cpu().numpy().astype(np.float64)
+            res["roofline_valu"].update({"executed_lane_steps_per_launch": d[0] * 256.0,
+                                         "lane_efficiency": em_steps / (d[0] * 256.0),
+                                         "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
         if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
         if world == 1 and not a.no_cpu_baseline and a.model == "basic":
