@@ -56,3 +56,13 @@ def test_fuzz_bit_parity(chunk):
                 assert np.array_equal(g["ext"].cpu().numpy().view(np.uint32), o["ext"].view(np.uint32)), ctx
     finally:
         _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
+
+
+def test_stress_parity_subset():
+    """tools/stress_parity.py at two sizes per model: the ordering pre-pass (B >= 2048), a multi-chunk queue and a set
+    split into tiles (N = 700), against the oracle, every bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_parity
+    assert stress_parity.run(sizes=((6000, 300), (2500, 700)), verbose=False, threads=8) == []
