@@ -93,7 +93,7 @@ struct AuxStream {
     __device__ __forceinline__ float normal(uint32_t a)
     {
         const uint32_t b = a >> 2;
-        if (b != blk) { x = philox4x32_10_lds(b, trial, set_lo, c3, kbase); blk = b; have01 = false; have23 = false; }
+        if (b != blk) { x = philox4x32_10_lds(set_lo, trial, c3, b, kbase); blk = b; have01 = false; have23 = false; }
         const uint32_t j = a & 3u;
         const float sc = noise_unit<FAST>(1.0f);
         if (j < 2u) {
@@ -230,8 +230,8 @@ __device__ __forceinline__ bool in_range(float w, float h)
 // Per-set constants of the trial hand-out, computed ONCE when a tile opens (a hand-out then costs three LDS reads and an
 // xor instead of ~15 VALU instructions per refill): dword index into the tile's DV-dword LDS record.
 enum { D_MU = 0, D_INVS = 1, D_H = 2, D_W0 = 3,      // (in noise units) drift*dt, 1 / unit, boundary/2, centred start point
-       D_N1 = 4, D_HIK = 5, D_C3K = 6, D_SETLO = 7,  // Philox round-0 constants of the set (PathCtr), low set word
-       D_C3 = 8, D_SPARE = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), -, first trial of the
+       D_CA = 4, D_CB = 5, D_HP1K = 6, D_X1 = 7,     // Philox constants of the set (PathSet in nddm_rng.h)
+       D_C3 = 8, D_SETLO = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), low set word, first trial of the
        DV = 12 };                                    // tile within its set, in-call set index
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // which lanes hold a trial / are still stepping: wave-uniform lane masks kept in SGPRs (a per-lane bool that is
     // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
     unsigned long long has_m = 0ull, act_m = 0ull;
-    PathCtr pc = {0u, 0u, 0u};
+    PathCtr pc = {0u, 0u, 0u, 0u, 0u};
 
     // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
     int tile_open = 0;       // tiles whose parameters are staged in LDS
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const int sic = A.tiles_per_set == 1 ? vset : vset / A.tiles_per_set;
                 const unsigned long long gset = A.set_offset + (unsigned long long)sic;
                 const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
-                const uint64_t p1 = (uint64_t)0xCD9E8D57u * s_lo;
+                PathSet ps;
+                ps.init(s_lo, s_hi, A.k0, A.k1);              // stream 0: no tag bits in c2
                 float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 0.0f;       // the per-SET ones of the model
                 if constexpr (MODEL == NDDM_BASIC_DDM_DC) { drift = row[0]; a = row[1]; beta = row[2]; sig_c = row[4]; }
                 else if constexpr (MODEL == NDDM_SINGLE_TRIAL) { drift = row[0]; beta = row[2]; sig_c = row[5]; }
@@ -342,12 +343,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     d[D_INVS] = __float_as_uint(inv_s);
                     d[D_H] = __float_as_uint(hv * inv_s);
                     d[D_W0] = __float_as_uint((a * beta - hv) * inv_s);
-                    d[D_N1] = (uint32_t)p1;
-                    d[D_HIK] = (uint32_t)(p1 >> 32) ^ A.k0;
-                    d[D_C3K] = s_hi ^ A.k1;
+                    d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
                     d[D_SETLO] = s_lo;
                     d[D_C3] = s_hi;
-                    d[D_SPARE] = 0u;
                     d[D_TBASE] = (uint32_t)((vset - sic * A.tiles_per_set) * N);
                     d[D_SIC] = (uint32_t)sic;
                 }
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 4);
                 const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 8);
                 trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
-                set_lo = d1.w;
+                set_lo = d2.y;
                 c3 = d2.x;
                 mu_dt = __uint_as_float(d0.x);
                 const float inv_s = __uint_as_float(d0.y);       // per-set where the model's noise scale is per set
@@ -474,9 +472,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     h = invalid ? 0.0f : hv * inv_s;
                     w = (a * pp[1] - hv) * inv_s;
                 }
-                pc.n0 = d1.y ^ trial;
-                pc.n1 = d1.x;
-                pc.c3k = d1.z;
+                pc.init(d1.x, d1.y, d1.z, d1.w, trial, A.k0, A.k1);
                 k = 0;
                 jit = 0;
             }
@@ -500,7 +496,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             rr[1] = rr[0]; rr[3] = rr[2];
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
-                const u32x4 u4 = philox4x32_10_lds(blk, trial, set_lo, c3 | 0x30000000u, kbase);   // stream 3
+                const u32x4 u4 = philox4x32_10_lds(set_lo, trial, c3 | 0x30000000u, blk, kbase);   // stream 3
                 ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
             }
 #pragma unroll

@@ -43,37 +43,66 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-// The path stream's Philox block with (a) the round keys fetched from LDS and (b) round 0 partly precomputed.
-// (a) On gfx950 a VOP2 xor that reads an SGPR issues at ~4.2 cycles, a VGPR-only one at ~2.3; the LDS pipe is otherwise
-//     idle in the step loop, so it delivers the (wave-uniform) keys as broadcast reads, prefetched one round ahead.
-//     LDS bytes [0, 80) hold key pair r at 8r; kbase is a VGPR holding LDS byte address 0.
-// (b) Within one trial only the block index changes, so round 0's M1*set_lo product and both key xors are per-trial
-//     constants: PathCtr carries them instead of (trial, set_lo, set_hi).
-struct PathCtr {
-    uint32_t n0, n1, c3k;    // hi(M1*set_lo) ^ trial ^ k0 ; lo(M1*set_lo) ; (set_hi | stream tag) ^ k1
-    __device__ __forceinline__ void init(uint32_t trial, uint32_t set_lo, uint32_t c3, uint32_t k0, uint32_t k1)
+// The path stream's Philox block, specialised.  Counter layout of every per-trial stream:
+//     (c0, c1, c2, c3) = (set_lo, trial, set_hi28 | stream << 28, draw)
+// i.e. the words that are constant within a set sit where round 0 MULTIPLIES (c0, c2) and the one that changes from
+// block to block (draw = index of the block's first step) where round 0 only XORs.  Following the constants through
+// the rounds, round 0 needs no multiply at all per block, rounds 1 and 2 need one each, and six of the round keys
+// fold into per-set / per-trial constants: 16 v_mad_u64_u32 + 13 v_bitop3 + 5 v_xor per block instead of 20 + 20.
+//   per set   (PathSet, computed when a tile opens):  P0 = M0*set_lo, P1 = M1*c2
+//   per trial (PathCtr, computed at hand-out, 2 multiplies): Q0 = M0*c0[1], S1 = M1*c2[2]      ([r] = after round r-1)
+//   per block: see philox4x32_10_path
+// The remaining round keys come from LDS: on gfx950 an SGPR operand costs VALU issue time, the LDS pipe is otherwise
+// idle in the step loop, so it delivers the (wave-uniform) keys as broadcast reads, prefetched one round ahead.
+// LDS bytes [0, 80) hold key pair r at 8r; kbase is a VGPR holding LDS byte address 0.
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u, PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+
+struct PathSet {
+    uint32_t cA, cB, hP1k, X1;
+    __device__ __forceinline__ void init(uint32_t set_lo, uint32_t c2, uint32_t k0, uint32_t k1)
     {
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * set_lo;
-        n0 = (uint32_t)(p1 >> 32) ^ trial ^ k0;
-        n1 = (uint32_t)p1;
-        c3k = c3 ^ k1;
+        const uint64_t P0 = (uint64_t)PHILOX_M0 * set_lo, P1 = (uint64_t)PHILOX_M1 * c2;
+        cA = (uint32_t)(P0 >> 32) ^ k1;                       // round 0: c2[1] = cA ^ draw
+        cB = (uint32_t)P1 ^ (k0 + PHILOX_W0);                 // round 1: c0[2] = hi(Q1) ^ cB
+        hP1k = (uint32_t)(P1 >> 32) ^ k0;                     // round 0: c0[1] = hP1k ^ trial
+        X1 = (uint32_t)P0 ^ (k1 + PHILOX_W1);                 // round 1: c2[2] = hi(Q0) ^ X1
     }
 };
 
-__device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t blk, const PathCtr &pc, uint32_t kbase)
+struct PathCtr {
+    uint32_t cA, cB, cC, cD, cE;
+    __device__ __forceinline__ void init(uint32_t sA, uint32_t sB, uint32_t hP1k, uint32_t X1, uint32_t trial,
+                                         uint32_t k0, uint32_t k1)
+    {
+        cA = sA; cB = sB;
+        const uint64_t Q0 = (uint64_t)PHILOX_M0 * (hP1k ^ trial);                  // round 1, constant half
+        const uint64_t S1 = (uint64_t)PHILOX_M1 * ((uint32_t)(Q0 >> 32) ^ X1);     // round 2, constant half
+        cC = (uint32_t)(S1 >> 32) ^ (k0 + 2u * PHILOX_W0);    // round 2: c0[3] = lo(Q1) ^ cC
+        cD = (uint32_t)Q0 ^ (k1 + 2u * PHILOX_W1);            // round 2: c2[3] = hi(S0) ^ cD
+        cE = (uint32_t)S1 ^ (k0 + 3u * PHILOX_W0);            // round 3: c0[4] = hi(T1) ^ cE
+    }
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t draw, const PathCtr &pc, uint32_t kbase)
 {
     uint32_t ka, kb;
     uint64_t kn;
-    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(kn) : "v"(kbase));          // keys of round 1
-    const uint64_t q0 = (uint64_t)0xD2511F53u * blk;                                 // round 0
-    uint32_t c0 = pc.n0, c1 = pc.n1, c2 = (uint32_t)(q0 >> 32) ^ pc.c3k, c3 = (uint32_t)q0;
+    asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(kn) : "v"(kbase));          // keys of round 3 (only k1 + 3 W1 is used)
+    const uint64_t Q1 = (uint64_t)PHILOX_M1 * (pc.cA ^ draw);                        // rounds 0 + 1
+    const uint64_t S0 = (uint64_t)PHILOX_M0 * ((uint32_t)(Q1 >> 32) ^ pc.cB);        // round 2
+    const uint64_t T0 = (uint64_t)PHILOX_M0 * ((uint32_t)Q1 ^ pc.cC);                // round 3
+    const uint64_t T1 = (uint64_t)PHILOX_M1 * ((uint32_t)(S0 >> 32) ^ pc.cD);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+    kb = (uint32_t)(kn >> 32);
+    uint32_t c0 = (uint32_t)(T1 >> 32) ^ pc.cE, c1 = (uint32_t)T1, c2 = xor3((uint32_t)(T0 >> 32), (uint32_t)S0, kb), c3 = (uint32_t)T0;
+    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(kn) : "v"(kbase));          // keys of round 4
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
     ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32);
 #define NDDM_ROUND(NEXT_OFF, LAST)                                                                        \
     {                                                                                                     \
         if (!(LAST)) asm volatile("ds_read_b64 %0, %1 offset:" #NEXT_OFF : "=v"(kn) : "v"(kbase));        \
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;                                                   \
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;                                                   \
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;                                                     \
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;                                                     \
         const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, ka);                                           \
         const uint32_t n1 = (uint32_t)p1;                                                                 \
         const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, kb);                                           \
@@ -81,8 +110,8 @@ __device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t blk, const PathCtr 
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
         if (!(LAST)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn)); ka = (uint32_t)kn; kb = (uint32_t)(kn >> 32); } \
     }
-    NDDM_ROUND(16, false) NDDM_ROUND(24, false) NDDM_ROUND(32, false) NDDM_ROUND(40, false) NDDM_ROUND(48, false)
-    NDDM_ROUND(56, false) NDDM_ROUND(64, false) NDDM_ROUND(72, false) NDDM_ROUND(0, true)
+    NDDM_ROUND(40, false) NDDM_ROUND(48, false) NDDM_ROUND(56, false) NDDM_ROUND(64, false) NDDM_ROUND(72, false)
+    NDDM_ROUND(0, true)
 #undef NDDM_ROUND
     return {c0, c1, c2, c3};
 }
