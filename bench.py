@@ -34,12 +34,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_MODEL = {
     "clock_ghz": 2.4, "simds": 1024,
     # SIMD cycles one wave64 needs per Philox block (4 E-M steps x 64 lanes) when EVERY lane is useful: measured with
-    # tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes): 272 cycles per block at
-    # lane efficiency 0.983 (fast), 522 at 0.980 (exact) -- profiles/r1_summary.md.  The sum of the isolated
-    # per-instruction issue costs of the loop (tools/isa_mix.py x profiles/r1_ubench_valu.txt) is 293 / 614: the real
+    # tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes): 265 cycles per block at
+    # lane efficiency 0.984 (fast), 506 at 0.978 (exact) -- profiles/r1_summary.md.  The sum of the isolated
+    # per-instruction issue costs of the loop (tools/isa_mix.py x profiles/r1_ubench_valu.txt) is 274 / 595: the real
     # loop issues slightly better than that sum, so the measured figure is the tighter ceiling.
-    "cycles_per_block_fast": 267.0, "cycles_per_block_exact": 512.0,
-    "sum_of_issue_costs_fast": 293.0, "sum_of_issue_costs_exact": 614.0,
+    "cycles_per_block_fast": 261.0, "cycles_per_block_exact": 495.0,
+    "sum_of_issue_costs_fast": 274.0, "sum_of_issue_costs_exact": 595.0,
 }
 
 
