@@ -20,6 +20,10 @@
 //     when the last trial of a set retires the wave FLUSHES the slot: one coalesced float2
 //     store sweep to HBM plus the fused per-set summary reduction (integer sums reduced
 //     across the wave with shuffles, so summaries are bit-reproducible).
+//   * the evidence is carried centred and in noise units, w = (x - a/2) / sigma: one step is
+//     w = fma(r, cos|sin, w) + mu with the unit Box-Muller radius, the range test is |w| < h.
+//     Everything of a hand-out that is constant within a set (mu, 1/sigma, h, w0, the Philox
+//     products of the set words) is computed once per tile into a 48-byte LDS record.
 //   * the Gaussian stream is counter-based (nddm_rng.h): no RNG state is loaded or stored.
 //     Philox's wave-uniform round keys are served from LDS as broadcast reads, because a VALU xor
 //     that reads an SGPR operand issues at half the rate of a VGPR-only one on gfx950.
