@@ -204,10 +204,11 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
         n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
         sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
         if (lane == 0) {
-            if (TPS == 1) {
+            if (!A.partials) {      // small launches: finalise in place (one lane, f64 divisions: ~250 instructions)
                 finalize_summary(A.out_summary + set_in_call * NDDM_SUMMARY_K, n_up, n_lo, n_miss, sk, sk2, sk_up, sk2_up,
                                  sz, szz, A.n_total, A.tscale, tau);
-            } else {          // integer partial sums of this tile; combine_partials_kernel adds the tiles up
+            } else {          // integer partial sums of this tile; combine_partials_kernel adds the tiles up and
+                              // finalises with one THREAD per set instead of one WAVE per set
                 long long *q = A.partials + vset * 9;
                 q[0] = n_up; q[1] = n_lo; q[2] = n_miss; q[3] = (long long)sk; q[4] = (long long)sk2;
                 q[5] = (long long)sk_up; q[6] = (long long)sk2_up; q[7] = sz; q[8] = szz;
@@ -841,15 +842,6 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if ((long long)tile_n * tiles >= (1ll << 30) || n_trials >= (1 << 30))
         return fail(NDDM_ERR_SHAPE, "n_trials must be < 2^30%s");
     A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles; A.B = vB;
-    // geometry: ring slots so that the wave's window spans >= ~1024 trials (16 per lane): sets are flushed in order, so
-    // a straggler trial in the oldest set must not stall the lanes that are ahead of it
-    int ring = g_tuning.ring ? g_tuning.ring : round_up_pow2((1024 + tile_n - 1) / tile_n);
-    if (ring < 4 && !g_tuning.ring) ring = 4;
-    if (ring < 2) ring = 2;
-    if (ring > 64) ring = 64;
-    while (ring > 2 && (size_t)ring * tile_n * per_trial > 40 * 1024) ring >>= 1;
-    if ((size_t)ring * tile_n * per_trial > 60 * 1024)
-        return fail(NDDM_ERR_SHAPE, "tile too large for the LDS ring (tuning override?)%s");
     // chunk = the unit a wave pulls from the global queue: small (tail of the whole launch <= one chunk), but large
     // enough that the queue's atomic counter is touched rarely (~ once per 1200+ trials per wave)
     int spc = g_tuning.sets_per_chunk;
@@ -858,7 +850,38 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
         while (spc > 1 && vB / spc < 32 * 7168) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
+        // ... but the queue is ONE atomic word: same-address atomics retire at ~85 M/s on MI355X (measured: 1M chunks
+        // take 11.6 ms whatever the work), so short-trial workloads (dt = .01, few trials per set) must not pull more
+        // than ~40 M chunks/s.  Expected duration from the stepping alone: E[steps] ~ min(cap, 0.25 / dt) under the
+        // reference priors, 265 SIMD cycles per 256 lane-steps.  Keep at least ~8 chunks per wave for the tail.
+        double est_steps = 0.25 / (double)dt;
+        if (est_steps > (double)max_steps) est_steps = (double)max_steps;
+        if (est_steps < 1.0) est_steps = 1.0;
+        const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / (1024.0 * 2.4e9);
+        double max_chunks = t_est * 4.0e7;
+        if (max_chunks < 8.0 * 6144.0) max_chunks = 8.0 * 6144.0;
+        if ((double)vB / spc > max_chunks) {
+            spc = (int)((double)vB / max_chunks) + 1;
+            if (spc > 64) spc = 64;
+        }
     }
+    // geometry: ring slots.  Sets are flushed in order, so a straggler trial in the oldest set must not stall the lanes
+    // that are ahead of it: the wave's window (ring x tile) should span >= ~480 trials (7-8 per lane; measured: 400 costs
+    // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 6 waves per SIMD resident
+    // (24 single-wave workgroups per CU: <= 160 KB / 24 each) -- below that the VALU pipe starves (-6 % at 5, -17 % at 4),
+    // which costs more than a short window.
+    const auto lds_of = [&](int r) { return 80 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
+    int ring = g_tuning.ring;
+    if (!ring) {
+        ring = round_up_pow2((480 + tile_n - 1) / tile_n);
+        if (ring < 4) ring = 4;
+        if (ring > 64) ring = 64;
+        while (ring > 2 && lds_of(ring) > 6656) ring >>= 1;
+    }
+    if (ring < 2) ring = 2;
+    if (ring > 64) ring = 64;
+    if (lds_of(ring) > 60 * 1024)
+        return fail(NDDM_ERR_SHAPE, "tile too large for the LDS ring (tuning override?)%s");
     A.sets_per_chunk = spc; A.ring = ring;
     // refill threshold: a refill costs ~170 issue cycles whatever the number of lanes it serves, a waiting lane wastes
     // its share of every block; with lambda completions per block the optimum is ~sqrt(61 lambda) finished lanes:
@@ -872,7 +895,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
     A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
-    const size_t lds = 80 + (size_t)ring * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)ring * tile_n * per_trial;
+    const size_t lds = lds_of(ring);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // one queue word per launch from a small per-device pool, zeroed on the launch's stream
     {
@@ -922,7 +945,9 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     // split sets: the tiles leave integer partial sums in a stream-ordered scratch buffer
     A.partials = nullptr;
-    if (tiles > 1 && out_summary) {
+    // ... and so do unsplit sets of large launches: the f64 finalisation is then done by combine_partials_kernel at full
+    // lane occupancy instead of by lane 0 of every flush (same function, same integers in: same bits out)
+    if ((tiles > 1 || B >= 2048) && out_summary) {
         const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&A.partials), (size_t)vB * 9 * sizeof(long long), st);
         if (e != hipSuccess) {
             if (order_ws) (void)hipFreeAsync(order_ws, st);
