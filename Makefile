@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 HIPFLAGS = -O3 -ffp-contract=off --offload-arch=gfx950 -std=c++17 -fPIC -shared
 
-all: lib oracle ubench
+all: lib oracle ubench demo
 
 lib: bayesflow_nddms_amd/libnddm_hip.so
 bayesflow_nddms_amd/libnddm_hip.so: bayesflow_nddms_amd/csrc/nddm_kernels.hip bayesflow_nddms_amd/csrc/nddm_rng.h include/nddm.h
@@ -17,11 +17,17 @@ ubench: tools/ubench_valu
 tools/ubench_valu: tools/ubench_valu.hip
 	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<
 
+# the boundary from plain C (examples/c_abi_demo.c): no Python, no PyTorch
+demo: examples/c_abi_demo
+examples/c_abi_demo: examples/c_abi_demo.c include/nddm.h bayesflow_nddms_amd/libnddm_hip.so
+	gcc -O2 -std=c99 -D_POSIX_C_SOURCE=199309L -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude $< -o $@ \
+	    -Lbayesflow_nddms_amd -lnddm_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../bayesflow_nddms_amd' -Wl,-rpath,/opt/rocm/lib
+
 test-cpu:
 	python -m pytest tests -x -q -m "not gpu"
 test-gpu:
 	python -m pytest tests -x -q -m gpu
 
 clean:
-	rm -f bayesflow_nddms_amd/libnddm_hip.so oracle/liboracle.so tools/ubench_valu
-.PHONY: all lib oracle ubench test-cpu test-gpu clean
+	rm -f bayesflow_nddms_amd/libnddm_hip.so oracle/liboracle.so tools/ubench_valu examples/c_abi_demo
+.PHONY: all lib oracle ubench demo test-cpu test-gpu clean
