@@ -73,7 +73,8 @@ struct SimArgs {
     uint32_t k0, k1;
     int sets_per_chunk;
     int n_chunks;
-    unsigned int *chunk_counter;   // device word, zeroed before the launch: the next chunk to hand out
+    unsigned int *chunk_counter;   // device words [0] next chunk to hand out, [1] waves that have left; both are zero
+                                   // between launches: the last wave to leave resets them
     int ring;                 // LDS ring slots (power of two)
     int open_ahead;           // tiles staged ahead of the one being handed out (0 when work is scarce, else 1)
     float ext_sigma;
@@ -541,6 +542,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
         }
     }
+    // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
+    // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
+    // per launch, and a captured launch is kernels only.
+    if (lane == 0) {
+        const unsigned int left = atomicAdd(A.chunk_counter + 1, 1u);
+        if (left == gridDim.x - 1u) { atomicExch(A.chunk_counter, 0u); atomicExch(A.chunk_counter + 1, 0u); }
+    }
     if (A.dbg && lane == 0) {
         atomicAdd(A.dbg + 0, dbg_blocks);
         atomicAdd(A.dbg + 1, dbg_refills);
@@ -583,6 +591,10 @@ __device__ __forceinline__ int duration_bucket(int model, const float *p, float 
 }
 
 // ws[0..31] histogram, ws[32..63] cursors (both zeroed before the launch)
+// zeroes the 64 counting-sort counters (a kernel, not hipMemsetAsync: memset NODES of a captured launch were observed not
+// to take effect on graph replay with ROCm 7.2)
+__global__ void order_zero_kernel(int *ws) { ws[threadIdx.x] = 0; }
+
 __global__ void order_hist_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws)
 {
     __shared__ int h[ORDER_BUCKETS];
@@ -897,86 +909,110 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
     const size_t lds = lds_of(ring);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // one queue word per launch from a small per-device pool, zeroed on the launch's stream
+    const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
+    // ---- per-launch device scratch -------------------------------------------------------------------------------
+    //  * one queue (chunk counter + exit counter, self-resetting), from a per-device pool of 4096 handed out round-robin;
+    //  * the longest-first order (64 counters + B indices + the gathered parameter rows) for launches of >= 2048 sets;
+    //  * integer partial sums [vB, 9] when sets are split into tiles, and for launches of >= 2048 sets (whose f64
+    //    finalisation is then done by combine_partials_kernel at full lane occupancy instead of by lane 0 of every flush:
+    //    same function, same integers in, same bits out).
+    // Scratch of up to 1 MB comes from a persistent 64 MB per-device ring, also round-robin (a region is reused after
+    // >= 64 later launches; launches on one stream are ordered anyway), so that the small, fixed-shape launches of a
+    // training loop hold no allocation and can be captured in a hipGraph.  Larger scratch is stream-ordered
+    // (hipMallocAsync / hipFreeAsync) and such a launch is refused while the stream is capturing: graphs that held
+    // hipMallocAsync nodes lost the ordering between the queue-word memset and the kernel on replay (ROCm 7.2).
+    const bool want_order = B >= 2048 && g_tuning.no_order == 0;
+    const bool want_partials = (tiles > 1 || B >= 2048) && out_summary;
+    const size_t order_bytes = want_order ? (((size_t)(64 + B + B * P) * sizeof(int) + 255) & ~(size_t)255) : 0;
+    const size_t partial_bytes = want_partials ? (size_t)vB * 9 * sizeof(long long) : 0;
+    const size_t scratch_bytes = order_bytes + partial_bytes;
+    char *scratch = nullptr;
+    bool scratch_async = false;
     {
         static std::mutex mu;
         static unsigned int *pool[64] = {nullptr};
         static unsigned int next[64] = {0};
+        static char *ring_base[64] = {nullptr};
+        static size_t ring_off[64] = {0};
         constexpr unsigned int POOL = 4096;
+        constexpr size_t RING_BYTES = 64u << 20, RING_MAX = 1u << 20;
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess || dev < 0 || dev >= 64) return fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
         std::lock_guard<std::mutex> lock(mu);
         if (!pool[dev]) {
-            // the stream-ordered scratch buffers (processing order, partial sums) come from the device's default memory
-            // pool: keep freed blocks cached instead of handing them back to the OS at every synchronisation
+            // keep freed stream-ordered blocks cached instead of handing them back to the OS at every synchronisation
             hipMemPool_t mp;
             if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess) {
                 uint64_t keep = UINT64_MAX;
                 (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
             }
-            e = hipMalloc(reinterpret_cast<void **>(&pool[dev]), POOL * sizeof(unsigned int));
+            e = hipMalloc(reinterpret_cast<void **>(&pool[dev]), 2 * POOL * sizeof(unsigned int));
+            if (e == hipSuccess) e = hipMemset(pool[dev], 0, 2 * POOL * sizeof(unsigned int));
             if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(queue words): %s", hipGetErrorString(e));
+            e = hipMalloc(reinterpret_cast<void **>(&ring_base[dev]), RING_BYTES);
+            if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(scratch ring): %s", hipGetErrorString(e));
         }
-        A.chunk_counter = pool[dev] + (next[dev]++ % POOL);
-        e = hipMemsetAsync(A.chunk_counter, 0, sizeof(unsigned int), st);
-        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMemsetAsync(queue word): %s", hipGetErrorString(e));
+        A.chunk_counter = pool[dev] + 2 * (next[dev]++ % POOL);
+        if (scratch_bytes && scratch_bytes <= RING_MAX) {
+            const size_t need = (scratch_bytes + 255) & ~(size_t)255;
+            if (ring_off[dev] + need > RING_BYTES) ring_off[dev] = 0;
+            scratch = ring_base[dev] + ring_off[dev];
+            ring_off[dev] += need;
+        }
     }
-    const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
-    // longest-first processing order (stream-ordered scratch: 64 counters + B indices + the gathered parameter rows)
+    if (scratch_bytes && !scratch) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(NDDM_ERR_PARAM, "this launch needs stream-ordered scratch (>= 2048 sets, or many split sets) and cannot "
+                                        "be captured in a hipGraph%s");
+        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&scratch), scratch_bytes, st);
+        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(scratch): %s", hipGetErrorString(e));
+        scratch_async = true;
+    }
+    int rc = NDDM_OK;
     A.order = nullptr;
-    int *order_ws = nullptr;
-    if (B >= 2048 && g_tuning.no_order == 0) {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&order_ws), (size_t)(64 + B + B * P) * sizeof(int), st);
-        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(order): %s", hipGetErrorString(e));
-        e = hipMemsetAsync(order_ws, 0, 64 * sizeof(int), st);
-        if (e != hipSuccess) { (void)hipFreeAsync(order_ws, st); return fail(NDDM_ERR_HIP, "hipMemsetAsync(order): %s", hipGetErrorString(e)); }
-        const int threads = 256;
-        long long blocks = (B + threads - 1) / threads;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
-                           (int)max_steps, order_ws);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
-                           (int)max_steps, order_ws, order_ws + 64, reinterpret_cast<float *>(order_ws + 64 + B));
-        e = hipGetLastError();
-        if (e != hipSuccess) { (void)hipFreeAsync(order_ws, st); return fail(NDDM_ERR_HIP, "order kernels: %s", hipGetErrorString(e)); }
+    A.partials = want_partials ? reinterpret_cast<long long *>(scratch + order_bytes) : nullptr;
+    if (want_order) {
+        // longest-first processing order
+        int *order_ws = reinterpret_cast<int *>(scratch);
+        hipError_t e = hipSuccess;
+        {
+            hipLaunchKernelGGL(order_zero_kernel, dim3(1), dim3(64), 0, st, order_ws);
+            const int threads = 256;
+            long long blocks = (B + threads - 1) / threads;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
+                               (int)max_steps, order_ws);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
+                               (int)max_steps, order_ws, order_ws + 64, reinterpret_cast<float *>(order_ws + 64 + B));
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "ordering pre-pass: %s", hipGetErrorString(e));
         A.order = order_ws + 64;
         A.params_q = reinterpret_cast<const float *>(order_ws + 64 + B);
     }
-    // split sets: the tiles leave integer partial sums in a stream-ordered scratch buffer
-    A.partials = nullptr;
-    // ... and so do unsplit sets of large launches: the f64 finalisation is then done by combine_partials_kernel at full
-    // lane occupancy instead of by lane 0 of every flush (same function, same integers in: same bits out)
-    if ((tiles > 1 || B >= 2048) && out_summary) {
-        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&A.partials), (size_t)vB * 9 * sizeof(long long), st);
-        if (e != hipSuccess) {
-            if (order_ws) (void)hipFreeAsync(order_ws, st);
-            return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
+    if (rc == NDDM_OK) {
+        switch (model) {
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st); break;
+        case NDDM_ALPHA_NOT_SCALED:
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
+            break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st); break;
         }
     }
-    int rc;
-    switch (model) {
-    case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st); break;
-    case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st); break;
-    case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st); break;
-    case NDDM_ALPHA_NOT_SCALED:
-        rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
-                    : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
-        break;
-    default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st); break;
+    if (rc == NDDM_OK && A.partials) {
+        const int tau_idx = model == NDDM_EXPLICIT_BOUNDARY ? 2 : 3;
+        const int threads = 256;
+        hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st,
+                           A.partials, params, P, tau_idx, (long long)B, tiles, n_trials, A.tscale, out_summary);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
     }
-    if (order_ws) (void)hipFreeAsync(order_ws, st);
-    if (A.partials) {
-        if (rc == NDDM_OK) {
-            const int tau_idx = model == NDDM_EXPLICIT_BOUNDARY ? 2 : 3;
-            const int threads = 256;
-            hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st,
-                               A.partials, params, P, tau_idx, (long long)B, tiles, n_trials, A.tscale, out_summary);
-            const hipError_t e = hipGetLastError();
-            if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
-        }
-        (void)hipFreeAsync(A.partials, st);
-    }
+    if (scratch_async) (void)hipFreeAsync(scratch, st);
     return rc;
 }
 

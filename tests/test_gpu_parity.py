@@ -298,3 +298,53 @@ def test_fast_mode_agrees_with_exact(model):
     gs, os_ = g["summary"], o["summary"]
     assert np.allclose(np.nan_to_num(gs[:, :3]), np.nan_to_num(os_[:, :3]), atol=2)
     assert np.allclose(np.nan_to_num(gs[:, 3]), np.nan_to_num(os_[:, 3]), rtol=0.02, atol=1e-3)
+
+
+@pytest.mark.parametrize("B", [32, 1500, 4096])
+def test_hipgraph_capture_and_replay(B):
+    """after a first call, a launch whose scratch fits the library's persistent ring (<= 1 MB: small
+    training-loop shapes, here up to 4096 sets x 180 trials incl. the ordering pre-pass and the combine kernel) is
+    capturable in a hipGraph; every replay reproduces the eager result bit for bit."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    p = torch.as_tensor(prior_util.basic_prior(B, 1)).cuda()
+    out = torch.empty((B, 180, 2), device="cuda")
+    summ = torch.empty((B, 10), device="cuda")
+    kw = dict(dt=.001, max_steps=4000, seed=3, set_offset=7, fast=True, out_trials=out, out_summary=summ)
+    engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+    torch.cuda.synchronize()
+    ref_t, ref_s = out.clone(), summ.clone()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+    for _ in range(5):
+        out.zero_(); summ.fill_(-7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_t)
+        assert torch.equal(torch.nan_to_num(summ), torch.nan_to_num(ref_s))
+
+
+def test_large_launch_is_refused_under_capture():
+    """A launch that needs stream-ordered scratch (> 1 MB) must not be captured: it fails with ValueError instead of
+    producing a graph that misbehaves on replay, and the library stays usable."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B = 40000
+    p = torch.as_tensor(prior_util.basic_prior(B, 2)).cuda()
+    r = engine.simulate(engine.BASIC_DDM_DC, p, 100, dt=.01, max_steps=400, seed=1, set_offset=0, fast=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with pytest.raises(ValueError, match="cannot be captured"):
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                engine.simulate(engine.BASIC_DDM_DC, p, 100, dt=.01, max_steps=400, seed=1, set_offset=0, fast=True,
+                                out_trials=r["trials"], out_summary=r["summary"])
+    torch.cuda.synchronize()
+    r2 = engine.simulate(engine.BASIC_DDM_DC, p, 100, dt=.01, max_steps=400, seed=1, set_offset=0, fast=True)
+    assert torch.equal(r2["trials"], r["trials"])
