@@ -198,7 +198,11 @@ def main():
                         set_offset=(i * world + rank) * B, fast=fast, out_trials=out_trials, out_summary=out_summary,
                         want_trials=not a.summary_only, bridge=bridge)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out_summary if a.gather == "summary" else out_trials)
+            src = out_summary if a.gather == "summary" else out_trials
+            if a.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, src)              # one RCCL all-gather per batch
+            else:                                                       # gloo rehearsal: list form
+                dist.all_gather(list(gathered.unbind(0)), src)
 
     def barrier():
         if world > 1:
