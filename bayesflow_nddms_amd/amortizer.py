@@ -200,11 +200,43 @@ class Trainer:
     def _setup_schedule(self, total_steps):
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=max(1, total_steps))
 
-    def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, **_):
+    def _prefetcher(self, batch_size, total):
+        """Yields `total` configured batches, simulating batch i+1 on a side stream BEFORE batch i is trained on: the
+        simulator launch (and a host-side prior) then overlaps the training step, whose loss read-back is the only
+        synchronisation point of an iteration.  Batches come in the same order from the same random stream as without
+        prefetching; nothing is simulated beyond `total`."""
+        if self.device.type != "cuda" or total <= 0:
+            for _ in range(total):
+                yield self._simulate(batch_size)
+            return
+        side = torch.cuda.Stream(device=self.device)
+
+        def launch():
+            with torch.cuda.stream(side):
+                conf = self._simulate(batch_size)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return conf, ev
+
+        nxt = launch()
+        for i in range(total):
+            conf, ev = nxt
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            for v in conf.values():          # the tensors were allocated on the side stream's pool
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+            if i + 1 < total:
+                nxt = launch()
+            yield conf
+
+    def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, prefetch=True, **_):
         self._setup_schedule(epochs * iterations_per_epoch)
         for ep in range(epochs):
-            for _ in range(iterations_per_epoch):
-                self.loss_history.append(self._step(self._simulate(batch_size)))
+            batches = (self._prefetcher(batch_size, iterations_per_epoch) if prefetch
+                       else (self._simulate(batch_size) for _ in range(iterations_per_epoch)))
+            for conf in batches:
+                self.loss_history.append(self._step(conf))
             if save_checkpoint:
                 self.save_checkpoint()
         return self.loss_history

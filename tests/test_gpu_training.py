@@ -27,3 +27,33 @@ def test_online_training_on_device_simulator():
     assert np.max(rho) > 0.4 and np.mean(rho) > 0.15, rho
     post = am.sample(basic_ddm_dc.configurator(gm(1)), 1000)
     assert post.shape == (1000, 5) and np.all(np.isfinite(post))
+
+
+def test_prefetched_online_training_sees_the_same_batches():
+    """train_online(prefetch=True) simulates batch i+1 on a side stream while batch i is trained on.  Same seeds =>
+    the same batches in the same order => the same loss curve as without prefetching, the same simulator stream state
+    afterwards (nothing is simulated beyond the last iteration), and it is not slower."""
+    import time
+    import torch
+    import bayesflow_nddms_amd as nd
+    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    hist, state, secs = {}, {}, {}
+    for prefetch in (False, True):
+        torch.manual_seed(0)
+        np.random.seed(7)
+        nd.seed(99)
+        gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+        tr = Trainer(am, gm, basic_ddm_dc.configurator, checkpoint_path=None, learning_rate=1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hist[prefetch] = tr.train_online(epochs=2, iterations_per_epoch=40, batch_size=64, save_checkpoint=False,
+                                         prefetch=prefetch)
+        torch.cuda.synchronize()
+        secs[prefetch] = time.perf_counter() - t0
+        state[prefetch] = nd.GLOBAL_STREAM.get_state()
+    assert len(hist[True]) == len(hist[False]) == 80
+    assert np.allclose(hist[True], hist[False], rtol=1e-4, atol=1e-4)
+    assert state[True] == state[False]
+    assert secs[True] < secs[False] * 2.0       # (overlap helps; the bound only guards against a pathological stall)
