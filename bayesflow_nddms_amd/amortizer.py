@@ -242,7 +242,7 @@ class Trainer:
         return self.loss_history
 
     def train_experience_replay(self, epochs, iterations_per_epoch, batch_size, capacity_in_batches=100,
-                                save_checkpoint=True, validation_sims=None, **_):
+                                save_checkpoint=True, validation_sims=None, prefetch=True, **_):
         """Each iteration simulates one fresh batch into a ring buffer of `capacity_in_batches` batches and trains on
         a randomly chosen stored batch (BayesFlow's experience replay, used at basic_ddm_dc.py:199-202).  Batches keep
         their own N (the non-batchable context), as in BayesFlow's buffer."""
@@ -250,8 +250,9 @@ class Trainer:
         rng = np.random.default_rng(0)
         val = []
         for ep in range(epochs):
-            for _ in range(iterations_per_epoch):
-                conf = self._simulate(batch_size)
+            batches = (self._prefetcher(batch_size, iterations_per_epoch) if prefetch
+                       else (self._simulate(batch_size) for _ in range(iterations_per_epoch)))
+            for conf in batches:
                 if len(self.replay) < capacity_in_batches:
                     self.replay.append(conf)
                 else:
