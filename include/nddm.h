@@ -92,7 +92,8 @@ int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
  *   dt          Euler-Maruyama step (reference default .01, basic_ddm_dc.py:87; fine study .001, single_trial_alpha_not_scaled.py:1719)
  *   max_steps   step cap (reference default 400; 4000 in the fine study)
  *   seed        64-bit stream key
- *   set_offset  global index of row 0 (makes shards of one logical batch reproducible)
+ *   set_offset  global index of row 0 (makes shards of one logical batch reproducible); set_offset + row must stay
+ *               below 2^60 (the random stream is keyed by the low 60 bits of the global set index)
  *   flags       enum nddm_flags
  *   out_trials  device f32 [B, n_trials, 2] or NULL
  *   out_summary device f32 [B, NDDM_SUMMARY_K] or NULL
