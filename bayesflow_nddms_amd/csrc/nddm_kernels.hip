@@ -815,6 +815,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     if (B < 0 || n_trials <= 0 || max_steps < 0) return fail(NDDM_ERR_SHAPE, "B < 0, n_trials <= 0 or max_steps < 0%s");
     if (max_steps >= (1 << 30)) return fail(NDDM_ERR_SHAPE, "max_steps must be < 2^30%s");
+    if (set_offset >= (1ull << 60) || set_offset + (uint64_t)B > (1ull << 60))
+        return fail(NDDM_ERR_SHAPE, "set_offset + B must be <= 2^60 (the random stream is keyed by 60 bits of the set index)%s");
     if (!(dt > 0.0f) || !isfinite(dt)) return fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
     if (flags > 3u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
     const bool bridge = (flags & NDDM_BRIDGE) != 0;

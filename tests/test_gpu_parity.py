@@ -285,6 +285,8 @@ def test_edge_cases():
         engine.simulate(4, np.array([[1.0, .5, .3, 1.0]]), 4, bounds=np.array([[1.0, -0.1, 1.0, 1.0]]))
     with pytest.raises(ValueError):
         engine.simulate(0, np.zeros((3, 4), np.float32), 10)
+    with pytest.raises(ValueError):            # the stream is keyed by the low 60 bits of the global set index
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, seed=1, set_offset=2**60 - 1)
 
 
 @pytest.mark.parametrize("model", ["basic", "single", "alpha_ns"])
