@@ -238,7 +238,8 @@ __device__ __forceinline__ bool in_range(float w, float h)
 enum { D_MU = 0, D_INVS = 1, D_H = 2, D_W0 = 3,      // (in noise units) drift*dt, 1 / unit, boundary/2, centred start point
        D_CA = 4, D_CB = 5, D_HP1K = 6, D_X1 = 7,     // Philox constants of the set (PathSet in nddm_rng.h)
        D_C3 = 8, D_SETLO = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), low set word, first trial of the
-       DV = 12 };                                    // tile within its set, in-call set index
+       D_BCA = 12, D_BCB = 13, D_BHP1K = 14, D_BX1 = 15, // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
+       DV = 16 };                                    // tile within its set, in-call set index
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
 // once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
     unsigned long long has_m = 0ull, act_m = 0ull;
     PathCtr pc = {0u, 0u, 0u, 0u, 0u};
+    PathCtr pcb = {0u, 0u, 0u, 0u, 0u};           // bridge-uniform stream (BRIDGE only)
 
     // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
     int tile_open = 0;       // tiles whose parameters are staged in LDS
@@ -350,6 +352,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     d[D_H] = __float_as_uint(hv * inv_s);
                     d[D_W0] = __float_as_uint((a * beta - hv) * inv_s);
                     d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
+                    if constexpr (BRIDGE) {
+                        PathSet pb;
+                        pb.init(s_lo, s_hi | 0x30000000u, A.k0, A.k1);
+                        d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
+                    }
                     d[D_SETLO] = s_lo;
                     d[D_C3] = s_hi;
                     d[D_TBASE] = (uint32_t)((vset - sic * A.tiles_per_set) * N);
@@ -479,6 +486,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     w = (a * pp[1] - hv) * inv_s;
                 }
                 pc.init(d1.x, d1.y, d1.z, d1.w, trial, A.k0, A.k1);
+                if constexpr (BRIDGE) {
+                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 12);
+                    pcb.init(d3.x, d3.y, d3.z, d3.w, trial, A.k0, A.k1);
+                }
                 k = 0;
                 jit = 0;
             }
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             rr[1] = rr[0]; rr[3] = rr[2];
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
-                const u32x4 u4 = philox4x32_10_lds(set_lo, trial, c3 | 0x30000000u, blk, kbase);   // stream 3
+                const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);          // stream 3, same constant folding as the path stream
                 ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
             }
 #pragma unroll
