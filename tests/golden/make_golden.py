@@ -114,6 +114,12 @@ RATCLIFF_SETS = np.array([
     [-4.0, 0.8, 0.3, 0.15, 2.0, 1.4],
     [2.0, 1.4, 0.7, 0.60, 0.5, 0.8],
     [1.0, 1.1, 0.5, 0.40, 1.5, 1.0],
+    # five more corners / interior points of the generator's ranges (alpha_not_scaled.py:66-72)
+    [4.0, 0.8, 0.7, 0.15, 0.1, 0.8],
+    [-1.0, 1.4, 0.3, 0.60, 2.0, 1.4],
+    [0.5, 0.9, 0.6, 0.25, 0.7, 1.3],
+    [-3.0, 1.3, 0.65, 0.50, 1.2, 0.9],
+    [2.5, 1.0, 0.35, 0.45, 1.8, 1.1],
 ])
 DT_CONFIGS = [(0.01, 400.0), (0.001, 4000.0)]
 N_KS = 400_000
