@@ -205,11 +205,8 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
         n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
         sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
         if (lane == 0) {
-            if (!A.partials) {      // small launches: finalise in place (one lane, f64 divisions: ~250 instructions)
-                finalize_summary(A.out_summary + set_in_call * NDDM_SUMMARY_K, n_up, n_lo, n_miss, sk, sk2, sk_up, sk2_up,
-                                 sz, szz, A.n_total, A.tscale, tau);
-            } else {          // integer partial sums of this tile; combine_partials_kernel adds the tiles up and
-                              // finalises with one THREAD per set instead of one WAVE per set
+            {                 // integer partial sums of this tile; combine_partials_kernel adds the tiles up and
+                              // finalises in f64 with one THREAD per set instead of one lane per flush
                 long long *q = A.partials + vset * 9;
                 q[0] = n_up; q[1] = n_lo; q[2] = n_miss; q[3] = (long long)sk; q[4] = (long long)sk2;
                 q[5] = (long long)sk_up; q[6] = (long long)sk2_up; q[7] = sz; q[8] = szz;
@@ -772,13 +769,18 @@ static int resident_waves(K kernel, size_t lds_bytes)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = 8;
     if (per_cu > 32) per_cu = 32;
-    // The occupancy query over-counts on gfx950: measured with the in-kernel wave-lifetime counters, a wave64 kernel with
-    // 65..80 VGPRs keeps 6 waves per SIMD resident, not 512 / 72 = 7 -- registers are handed out in blocks of 16.  A grid
-    // larger than what is resident only adds waves that start when the first ones exit (-6 % on mid-size launches).
+    // The occupancy query over-counts on gfx950: it allows 7-8 waves per SIMD for these kernels, but the in-kernel
+    // wave-lifetime counters show 6.  The limiter is the SGPR file: 800 per SIMD, and a wave is charged its SGPRs + 22
+    // (VCC etc. + the trap handler's 16) rounded up to 16 -- measured with a residency micro-kernel: highest SGPR s70 ->
+    // 8 waves, s86 -> 7, s94 and up -> 6.  Every sim_kernel instantiation uses 100+ SGPRs (the launch arguments and the
+    // wave-uniform bookkeeping live there), so 6 it is; capping them at 88 to get a 7th wave was measured neutral
+    // (spill traffic), at 72 negative.  A grid larger than what is resident only adds waves that start when the first
+    // ones exit and find the queue empty.  VGPRs (61-78) and LDS (allocated in 1280-byte granules: 5.3 KB -> 6.4 KB
+    // -> 25 per CU) allow at least as many.
+    if (per_cu > 24) per_cu = 24;
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) == hipSuccess && fa.numRegs > 0) {
-        int per_simd = 512 / (((fa.numRegs + 15) / 16) * 16);
-        if (per_simd > 8) per_simd = 8;
+        int per_simd = 512 / (((fa.numRegs + 7) / 8) * 8);
         if (per_simd < 1) per_simd = 1;
         if (per_cu > 4 * per_simd) per_cu = 4 * per_simd;
     }
@@ -893,7 +895,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // geometry: ring slots.  Sets are flushed in order, so a straggler trial in the oldest set must not stall the lanes
     // that are ahead of it: the wave's window (ring x tile) should span >= ~480 trials (7-8 per lane; measured: 400 costs
     // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 6 waves per SIMD resident
-    // (24 single-wave workgroups per CU: <= 160 KB / 24 each) -- below that the VALU pipe starves (-6 % at 5, -17 % at 4),
+    // (24 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 6400 B each) -- below that the
+    // VALU pipe starves (-6 % at 5, -17 % at 4),
     // which costs more than a short window.
     const auto lds_of = [&](int r) { return 80 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
     int ring = g_tuning.ring;
@@ -901,7 +904,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);
         if (ring < 4) ring = 4;
         if (ring > 64) ring = 64;
-        while (ring > 2 && lds_of(ring) > 6656) ring >>= 1;
+        while (ring > 2 && lds_of(ring) > 6400) ring >>= 1;     // 5 LDS granules of 1280 B: 25 workgroups per CU
     }
     if (ring < 2) ring = 2;
     if (ring > 64) ring = 64;
@@ -926,16 +929,16 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // ---- per-launch device scratch -------------------------------------------------------------------------------
     //  * one queue (chunk counter + exit counter, self-resetting), from a per-device pool of 4096 handed out round-robin;
     //  * the longest-first order (64 counters + B indices + the gathered parameter rows) for launches of >= 2048 sets;
-    //  * integer partial sums [vB, 9] when sets are split into tiles, and for launches of >= 2048 sets (whose f64
-    //    finalisation is then done by combine_partials_kernel at full lane occupancy instead of by lane 0 of every flush:
-    //    same function, same integers in, same bits out).
+    //  * integer partial sums [vB, 9] whenever summaries are requested: the f64 finalisation is done by
+    //    combine_partials_kernel with one thread per set instead of by lane 0 of every flush (which also kept ~8 more
+    //    VGPRs alive in the simulator kernel).
     // Scratch of up to 1 MB comes from a persistent 64 MB per-device ring, also round-robin (a region is reused after
     // >= 64 later launches; launches on one stream are ordered anyway), so that the small, fixed-shape launches of a
     // training loop hold no allocation and can be captured in a hipGraph.  Larger scratch is stream-ordered
     // (hipMallocAsync / hipFreeAsync) and such a launch is refused while the stream is capturing: graphs that held
     // hipMallocAsync nodes lost the ordering between the queue-word memset and the kernel on replay (ROCm 7.2).
     const bool want_order = B >= 2048 && g_tuning.no_order == 0;
-    const bool want_partials = (tiles > 1 || B >= 2048) && out_summary;
+    const bool want_partials = out_summary != nullptr;
     const size_t order_bytes = want_order ? (((size_t)(64 + B + B * P) * sizeof(int) + 255) & ~(size_t)255) : 0;
     const size_t partial_bytes = want_partials ? (size_t)vB * 9 * sizeof(long long) : 0;
     const size_t scratch_bytes = order_bytes + partial_bytes;
