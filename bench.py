@@ -293,7 +293,7 @@ def main():
                                          "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             res["occupancy"] = {"resident_waves_per_simd": d[4] / (4.0 * cus), "hardware_max": 8,
-                                "limit": "VGPRs (65-80 per lane -> 6 wave64 per SIMD)", "grid_waves": int(d[4]),
+                                "limit": "SGPR file (~106 SGPRs per wave -> 6 wave64 per SIMD; DESIGN.md 5.1)", "grid_waves": int(d[4]),
                                 "note": "persistent grid = resident waves; PMC SQ_WAVE_CYCLES agrees (profiles/r1_summary.md)"}
         if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
