@@ -84,6 +84,17 @@ struct SimArgs {
     int max_blocks;           // ... or after this many Philox blocks (4 steps each)
 };
 
+// The launch arguments as they sit in the kernarg segment (constant address space: scalar loads).  The rarely executed
+// parts of the kernel (opening a tile, flushing a set) read their arguments through this pointer at the point of use,
+// behind a compiler barrier, instead of keeping ~30 SGPRs live through the step loop: SGPRs, not VGPRs, limit these
+// kernels' residency.
+typedef const __attribute__((address_space(4))) SimArgs *ArgsPtr;
+__device__ __forceinline__ ArgsPtr fresh_args(ArgsPtr p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // auxiliary normal `a` of (set, trial): stream 1.  One Philox block serves normals 4b..4b+3; each Box-Muller pair is
 // evaluated only when one of its two normals is asked for (the common case needs a = 0 and a = 1: one pair).
 template <bool FAST>
@@ -162,26 +173,26 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
 // wrote column 1 straight to HBM when each trial retired and keep only integer sums of it in LDS (zsum), so that their
 // LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
 template <int MODEL, bool FAST>
-__device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long vset, const float *pp,
+__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, const float *pp,
                                           const uint32_t *res, const long long *zsum, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
-    const int N = A.n_trials;
-    const int TPS = A.tiles_per_set;
+    const int N = Ap->n_trials;
+    const int TPS = Ap->tiles_per_set;
     const long long set_in_call = TPS == 1 ? vset : vset / TPS;
     const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
-    const int n_here = (A.n_total - t0) < N ? (A.n_total - t0) : N;           // the last tile may be padded
+    const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
     const float tau = pp[T::TAU];
     int n_up = 0, n_lo = 0, n_miss = 0;
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
     long long sz = 0, szz = 0;
-    float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set_in_call * A.n_total + t0 : nullptr;
+    float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
     for (int j = lane; j < n_here; j += WAVE) {
         const uint32_t v = res[j];
-        const uint32_t k = v & 0x3fffffffu;                  // time in units of A.tscale (step index, or 1/256 step)
+        const uint32_t k = v & 0x3fffffffu;                  // time in units of Ap->tscale (step index, or 1/256 step)
         const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
         const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
-        const float rt = __builtin_fmaf((float)k, A.tscale, tau);
+        const float rt = __builtin_fmaf((float)k, Ap->tscale, tau);
         float2 o;
         if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
         else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
@@ -191,7 +202,7 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
             if constexpr (T::HAS_Z) reinterpret_cast<float *>(out)[2 * j] = o.x;     // column 1 is already in place
             else out[j] = o;
         }
-        if (A.out_summary) {
+        if (Ap->out_summary) {
             const unsigned long long kk = (unsigned long long)k * k;
             if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
             else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
@@ -201,24 +212,24 @@ __device__ __forceinline__ void flush_set(const SimArgs &A, int lane, long long 
     if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
         if (lane == 0) { sz = zsum[0]; szz = zsum[1]; }
     }
-    if (A.out_summary) {
+    if (Ap->out_summary) {
         n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
         sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
         if (lane == 0) {
             {                 // integer partial sums of this tile; combine_partials_kernel adds the tiles up and
                               // finalises in f64 with one THREAD per set instead of one lane per flush
-                long long *q = A.partials + vset * 9;
+                long long *q = Ap->partials + vset * 9;
                 q[0] = n_up; q[1] = n_lo; q[2] = n_miss; q[3] = (long long)sk; q[4] = (long long)sk2;
                 q[5] = (long long)sk_up; q[6] = (long long)sk2_up; q[7] = sz; q[8] = szz;
             }
         }
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-        if (A.out_ext && lane == 0 && t0 == 0) {
-            const unsigned long long gset = A.set_offset + (unsigned long long)set_in_call;
+        if (Ap->out_ext && lane == 0 && t0 == 0) {
+            const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
             AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
-            const float loc = (A.ext_mode == 0) ? pp[1] : 1.0f;
-            A.out_ext[set_in_call] = __builtin_fmaf(A.ext_sigma, aux.normal(0), loc);
+            const float loc = (Ap->ext_mode == 0) ? pp[1] : 1.0f;
+            Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
         }
     }
 }
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     constexpr int P = T::P;
     extern __shared__ uint32_t lds_raw[];
 
+    const ArgsPtr Ak = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x;
     const int N = A.n_trials;
     const int ring = A.ring, ring_mask = A.ring - 1;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t off = (uint32_t)(size_t)lds_raw;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
     }
-    uint32_t *dv = lds_raw + 20;                                       // [ring][DV], 16-byte aligned
+    uint32_t *dv = lds_raw + 24;                                       // [ring][DV], 16-byte aligned (bytes [80, 96): debug stamps)
     float *lp = reinterpret_cast<float *>(dv + ring * DV);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
@@ -292,71 +304,74 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int tile_open = 0;       // tiles whose parameters are staged in LDS
     int flushed = 0;         // tiles already flushed
     int next_tile = 0, next_trial = 0;            // next unassigned trial of the wave's stream
-    unsigned long long retired = 0;               // trials retired so far
-    unsigned long long gate = (unsigned long long)N;   // the oldest tile cannot be complete before retired >= gate
+    // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
+    unsigned int retired = 0;                     // trials retired so far
+    unsigned int gate = (unsigned int)N;          // the oldest tile cannot be complete before retired >= gate
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left
     bool more = true;                             // chunks may remain in the global queue
-    unsigned long long dbg_blocks = 0, dbg_refills = 0, dbg_t0 = 0, dbg_r0 = 0;
-    if (A.dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned int dbg_blocks = 0, dbg_refills = 0;          // per-wave, < 2^32
+    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // start clocks, parked in LDS
+    if (A.dbg && lane == 0) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
 
     // open tiles (fetch chunk ids from the global queue, stage the parameter row of each new tile) while ring slots
     // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
     // sets its neighbours could be working on (with an eager ring fill, 10,000 sets ended up on 2,500 of the
     // 7,168 waves: 6x slower for mid-size batches)
     auto open_tiles = [&]() {
-        while (tile_open < flushed + ring && tile_open <= next_tile + A.open_ahead) {
+        const ArgsPtr R = fresh_args(Ak);
+        while (tile_open < flushed + ring && tile_open <= next_tile + R->open_ahead) {
             if (chunk_left == 0) {
                 if (!more) break;
                 unsigned int c = 0;
-                if (lane == 0) c = atomicAdd(A.chunk_counter, 1u);
+                if (lane == 0) c = atomicAdd(R->chunk_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= (unsigned int)A.n_chunks) { more = false; break; }
-                chunk_set = (int)c * A.sets_per_chunk;
-                const long long left = A.B - (long long)chunk_set;
-                chunk_left = (int)(left < A.sets_per_chunk ? left : A.sets_per_chunk);
+                if (c >= (unsigned int)R->n_chunks) { more = false; break; }
+                chunk_set = (int)c * R->sets_per_chunk;
+                const long long left = R->B - (long long)chunk_set;
+                chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
             }
             const int slot = tile_open & ring_mask;
             // queue position -> virtual set (set * tiles_per_set + tile), through the longest-first order if present
             int vset = chunk_set, prow = chunk_set;
-            if (A.tiles_per_set != 1) prow = chunk_set / A.tiles_per_set;
-            const float *row = A.params + (long long)prow * P;
-            if (A.order) {
-                const int qt = chunk_set - prow * A.tiles_per_set;      // tile within the set (0 when not tiled)
-                row = A.params_q + (long long)prow * P;                 // rows are stored in queue order: sequential
-                vset = A.order[prow] * A.tiles_per_set + qt;
+            if (R->tiles_per_set != 1) prow = chunk_set / R->tiles_per_set;
+            const float *row = R->params + (long long)prow * P;
+            if (R->order) {
+                const int qt = chunk_set - prow * R->tiles_per_set;      // tile within the set (0 when not tiled)
+                row = R->params_q + (long long)prow * P;                 // rows are stored in queue order: sequential
+                vset = R->order[prow] * R->tiles_per_set + qt;
             }
             if (lane < P) lp[slot * P + lane] = row[lane];
             if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; zsum[2 * slot] = 0; zsum[2 * slot + 1] = 0; }
             {
                 // everything here is wave-uniform (row is a uniform pointer: scalar loads)
-                const int sic = A.tiles_per_set == 1 ? vset : vset / A.tiles_per_set;
-                const unsigned long long gset = A.set_offset + (unsigned long long)sic;
+                const int sic = R->tiles_per_set == 1 ? vset : vset / R->tiles_per_set;
+                const unsigned long long gset = R->set_offset + (unsigned long long)sic;
                 const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
                 PathSet ps;
-                ps.init(s_lo, s_hi, A.k0, A.k1);              // stream 0: no tag bits in c2
+                ps.init(s_lo, s_hi, R->k0, R->k1);              // stream 0: no tag bits in c2
                 float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 0.0f;       // the per-SET ones of the model
                 if constexpr (MODEL == NDDM_BASIC_DDM_DC) { drift = row[0]; a = row[1]; beta = row[2]; sig_c = row[4]; }
                 else if constexpr (MODEL == NDDM_SINGLE_TRIAL) { drift = row[0]; beta = row[2]; sig_c = row[5]; }
                 else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) { drift = row[0]; a = row[1]; beta = row[2]; }
                 else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { a = row[1]; beta = row[2]; sig_c = row[5]; }
                 else { drift = row[0]; beta = row[1]; sig_c = row[3]; }
-                const float inv_s = 1.0f / noise_unit<FAST>(A.sqrt_dt * sig_c);
+                const float inv_s = 1.0f / noise_unit<FAST>(R->sqrt_dt * sig_c);
                 const float hv = 0.5f * a;
                 if (lane == 0) {
                     uint32_t *d = dv + slot * DV;
-                    d[D_MU] = __float_as_uint((drift * A.dt) * inv_s);
+                    d[D_MU] = __float_as_uint((drift * R->dt) * inv_s);
                     d[D_INVS] = __float_as_uint(inv_s);
                     d[D_H] = __float_as_uint(hv * inv_s);
                     d[D_W0] = __float_as_uint((a * beta - hv) * inv_s);
                     d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
                     if constexpr (BRIDGE) {
                         PathSet pb;
-                        pb.init(s_lo, s_hi | 0x30000000u, A.k0, A.k1);
+                        pb.init(s_lo, s_hi | 0x30000000u, R->k0, R->k1);
                         d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
                     }
                     d[D_SETLO] = s_lo;
                     d[D_C3] = s_hi;
-                    d[D_TBASE] = (uint32_t)((vset - sic * A.tiles_per_set) * N);
+                    d[D_TBASE] = (uint32_t)((vset - sic * R->tiles_per_set) * N);
                     d[D_SIC] = (uint32_t)sic;
                 }
             }
@@ -398,20 +413,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             atomicAdd(&cnt[slot], 1);
         }
         has_m &= ~fin_mask0;
-        retired += (unsigned long long)__popcll(fin_mask0);
+        retired += (unsigned int)__popcll(fin_mask0);
         // ------------------------------------------------------------ flush complete sets, in order (rare path:
         // only entered when enough trials have retired for the oldest tile to possibly be complete)
-        if (retired >= gate) {
+        if ((int)(retired - gate) >= 0) {
             __syncthreads();
             while (flushed < tile_open) {
                 const int slot = flushed & ring_mask;
                 const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
-                flush_set<MODEL, FAST>(A, lane, (long long)set_in_call, lp + slot * P, res + (size_t)slot * N,
+                flush_set<MODEL, FAST>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P, res + (size_t)slot * N,
                                        zsum + 2 * slot, kbase);
                 flushed++;
-                gate += (unsigned long long)N;
+                gate += (unsigned int)N;
             }
             __syncthreads();
             open_tiles();
@@ -558,10 +573,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         if (left == gridDim.x - 1u) { atomicExch(A.chunk_counter, 0u); atomicExch(A.chunk_counter + 1, 0u); }
     }
     if (A.dbg && lane == 0) {
-        atomicAdd(A.dbg + 0, dbg_blocks);
-        atomicAdd(A.dbg + 1, dbg_refills);
-        atomicAdd(A.dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
-        atomicAdd(A.dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0));
+        atomicAdd(A.dbg + 0, (unsigned long long)dbg_blocks);
+        atomicAdd(A.dbg + 1, (unsigned long long)dbg_refills);
+        atomicAdd(A.dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
+        atomicAdd(A.dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
         atomicAdd(A.dbg + 4, 1ull);
     }
 }
@@ -898,7 +913,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // (24 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 6400 B each) -- below that the
     // VALU pipe starves (-6 % at 5, -17 % at 4),
     // which costs more than a short window.
-    const auto lds_of = [&](int r) { return 80 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
+    const auto lds_of = [&](int r) { return 96 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
     int ring = g_tuning.ring;
     if (!ring) {
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);
