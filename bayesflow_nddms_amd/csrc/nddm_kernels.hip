@@ -80,6 +80,7 @@ struct SimArgs {
     float ext_sigma;
     int ext_mode;
     unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
+    int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
     int max_blocks;           // ... or after this many Philox blocks (4 steps each)
 };
@@ -174,7 +175,7 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
 // LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
 template <int MODEL, bool FAST>
 __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, const float *pp,
-                                          const uint32_t *res, const long long *zsum, uint32_t kbase)
+                                          const void *res, const long long *zsum, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
     const int N = Ap->n_trials;
@@ -188,9 +189,14 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     long long sz = 0, szz = 0;
     float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
     for (int j = lane; j < n_here; j += WAVE) {
-        const uint32_t v = res[j];
-        const uint32_t k = v & 0x3fffffffu;                  // time in units of Ap->tscale (step index, or 1/256 step)
-        const uint32_t code = v >> 30;                       // 0 timeout, 1 upper, 2 lower, 3 invalid trial
+        uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
+        if (Ap->res16) {                                     // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
+            const uint32_t v = static_cast<const uint16_t *>(res)[j];
+            k = v & 0x3fffu; code = v >> 14;
+        } else {
+            const uint32_t v = static_cast<const uint32_t *>(res)[j];
+            k = v & 0x3fffffffu; code = v >> 30;
+        }
         const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
         const float rt = __builtin_fmaf((float)k, Ap->tscale, tau);
         float2 o;
@@ -284,7 +290,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
     long long *zsum = reinterpret_cast<long long *>(cnt + ring);      // [ring][2]: fixed-point sums of z and z^2
+    // staged results: one 32-bit word per trial, or one 16-bit word when the step cap allows (halves the LDS footprint,
+    // which is what lets a 7th wave per SIMD stay resident at 300 trials per set)
     uint32_t *res = reinterpret_cast<uint32_t *>(zsum + 2 * ring);
+    uint16_t *res_h = reinterpret_cast<uint16_t *>(res);
 
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
-            res[(size_t)slot * N + ltrial] = tfix | (code << 30);
+            if (fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
+            else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
             if constexpr (T::HAS_Z) {
                 if (trial < (uint32_t)A.n_total) {           // not a padding trial of a split set's last tile
                     if (A.out_trials) {
@@ -423,7 +433,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
-                flush_set<MODEL, FAST>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P, res + (size_t)slot * N,
+                flush_set<MODEL, FAST>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
+                                       fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
+                                                             : static_cast<const void *>(res + (size_t)slot * N),
                                        zsum + 2 * slot, kbase);
                 flushed++;
                 gate += (unsigned int)N;
@@ -784,21 +796,26 @@ static int resident_waves(K kernel, size_t lds_bytes)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = 8;
     if (per_cu > 32) per_cu = 32;
-    // The occupancy query over-counts on gfx950: it allows 7-8 waves per SIMD for these kernels, but the in-kernel
-    // wave-lifetime counters show 6.  The limiter is the SGPR file: 800 per SIMD, and a wave is charged its SGPRs + 22
-    // (VCC etc. + the trap handler's 16) rounded up to 16 -- measured with a residency micro-kernel: highest SGPR s70 ->
-    // 8 waves, s86 -> 7, s94 and up -> 6.  Every sim_kernel instantiation uses 100+ SGPRs (the launch arguments and the
-    // wave-uniform bookkeeping live there), so 6 it is; capping them at 88 to get a 7th wave was measured neutral
-    // (spill traffic), at 72 negative.  A grid larger than what is resident only adds waves that start when the first
-    // ones exit and find the queue empty.  VGPRs (61-78) and LDS (allocated in 1280-byte granules: 5.3 KB -> 6.4 KB
-    // -> 25 per CU) allow at least as many.
-    if (per_cu > 24) per_cu = 24;
+    // The occupancy query over-counts on gfx950, for two reasons found with a residency micro-kernel and confirmed by
+    // the in-kernel wave-lifetime counters:
+    //  * SGPRs: 800 per SIMD, and a wave is charged its SGPRs + 22 (VCC etc. + the trap handler's 16) rounded up to 16:
+    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  The fast basic / alpha_not_scaled kernels use
+    //    85-90 (7 waves), the single-trial family ~100 (6); the runtime does not report SGPR counts, so 7 is assumed --
+    //    a grid slightly larger than what is resident only adds waves that start late and find the queue empty.
+    //  * LDS is allocated in 1280-byte granules (5.3 KB -> 6.4 KB -> 25 workgroups per CU, not 30).
+    if (per_cu > 28) per_cu = 28;
+    {
+        const size_t granules = (lds_bytes + 1279) / 1280;
+        const int by_lds = granules ? (int)((160u * 1024u) / (granules * 1280)) : 32;
+        if (per_cu > by_lds) per_cu = by_lds;
+    }
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) == hipSuccess && fa.numRegs > 0) {
         int per_simd = 512 / (((fa.numRegs + 7) / 8) * 8);
         if (per_simd < 1) per_simd = 1;
         if (per_cu > 4 * per_simd) per_cu = 4 * per_simd;
     }
+    if (per_cu < 1) per_cu = 1;
     return cus * per_cu;
 }
 
@@ -867,7 +884,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
 
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
-    const size_t per_trial = 4;   // packed (time | choice) word; z columns go straight to HBM
+    // staged result per trial: a packed (time | choice) word of 4 bytes, or 2 when the step index fits 14 bits (no bridge:
+    // its time unit is 1/256 step); z columns go straight to HBM
+    const bool res16 = (flags & NDDM_BRIDGE) == 0 && max_steps < 16384;
+    const size_t per_trial = res16 ? 2 : 4;
     (void)has_z;
     // small and mid-size launches are bound by latency / by the slowest set (a set of 300 slow trials keeps one wave
     // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
@@ -909,17 +929,16 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     // geometry: ring slots.  Sets are flushed in order, so a straggler trial in the oldest set must not stall the lanes
     // that are ahead of it: the wave's window (ring x tile) should span >= ~480 trials (7-8 per lane; measured: 400 costs
-    // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 6 waves per SIMD resident
-    // (24 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 6400 B each) -- below that the
-    // VALU pipe starves (-6 % at 5, -17 % at 4),
-    // which costs more than a short window.
+    // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 7 waves per SIMD resident
+    // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
+    // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
     const auto lds_of = [&](int r) { return 96 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
     int ring = g_tuning.ring;
     if (!ring) {
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);
         if (ring < 4) ring = 4;
         if (ring > 64) ring = 64;
-        while (ring > 2 && lds_of(ring) > 6400) ring >>= 1;     // 5 LDS granules of 1280 B: 25 workgroups per CU
+        while (ring > 2 && lds_of(ring) > 5120) ring >>= 1;     // 4 LDS granules of 1280 B: 32 workgroups per CU fit
     }
     if (ring < 2) ring = 2;
     if (ring > 64) ring = 64;
@@ -933,6 +952,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // refill when this many lanes hold a finished trial: 8, or 16 where a refill is dearer relative to the stepping
     // between two refills (short trials; models whose hand-out draws per-trial auxiliary normals) -- measured +2..5 %
     const bool aux_handout = model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
+    A.res16 = res16 ? 1 : 0;
     A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
     A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
