@@ -284,17 +284,23 @@ def main():
             from bayesflow_nddms_amd import _lib
             dbg = torch.zeros(8, dtype=torch.int64, device=dev)
             _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
             step(a.warmup + a.steps - 1)
+            d1.record()
             torch.cuda.synchronize()
+            dbg_ms = d0.elapsed_time(d1)
             _lib.lib().nddm_set_debug_counters(None)
             d = dbg.cpu().numpy().astype(np.float64)
             res["roofline_valu"].update({"executed_lane_steps_per_launch": d[0] * 256.0,
                                          "lane_efficiency": em_steps / (d[0] * 256.0),
                                          "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            res["occupancy"] = {"resident_waves_per_simd": d[4] / (4.0 * cus), "hardware_max": 8,
-                                "limit": "SGPR file (~106 SGPRs per wave -> 6 wave64 per SIMD; DESIGN.md 5.1)", "grid_waves": int(d[4]),
-                                "note": "persistent grid = resident waves; PMC SQ_WAVE_CYCLES agrees (profiles/r1_summary.md)"}
+            # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
+            resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / (4.0 * cus)
+            res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": int(d[4]),
+                                "limit": "SGPR file (85-90 SGPRs per wave -> 7 wave64 per SIMD; DESIGN.md 5.1)",
+                                "note": "from in-kernel wave lifetimes; PMC SQ_WAVE_CYCLES agrees (profiles/r1_summary.md)"}
         if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
         if world == 1 and not a.no_cpu_baseline and a.model == "basic":
