@@ -913,13 +913,16 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (spc > 64) spc = 64;
         while (spc > 1 && vB / spc < 32 * 7168) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
         // ... but the queue is ONE atomic word: same-address atomics retire at ~85 M/s on MI355X (measured: 1M chunks
-        // take 11.6 ms whatever the work), so short-trial workloads (dt = .01, few trials per set) must not pull more
-        // than ~40 M chunks/s.  Expected duration from the stepping alone: E[steps] ~ min(cap, 0.25 / dt) under the
-        // reference priors, 265 SIMD cycles per 256 lane-steps.  Keep at least ~8 chunks per wave for the tail.
+        // take 11.6 ms whatever the work; contention already costs 15 % at 55 M/s), so short-trial workloads (dt = .01,
+        // few trials per set) must pull less often: at most ~40 M chunks/s over the shortest time the launch can take --
+        // its stepping (E[steps] ~ min(cap, 0.25 / dt) under the reference priors, 265 SIMD cycles per 256 lane-steps)
+        // plus one trial that runs to the cap on a full SIMD -- and never fewer than ~8 chunks per wave.  Mid-size
+        // launches, whose tail is one chunk, stay below the limit with their fine chunks.
         double est_steps = 0.25 / (double)dt;
         if (est_steps > (double)max_steps) est_steps = (double)max_steps;
         if (est_steps < 1.0) est_steps = 1.0;
-        const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / (1024.0 * 2.4e9);
+        const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / (1024.0 * 2.4e9)
+                             + (double)max_steps * 0.25 * 265.0 * 7.0 / 2.4e9;
         double max_chunks = t_est * 4.0e7;
         if (max_chunks < 8.0 * 6144.0) max_chunks = 8.0 * 6144.0;
         if ((double)vB / spc > max_chunks) {
