@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     bool more = true;                             // chunks may remain in the global queue
     unsigned int dbg_blocks = 0, dbg_refills = 0;          // per-wave, < 2^32
     unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // start clocks, parked in LDS
-    if (A.dbg && lane == 0) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+    if (Ak->dbg && lane == 0) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
 
     // open tiles (fetch chunk ids from the global queue, stage the parameter row of each new tile) while ring slots
     // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const unsigned long long fin_mask0 = has_m & ~act_m;
         dbg_refills++;
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
+            const ArgsPtr Rz = fresh_args(Ak);      // (only the models with an external datum read it)
             const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
@@ -402,13 +403,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
             else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
             if constexpr (T::HAS_Z) {
-                if (trial < (uint32_t)A.n_total) {           // not a padding trial of a split set's last tile
-                    if (A.out_trials) {
+                if (trial < (uint32_t)Rz->n_total) {           // not a padding trial of a split set's last tile
+                    if (Rz->out_trials) {
                         const long long sic = (long long)dv[slot * DV + D_SIC];
-                        A.out_trials[(sic * A.n_total + trial) * 2 + 1] = zout;
+                        Rz->out_trials[(sic * Rz->n_total + trial) * 2 + 1] = zout;
                     }
                     if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                        if (A.out_summary) {
+                        if (Rz->out_summary) {
                             double zd = (double)zout;
                             zd = zd > 1.0e6 ? 1.0e6 : zd;
                             zd = zd < -1.0e6 ? -1.0e6 : zd;
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             while (next_trial >= N) { next_trial -= N; next_tile++; }
             has_m |= ok_mask;
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
+                const ArgsPtr H = fresh_args(Ak);
                 tile = tl;
                 ltrial = (uint32_t)tr;
                 const int slot = tl & ring_mask;
@@ -493,26 +495,26 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
                     zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
-                    const float inv_t = 1.0f / noise_unit<FAST>(A.sqrt_dt * sig_c);      // per-trial noise scale
+                    const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);      // per-trial noise scale
                     const float hv = 0.5f * pp[1];
-                    mu_dt = (pp[0] * A.dt) * inv_t;
+                    mu_dt = (pp[0] * H->dt) * inv_t;
                     h = hv * inv_t;
                     w = (pp[1] * pp[2] - hv) * inv_t;
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    mu_dt = (__builtin_fmaf(pp[4], aux.normal(0), pp[0]) * A.dt) * inv_s;
+                    mu_dt = (__builtin_fmaf(pp[4], aux.normal(0), pp[0]) * H->dt) * inv_s;
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
-                    const float a = trial < (uint32_t)A.n_total ? A.bounds[(long long)d2.w * A.n_total + trial] : 1.0f;   // padded trial of a last tile
+                    const float a = trial < (uint32_t)H->n_total ? H->bounds[(long long)d2.w * H->n_total + trial] : 1.0f;   // padded trial of a last tile
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                     const float hv = 0.5f * a;
                     h = invalid ? 0.0f : hv * inv_s;
                     w = (a * pp[1] - hv) * inv_s;
                 }
-                pc.init(d1.x, d1.y, d1.z, d1.w, trial, A.k0, A.k1);
+                pc.init(d1.x, d1.y, d1.z, d1.w, trial, H->k0, H->k1);
                 if constexpr (BRIDGE) {
                     const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 12);
-                    pcb.init(d3.x, d3.y, d3.z, d3.w, trial, A.k0, A.k1);
+                    pcb.init(d3.x, d3.y, d3.z, d3.w, trial, H->k0, H->k1);
                 }
                 k = 0;
                 jit = 0;
@@ -581,15 +583,17 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
     // per launch, and a captured launch is kernels only.
     if (lane == 0) {
-        const unsigned int left = atomicAdd(A.chunk_counter + 1, 1u);
-        if (left == gridDim.x - 1u) { atomicExch(A.chunk_counter, 0u); atomicExch(A.chunk_counter + 1, 0u); }
+        unsigned int *const q = fresh_args(Ak)->chunk_counter;
+        const unsigned int left = atomicAdd(q + 1, 1u);
+        if (left == gridDim.x - 1u) { atomicExch(q, 0u); atomicExch(q + 1, 0u); }
     }
-    if (A.dbg && lane == 0) {
-        atomicAdd(A.dbg + 0, (unsigned long long)dbg_blocks);
-        atomicAdd(A.dbg + 1, (unsigned long long)dbg_refills);
-        atomicAdd(A.dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
-        atomicAdd(A.dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
-        atomicAdd(A.dbg + 4, 1ull);
+    unsigned long long *const dbg = fresh_args(Ak)->dbg;
+    if (dbg && lane == 0) {
+        atomicAdd(dbg + 0, (unsigned long long)dbg_blocks);
+        atomicAdd(dbg + 1, (unsigned long long)dbg_refills);
+        atomicAdd(dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
+        atomicAdd(dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
+        atomicAdd(dbg + 4, 1ull);
     }
 }
 
@@ -799,9 +803,10 @@ static int resident_waves(K kernel, size_t lds_bytes)
     // The occupancy query over-counts on gfx950, for two reasons found with a residency micro-kernel and confirmed by
     // the in-kernel wave-lifetime counters:
     //  * SGPRs: 800 per SIMD, and a wave is charged its SGPRs + 22 (VCC etc. + the trap handler's 16) rounded up to 16:
-    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  The fast basic / alpha_not_scaled kernels use
-    //    85-90 (7 waves), the single-trial family ~100 (6); the runtime does not report SGPR counts, so 7 is assumed --
-    //    a grid slightly larger than what is resident only adds waves that start late and find the queue empty.
+    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  Every sim_kernel instantiation uses 76-86
+    //    SGPRs (7 waves) now that the rare paths read their launch arguments from the kernarg segment; the runtime
+    //    does not report SGPR counts, so 7 is assumed.  (Going on to 73 SGPRs for an 8th wave -- by also recomputing
+    //    the LDS layout in the refill path -- cost more in the refill than the wave brought.)
     //  * LDS is allocated in 1280-byte granules (5.3 KB -> 6.4 KB -> 25 workgroups per CU, not 30).
     if (per_cu > 28) per_cu = 28;
     {
