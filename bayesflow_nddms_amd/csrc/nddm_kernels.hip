@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t off = (uint32_t)(size_t)lds_raw;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
     }
-    uint32_t *dv = lds_raw + 24;                                       // [ring][DV], 16-byte aligned (bytes [80, 96): debug stamps)
+    uint32_t *dv = lds_raw + 28;                                       // [ring][DV], 16-byte aligned (bytes [80, 112): debug stamps)
     float *lp = reinterpret_cast<float *>(dv + ring * DV);
     int *slot_set = reinterpret_cast<int *>(lp + ring * P);
     int *cnt = slot_set + ring;
@@ -316,11 +316,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
     unsigned int retired = 0;                     // trials retired so far
     unsigned int gate = (unsigned int)N;          // the oldest tile cannot be complete before retired >= gate
-    int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left
-    bool more = true;                             // chunks may remain in the global queue
-    unsigned int dbg_blocks = 0, dbg_refills = 0;          // per-wave, < 2^32
+    int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
+    unsigned int dbg_blocks = 0;                           // per-wave, < 2^32 (the refill count lives in LDS: dbg_stamp[2])
     unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // start clocks, parked in LDS
-    if (Ak->dbg && lane == 0) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+    if (lane == 0) { dbg_stamp[2] = 0; if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); } }
 
     // open tiles (fetch chunk ids from the global queue, stage the parameter row of each new tile) while ring slots
     // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
@@ -329,12 +328,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     auto open_tiles = [&]() {
         const ArgsPtr R = fresh_args(Ak);
         while (tile_open < flushed + ring && tile_open <= next_tile + R->open_ahead) {
-            if (chunk_left == 0) {
-                if (!more) break;
+            if (chunk_left <= 0) {
+                if (chunk_left < 0) break;
                 unsigned int c = 0;
                 if (lane == 0) c = atomicAdd(R->chunk_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= (unsigned int)R->n_chunks) { more = false; break; }
+                if (c >= (unsigned int)R->n_chunks) { chunk_left = -1; break; }
                 chunk_set = (int)c * R->sets_per_chunk;
                 const long long left = R->B - (long long)chunk_set;
                 chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
@@ -393,7 +392,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     while (true) {
         // ------------------------------------------------------------ retire finished trials
         const unsigned long long fin_mask0 = has_m & ~act_m;
-        dbg_refills++;
+        if (lane == 0) dbg_stamp[2]++;
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
             const ArgsPtr Rz = fresh_args(Ak);      // (only the models with an external datum read it)
             const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
@@ -445,9 +444,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             open_tiles();
             __syncthreads();
         }
-        if (flushed == tile_open && !more && chunk_left == 0) break;
+        if (flushed == tile_open && chunk_left < 0) break;
         // ------------------------------------------------------------ hand out new trials
-        if (tile_open <= next_tile + A.open_ahead && tile_open < flushed + ring && (more || chunk_left > 0)) {
+        if (tile_open <= next_tile + A.open_ahead && tile_open < flushed + ring && chunk_left >= 0) {
             open_tiles();
             __syncthreads();
         }
@@ -590,7 +589,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     unsigned long long *const dbg = fresh_args(Ak)->dbg;
     if (dbg && lane == 0) {
         atomicAdd(dbg + 0, (unsigned long long)dbg_blocks);
-        atomicAdd(dbg + 1, (unsigned long long)dbg_refills);
+        atomicAdd(dbg + 1, dbg_stamp[2]);
         atomicAdd(dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
         atomicAdd(dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
         atomicAdd(dbg + 4, 1ull);
@@ -803,12 +802,12 @@ static int resident_waves(K kernel, size_t lds_bytes)
     // The occupancy query over-counts on gfx950, for two reasons found with a residency micro-kernel and confirmed by
     // the in-kernel wave-lifetime counters:
     //  * SGPRs: 800 per SIMD, and a wave is charged its SGPRs + 22 (VCC etc. + the trap handler's 16) rounded up to 16:
-    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  Every sim_kernel instantiation uses 76-86
-    //    SGPRs (7 waves) now that the rare paths read their launch arguments from the kernarg segment; the runtime
-    //    does not report SGPR counts, so 7 is assumed.  (Going on to 73 SGPRs for an 8th wave -- by also recomputing
-    //    the LDS layout in the refill path -- cost more in the refill than the wave brought.)
+    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  The fast basic kernel uses 73 SGPRs (8 waves),
+    //    the other instantiations 75-83 (7), now that the rarer paths read their launch arguments from the kernarg
+    //    segment; the runtime does not report SGPR counts, so the hardware maximum of 8 is assumed -- a grid slightly
+    //    larger than what is resident only adds waves that start late and find the queue empty (measured neutral).
     //  * LDS is allocated in 1280-byte granules (5.3 KB -> 6.4 KB -> 25 workgroups per CU, not 30).
-    if (per_cu > 28) per_cu = 28;
+    if (per_cu > 32) per_cu = 32;
     {
         const size_t granules = (lds_bytes + 1279) / 1280;
         const int by_lds = granules ? (int)((160u * 1024u) / (granules * 1280)) : 32;
@@ -940,7 +939,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 7 waves per SIMD resident
     // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
     // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
-    const auto lds_of = [&](int r) { return 96 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
+    const auto lds_of = [&](int r) { return 112 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
     int ring = g_tuning.ring;
     if (!ring) {
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);

@@ -299,7 +299,7 @@ def main():
             # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
             resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / (4.0 * cus)
             res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": int(d[4]),
-                                "limit": "SGPR file (85-90 SGPRs per wave -> 7 wave64 per SIMD; DESIGN.md 5.1)",
+                                "limit": "SGPR file: 73 SGPRs per wave -> 8 wave64 per SIMD for this kernel, 75-83 -> 7 for the other models (DESIGN.md 5.1)",
                                 "note": "from in-kernel wave lifetimes; PMC SQ_WAVE_CYCLES agrees (profiles/r1_summary.md)"}
         if world == 1 and not a.no_ks and a.model == "basic":
             res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
