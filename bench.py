@@ -33,12 +33,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # mode, from the ISA of sim_kernel<basic, fast> x the measured per-instruction issue cost (tools/ubench_valu)
 VALU_MODEL = {
     "clock_ghz": 2.4, "simds": 1024,
-    # SIMD cycles one wave64 needs per Philox block (4 E-M steps x 64 lanes) when EVERY lane is useful: measured with
-    # tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes): 265 cycles per block at
-    # lane efficiency 0.984 (fast), 506 at 0.978 (exact) -- profiles/r1_summary.md.  The sum of the isolated
+    # SIMD cycles (at 2.4 GHz) one wave64 needs per Philox block (4 E-M steps x 64 lanes) when EVERY lane is useful:
+    # measured with tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes, same
+    # kernel, same residency): 2.48e12 E-M steps/s at lane efficiency 0.981 = 2.53e12 with every lane useful = 249 cycles
+    # per block (fast); 1.231e12 at 0.979 = 500 cycles (exact) -- profiles/r1_summary.md.  The sum of the isolated
     # per-instruction issue costs of the loop (tools/isa_mix.py x profiles/r1_ubench_valu.txt) is 274 / 595: the real
-    # loop issues slightly better than that sum, so the measured figure is the tighter ceiling.
-    "cycles_per_block_fast": 261.0, "cycles_per_block_exact": 495.0,
+    # loop issues better than that sum, so the measured figure is the tighter ceiling.
+    "cycles_per_block_fast": 249.0, "cycles_per_block_exact": 500.0,
     "sum_of_issue_costs_fast": 274.0, "sum_of_issue_costs_exact": 595.0,
 }
 
