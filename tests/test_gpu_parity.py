@@ -350,3 +350,13 @@ def test_large_launch_is_refused_under_capture():
     torch.cuda.synchronize()
     r2 = engine.simulate(engine.BASIC_DDM_DC, p, 100, dt=.01, max_steps=400, seed=1, set_offset=0, fast=True)
     assert torch.equal(r2["trials"], r["trials"])
+
+
+@pytest.mark.parametrize("model", ["basic", "single"])
+def test_wide_step_cap_uses_32bit_staging(model):
+    """Step caps of 2^14 and more cannot stage results as 16-bit words in LDS: the 32-bit staging path (otherwise only
+    taken with the bridge correction) must give the same bits as the oracle, timeouts at the large cap included."""
+    p, g, o = _run_both(model, B=48, N=130, dt=0.0002, max_steps=20000.0, seed=77)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+    assert o["k"].max() > 16383            # the case does exercise step indices beyond 14 bits
