@@ -47,6 +47,7 @@ EXPORTS = [
     "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
     "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_counters", "nddm_set_ordering",
+    "nddm_release_graph_memory",
 ]
 
 
@@ -54,16 +55,22 @@ def lib():
     """The loaded library; raises NddmLibraryError (an ImportError) when it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            try:                       # a fresh checkout: compile the HIP extension in-tree (hipcc, gfx950)
-                from .build import build_hip
+        from .build import build_hip, is_stale
+        build_error = None
+        if is_stale():                 # a fresh checkout or an edited kernel: compile in-tree (hipcc, gfx950)
+            try:
                 build_hip()
-            except Exception:          # noqa: BLE001 -- reported just below
-                pass
+            except Exception as e:     # noqa: BLE001 -- reported just below
+                build_error = e
         if not os.path.exists(SO_PATH):
             raise NddmLibraryError(
-                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+                f"{SO_PATH} is missing and could not be built ({build_error!r}): build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                "There is no CPU fallback.")
+        if build_error is not None:    # an older library exists but its sources changed and the rebuild failed
+            import warnings
+            warnings.warn(f"{SO_PATH} is older than its sources and rebuilding it failed ({build_error!r}); "
+                          "using the existing library", RuntimeWarning)
         # PyTorch (the plumbing for device memory / streams) bundles its own ROCm runtime: it must be the first HIP
         # runtime loaded into the process, otherwise torch and this library end up on different libamdhip64 copies
         import torch  # noqa: F401

@@ -34,10 +34,21 @@ def build_hip(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libnddm_hip.so; returns the path."""
     if not force and not is_stale():
         return SO_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", SO_PATH] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    # several ranks may import the package at once: one builds (to a temporary name, renamed into place), the others wait
+    with open(SO_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or is_stale():
+            tmp = f"{SO_PATH}.{os.getpid()}.tmp"
+            cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, SO_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return SO_PATH
 
 

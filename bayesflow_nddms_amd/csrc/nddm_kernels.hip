@@ -63,7 +63,7 @@ struct SimArgs {
     int n_trials;             // trials per TILE (a set is split into tiles_per_set tiles when it does not fit the LDS ring)
     int n_total;              // trials per set (row stride of out_trials / bounds)
     int tiles_per_set;
-    long long *partials;      // [B * tiles_per_set, 9] integer partial sums when tiles_per_set > 1, else null
+    unsigned long long *partials;   // [B * tiles_per_set, partial_words()] integer partial sums of the tiles (summaries requested), else null
     const int *order;         // [B] processing order of the sets (longest expected trials first) or null = as given
     const float *params_q;    // [B, P] parameter rows gathered into that order (sequential reads when a tile opens)
     int max_k;
@@ -80,7 +80,8 @@ struct SimArgs {
     float ext_sigma;
     int ext_mode;
     unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
-    int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384
+    int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384;
+                              // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
     int max_blocks;           // ... or after this many Philox blocks (4 steps each)
 };
@@ -96,29 +97,37 @@ __device__ __forceinline__ ArgsPtr fresh_args(ArgsPtr p)
     return p;
 }
 
-// auxiliary normal `a` of (set, trial): stream 1.  One Philox block serves normals 4b..4b+3; each Box-Muller pair is
-// evaluated only when one of its two normals is asked for (the common case needs a = 0 and a = 1: one pair).
+// auxiliary normal `a` of (set, trial): stream 1.  One Philox block serves normals 4b..4b+3.  Everything lives in named
+// registers (an array indexed by `a & 3` ends up in private scratch): the common hand-out asks for normals 0 and 1 --
+// one Box-Muller pair, first_pair() -- and only a rejected draw goes on to normal(a), which evaluates the pair that
+// holds normal `a` and selects its cosine or sine half.
 template <bool FAST>
 struct AuxStream {
     uint32_t trial, set_lo, c3, blk, kbase;
     u32x4 x;
-    float z[4];
-    bool have01, have23;
     __device__ __forceinline__ AuxStream(uint32_t kbase_, uint32_t set_lo_, uint32_t set_hi28, uint32_t trial_)
-        : trial(trial_), set_lo(set_lo_), c3(set_hi28 | 0x10000000u),
-          blk(0xffffffffu), kbase(kbase_), have01(false), have23(false) {}
+        : trial(trial_), set_lo(set_lo_), c3(set_hi28 | 0x10000000u), blk(0xffffffffu), kbase(kbase_) {}
+    __device__ __forceinline__ void block(uint32_t b)
+    {
+        if (b != blk) { x = philox4x32_10_lds(set_lo, trial, c3, b, kbase); blk = b; }
+    }
+    // normals 0 and 1
+    __device__ __forceinline__ void first_pair(float &z0, float &z1)
+    {
+        block(0u);
+        float r, cs, sn;
+        polar_pair<FAST>(x.x, x.y, r, cs, sn);
+        r *= noise_unit<FAST>(1.0f);
+        z0 = r * cs; z1 = r * sn;
+    }
     __device__ __forceinline__ float normal(uint32_t a)
     {
-        const uint32_t b = a >> 2;
-        if (b != blk) { x = philox4x32_10_lds(set_lo, trial, c3, b, kbase); blk = b; have01 = false; have23 = false; }
-        const uint32_t j = a & 3u;
-        const float sc = noise_unit<FAST>(1.0f);
-        if (j < 2u) {
-            if (!have01) { float r, cs, sn; polar_pair<FAST>(x.x, x.y, r, cs, sn); r *= sc; z[0] = r * cs; z[1] = r * sn; have01 = true; }
-            return j == 0u ? z[0] : z[1];
-        }
-        if (!have23) { float r, cs, sn; polar_pair<FAST>(x.z, x.w, r, cs, sn); r *= sc; z[2] = r * cs; z[3] = r * sn; have23 = true; }
-        return j == 2u ? z[2] : z[3];
+        block(a >> 2);
+        const bool second = (a & 2u) != 0u;
+        float r, cs, sn;
+        polar_pair<FAST>(second ? x.z : x.x, second ? x.w : x.y, r, cs, sn);
+        r *= noise_unit<FAST>(1.0f);
+        return r * ((a & 1u) ? sn : cs);
     }
 };
 
@@ -169,28 +178,58 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
     o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
 }
 
+// Sum of a 32-bit value over the 64 lanes, in the vector ALU's data-parallel-primitive lanes (no LDS traffic, six adds):
+// row_shr 1, 2, 4, 8 leave each 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it into the next rows; lanes
+// whose DPP source lies outside the row read the `old` operand, 0.  The wave's total ends up in lane 63.  Needs all 64
+// lanes active.  (The shuffle-based wave_sum above costs six ds_bpermute round trips per value.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    v = dpp_add<0x111, 0xf>(v);        // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);        // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);        // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);        // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Integer partial sums of one tile, as the simulator leaves them for combine_partials_kernel (which adds the tiles of a
+// set up and finalises the summary row in f64 with one THREAD per set instead of one lane per flush): PW 64-bit words
+//   [0] n_upper | n_lower << 21 | n_missing << 42   [1] sum k   [2] sum k^2   [3] sum k (upper)   [4] sum k^2 (upper)
+//   [5] sum z (fixed point, 2^-32)   [6] sum z^2 (2^-24)                     -- models with an external datum only
+__host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum ? 7 : 5; }
+
 // The fused epilogue of one tile (= one parameter set unless the set is split): coalesced (col0, col1) stores +
 // summary reduction.  vset = set * tiles_per_set + tile.  Models with an external datum (z1 / the explicit boundary)
-// wrote column 1 straight to HBM when each trial retired and keep only integer sums of it in LDS (zsum), so that their
-// LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
-template <int MODEL, bool FAST>
+// wrote column 1 straight to HBM when each trial was handed out and keep only integer sums of it in LDS (zsum), so that
+// their LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
+// SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
+// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
+// each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
+template <int MODEL, bool FAST, bool SMALL>
 __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, const float *pp,
                                           const void *res, const long long *zsum, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
+    constexpr bool ZSUM = MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT;
     const int N = Ap->n_trials;
     const int TPS = Ap->tiles_per_set;
     const long long set_in_call = TPS == 1 ? vset : vset / TPS;
     const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
     const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
     const float tau = pp[T::TAU];
-    int n_up = 0, n_lo = 0, n_miss = 0;
+    uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
+    int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
-    long long sz = 0, szz = 0;
     float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
     for (int j = lane; j < n_here; j += WAVE) {
         uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
-        if (Ap->res16) {                                     // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
+        if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
             const uint32_t v = static_cast<const uint16_t *>(res)[j];
             k = v & 0x3fffu; code = v >> 14;
         } else {
@@ -209,25 +248,36 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
             else out[j] = o;
         }
         if (Ap->out_summary) {
-            const unsigned long long kk = (unsigned long long)k * k;
-            if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
-            else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
-            else n_miss++;
+            if constexpr (SMALL) {
+                const uint32_t kk = k * k;                                           // < 2^28
+                const bool up = code == 1u, resp = up || code == 2u;
+                cnt3 += up ? 1u : (code == 2u ? (1u << 10) : (1u << 20));
+                sk32 += resp ? k : 0u; sk2_32 += resp ? kk : 0u;
+                sk_up32 += up ? k : 0u; sk2_up32 += up ? kk : 0u;
+            } else {
+                const unsigned long long kk = (unsigned long long)k * k;
+                if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
+                else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
+                else n_miss++;
+            }
         }
     }
-    if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-        if (lane == 0) { sz = zsum[0]; szz = zsum[1]; }
-    }
     if (Ap->out_summary) {
-        n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
-        sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
+        if constexpr (SMALL) {
+            cnt3 = wave_sum_dpp(cnt3);
+            n_up = (int)(cnt3 & 1023u); n_lo = (int)((cnt3 >> 10) & 1023u); n_miss = (int)(cnt3 >> 20);
+            sk = wave_sum_dpp(sk32); sk_up = wave_sum_dpp(sk_up32);
+            sk2 = ((unsigned long long)wave_sum_dpp(sk2_32 >> 16) << 16) + wave_sum_dpp(sk2_32 & 0xffffu);
+            sk2_up = ((unsigned long long)wave_sum_dpp(sk2_up32 >> 16) << 16) + wave_sum_dpp(sk2_up32 & 0xffffu);
+        } else {
+            n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
+            sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
+        }
         if (lane == 0) {
-            {                 // integer partial sums of this tile; combine_partials_kernel adds the tiles up and
-                              // finalises in f64 with one THREAD per set instead of one lane per flush
-                long long *q = Ap->partials + vset * 9;
-                q[0] = n_up; q[1] = n_lo; q[2] = n_miss; q[3] = (long long)sk; q[4] = (long long)sk2;
-                q[5] = (long long)sk_up; q[6] = (long long)sk2_up; q[7] = sz; q[8] = szz;
-            }
+            unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
+            q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
+            q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
+            if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
         }
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
@@ -297,7 +347,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
-    float w = 0.0f, h = 0.0f, mu_dt = 0.0f, zout = 0.0f;
+    float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
     int k = 0;
     uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
@@ -392,34 +442,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     while (true) {
         // ------------------------------------------------------------ retire finished trials
         const unsigned long long fin_mask0 = has_m & ~act_m;
-        if (lane == 0) dbg_stamp[2]++;
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned int *>(dbg_stamp + 2), 1u);      // refill phases (no-return LDS atomic)
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
-            const ArgsPtr Rz = fresh_args(Ak);      // (only the models with an external datum read it)
             const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
             if (fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
             else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
-            if constexpr (T::HAS_Z) {
-                if (trial < (uint32_t)Rz->n_total) {           // not a padding trial of a split set's last tile
-                    if (Rz->out_trials) {
-                        const long long sic = (long long)dv[slot * DV + D_SIC];
-                        Rz->out_trials[(sic * Rz->n_total + trial) * 2 + 1] = zout;
-                    }
-                    if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                        if (Rz->out_summary) {
-                            double zd = (double)zout;
-                            zd = zd > 1.0e6 ? 1.0e6 : zd;
-                            zd = zd < -1.0e6 ? -1.0e6 : zd;
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]),
-                                      (unsigned long long)(long long)(zd * 4294967296.0));
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]),
-                                      (unsigned long long)(long long)((zd * zd) * 16777216.0));
-                        }
-                    }
-                }
-            }
             atomicAdd(&cnt[slot], 1);
         }
         has_m &= ~fin_mask0;
@@ -433,10 +463,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
-                flush_set<MODEL, FAST>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
-                                       fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
-                                                             : static_cast<const void *>(res + (size_t)slot * N),
-                                       zsum + 2 * slot, kbase);
+                if (fresh_args(Ak)->res16 == 2)
+                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
+                                                 res_h + (size_t)slot * N, zsum + 2 * slot, kbase);
+                else
+                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
+                                                  fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
+                                                                        : static_cast<const void *>(res + (size_t)slot * N),
+                                                  zsum + 2 * slot, kbase);
                 flushed++;
                 gate += (unsigned int)N;
             }
@@ -476,24 +510,26 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 h = __uint_as_float(d0.z);
                 w = __uint_as_float(d0.w);
                 invalid = false;
-                zout = 0.0f;
+                [[maybe_unused]] float zout = 0.0f;
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    float a;
-                    uint32_t ai = 1;
-                    do { a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]); ai++; } while (!(a > 0.0f) && ai <= MAX_REJECT);
+                    float z0, z1;
+                    aux.first_pair(z0, z1);                 // normal 0: datum noise; normals 1, 2, ...: rejection draws
+                    float a = __builtin_fmaf(pp[4], z1, pp[1]);
+                    for (uint32_t ai = 2; !(a > 0.0f) && ai <= MAX_REJECT; ++ai) a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]);
                     if (!(a > 0.0f)) a = fabsf(a);
-                    zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * a);
+                    zout = __builtin_fmaf(pp[6], z0, pp[7] * a);
                     const float hv = 0.5f * a;
                     h = hv * inv_s;
                     w = (a * pp[2] - hv) * inv_s;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    float sig_c;
-                    uint32_t ai = 1;
-                    do { sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]); ai++; } while (!(sig_c > 0.0f) && ai <= MAX_REJECT);
+                    float z0, z1;
+                    aux.first_pair(z0, z1);
+                    float sig_c = __builtin_fmaf(pp[4], z1, pp[5]);
+                    for (uint32_t ai = 2; !(sig_c > 0.0f) && ai <= MAX_REJECT; ++ai) sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
-                    zout = __builtin_fmaf(pp[6], aux.normal(0), pp[7] * sig_c);
+                    zout = __builtin_fmaf(pp[6], z0, pp[7] * sig_c);
                     const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);      // per-trial noise scale
                     const float hv = 0.5f * pp[1];
                     mu_dt = (pp[0] * H->dt) * inv_t;
@@ -509,6 +545,25 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     const float hv = 0.5f * a;
                     h = invalid ? 0.0f : hv * inv_s;
                     w = (a * pp[1] - hv) * inv_s;
+                }
+                if constexpr (T::HAS_Z) {
+                    // column 1 (external datum / the boundary given) is known before the path is simulated: it goes
+                    // to HBM here, where the lanes of a hand-out hold CONSECUTIVE trials (one or two 128-byte lines per
+                    // store instruction instead of one line per lane at retire time), and its fixed-point sums to LDS
+                    if (trial < (uint32_t)H->n_total) {           // not a padding trial of a split set's last tile
+                        if (H->out_trials) H->out_trials[((long long)d2.w * H->n_total + trial) * 2 + 1] = zout;
+                        if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
+                            if (H->out_summary) {
+                                double zd = (double)zout;
+                                zd = zd > 1.0e6 ? 1.0e6 : zd;
+                                zd = zd < -1.0e6 ? -1.0e6 : zd;
+                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]),
+                                          (unsigned long long)(long long)(zd * 4294967296.0));
+                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]),
+                                          (unsigned long long)(long long)((zd * zd) * 16777216.0));
+                            }
+                        }
+                    }
                 }
                 pc.init(d1.x, d1.y, d1.z, d1.w, trial, H->k0, H->k1);
                 if constexpr (BRIDGE) {
@@ -628,11 +683,7 @@ __device__ __forceinline__ int duration_bucket(int model, const float *p, float 
     return ORDER_BUCKETS - 1 - b;                       // bucket 0 = slowest
 }
 
-// ws[0..31] histogram, ws[32..63] cursors (both zeroed before the launch)
-// zeroes the 64 counting-sort counters (a kernel, not hipMemsetAsync: memset NODES of a captured launch were observed not
-// to take effect on graph replay with ROCm 7.2)
-__global__ void order_zero_kernel(int *ws) { ws[threadIdx.x] = 0; }
-
+// ws[0..31] histogram, ws[32..63] cursors (both zeroed before the launch by zero_words_kernel)
 __global__ void order_hist_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws)
 {
     __shared__ int h[ORDER_BUCKETS];
@@ -674,20 +725,21 @@ __global__ void order_scatter_kernel(int model, const float *params, int P, int 
 // ------------------------------------------------------------------------------------------------
 // sets split into several tiles: add the tiles' integer partial sums up and finalise the summary row (one thread per
 // set; exact integer arithmetic, so the result equals the single-tile path bit for bit)
-__global__ void combine_partials_kernel(const long long *partials, const float *params, int P, int tau_idx,
+__global__ void combine_partials_kernel(const unsigned long long *partials, int pw, const float *params, int P, int tau_idx,
                                         long long B, int tiles_per_set, int n_total, float tscale, float *out_summary)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    long long a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long n_up = 0, n_lo = 0, n_miss = 0, sz = 0, szz = 0;
+    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
     for (int t = 0; t < tiles_per_set; ++t) {
-        const long long *q = partials + (b * tiles_per_set + t) * 9;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) a[i] += q[i];
+        const unsigned long long *q = partials + (b * tiles_per_set + t) * pw;       // layout: partial_words()
+        n_up += (long long)(q[0] & 0x1fffffull); n_lo += (long long)((q[0] >> 21) & 0x1fffffull); n_miss += (long long)(q[0] >> 42);
+        sk += q[1]; sk2 += q[2]; sk_up += q[3]; sk2_up += q[4];
+        if (pw > 5) { sz += (long long)q[5]; szz += (long long)q[6]; }
     }
-    finalize_summary(out_summary + b * NDDM_SUMMARY_K, (int)a[0], (int)a[1], (int)a[2], (unsigned long long)a[3],
-                     (unsigned long long)a[4], (unsigned long long)a[5], (unsigned long long)a[6], a[7], a[8], n_total,
-                     tscale, params[b * P + tau_idx]);
+    finalize_summary(out_summary + b * NDDM_SUMMARY_K, (int)n_up, (int)n_lo, (int)n_miss, sk, sk2, sk_up, sk2_up, sz, szz,
+                     n_total, tscale, params[b * P + tau_idx]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,30 +833,152 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// ---- process-wide state, all of it behind one mutex -------------------------------------------------------------------
+// Entry points are re-entrant: each call takes a SNAPSHOT of the developer knobs at entry and owns the device memory it is
+// handed (a LaunchSlot) until the work it enqueued has completed.
 struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order; };
+static std::mutex g_mu;
 static Tuning g_tuning = {0, 0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
+static unsigned long long *g_dbg = nullptr;       // nddm_set_debug_counters (profiling aid)
+
+constexpr int MAX_DEVICES = 64;
+struct DeviceInfo { int cus = 0; double clock_hz = 0.0; };
+static DeviceInfo g_dev[MAX_DEVICES];
+
+// compute units and clock of a device (cached): every sizing rule below is written in terms of these, not of MI355X's
+// 256 CUs / 1024 SIMDs / 2.4 GHz
+static bool device_info(int dev, DeviceInfo *out)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_dev[dev].cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        g_dev[dev].cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        g_dev[dev].clock_hz = prop.clockRate > 0 ? (double)prop.clockRate * 1e3 : 2.4e9;      // clockRate is in kHz
+    }
+    *out = g_dev[dev];
+    return true;
+}
+
+// Device memory a launch needs besides the caller's buffers: the work queue (chunk counter + exit counter; the kernel
+// leaves both zero) and up to SLOT_SCRATCH bytes of scratch (longest-first order, integer partial sums).  A slot belongs to
+// ONE launch at a time: it is handed out again only to the stream that used it last (launches on a stream are ordered)
+// or once the event recorded behind its last launch has completed -- never by launch count.  Launches under stream
+// capture do not use slots at all (see graph_alloc).
+constexpr size_t SLOT_QUEUE_BYTES = 256, SLOT_SCRATCH = 1u << 20;
+constexpr int MAX_SLOTS = 256;
+struct LaunchSlot {
+    char *base = nullptr;          // [SLOT_QUEUE_BYTES queue words | SLOT_SCRATCH scratch]
+    hipEvent_t done = nullptr;     // recorded on `stream` after the slot's last launch
+    hipStream_t stream = nullptr;
+    bool busy = false;             // between acquire and release (the enqueueing itself)
+    bool fresh = true;             // queue words not yet zeroed
+};
+static LaunchSlot *g_slots[MAX_DEVICES][MAX_SLOTS];
+static int g_nslots[MAX_DEVICES];
+
+// hipMalloc with the calling thread's capture mode relaxed: another thread (or this one) may be capturing a graph, and a
+// plain hipMalloc is refused then
+static hipError_t malloc_relaxed(void **p, size_t bytes)
+{
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    const hipError_t e = hipMalloc(p, bytes);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return e;
+}
+
+static LaunchSlot *acquire_slot(int dev, hipStream_t st, hipError_t *err)
+{
+    *err = hipSuccess;
+    std::lock_guard<std::mutex> lock(g_mu);
+    LaunchSlot *pick = nullptr;
+    // (a) the slot this stream used last: stream order makes it safe without a query.  hipStreamPerThread is one handle
+    //     for a different stream in every thread, so it never qualifies.
+    if (st != hipStreamPerThread)
+        for (int i = 0; i < g_nslots[dev] && !pick; ++i)
+            if (!g_slots[dev][i]->busy && g_slots[dev][i]->stream == st && !g_slots[dev][i]->fresh) pick = g_slots[dev][i];
+    // (b) any slot whose last launch has completed
+    for (int i = 0; i < g_nslots[dev] && !pick; ++i) {
+        LaunchSlot *s = g_slots[dev][i];
+        if (!s->busy && (s->fresh || hipEventQuery(s->done) == hipSuccess)) pick = s;
+    }
+    // (c) a new slot
+    if (!pick && g_nslots[dev] < MAX_SLOTS) {
+        LaunchSlot *s = new LaunchSlot();
+        hipError_t e = malloc_relaxed(reinterpret_cast<void **>(&s->base), SLOT_QUEUE_BYTES + SLOT_SCRATCH);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+        if (e != hipSuccess) { if (s->base) (void)hipFree(s->base); delete s; *err = e; return nullptr; }
+        if (g_nslots[dev] == 0) {
+            // keep freed stream-ordered blocks cached instead of handing them back to the OS at every synchronisation
+            hipMemPool_t mp;
+            if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess) {
+                uint64_t keep = UINT64_MAX;
+                (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+        }
+        g_slots[dev][g_nslots[dev]++] = s;
+        pick = s;
+    }
+    // (d) all MAX_SLOTS slots are in flight on other streams: queue behind the one used longest ago
+    if (!pick) {
+        for (int i = 0; i < g_nslots[dev] && !pick; ++i)
+            if (!g_slots[dev][i]->busy) pick = g_slots[dev][i];
+        if (!pick) { *err = hipErrorNotReady; return nullptr; }
+        const hipError_t e = hipStreamWaitEvent(st, pick->done, 0);
+        if (e != hipSuccess) { *err = e; return nullptr; }
+        // rotate it to the back so that the next starved launch waits on a different slot
+        int at = 0;
+        while (g_slots[dev][at] != pick) ++at;
+        for (int i = at; i + 1 < g_nslots[dev]; ++i) g_slots[dev][i] = g_slots[dev][i + 1];
+        g_slots[dev][g_nslots[dev] - 1] = pick;
+    }
+    pick->busy = true;
+    pick->stream = st;
+    return pick;
+}
+
+static void release_slot(LaunchSlot *s, hipStream_t st)
+{
+    (void)hipEventRecord(s->done, st);         // outside the lock: the slot is still marked busy
+    std::lock_guard<std::mutex> lock(g_mu);
+    s->fresh = false;
+    s->busy = false;
+}
+
+// Memory of launches captured into a hipGraph: the graph replays with the pointers it captured, at times the library
+// cannot see, so such a launch gets an allocation of its own that nothing else ever uses (queue words + ALL of its
+// scratch).  It lives until nddm_release_graph_memory().
+constexpr size_t GRAPH_SCRATCH_MAX = 64u << 20;
+struct GraphAlloc { void *p; GraphAlloc *next; };
+static GraphAlloc *g_graph_allocs[MAX_DEVICES];
+
+static char *graph_alloc(int dev, size_t bytes, hipError_t *err)
+{
+    void *p = nullptr;
+    *err = malloc_relaxed(&p, bytes);
+    if (*err != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_graph_allocs[dev] = new GraphAlloc{p, g_graph_allocs[dev]};
+    return static_cast<char *>(p);
+}
+
+// zeroes the 64 counting-sort counters / the queue words of a captured launch (a kernel, not hipMemsetAsync: memset NODES
+// of a captured launch were observed not to take effect on graph replay with ROCm 7.2)
+__global__ void zero_words_kernel(unsigned int *ws) { ws[threadIdx.x] = 0u; }
+
 // resident waves of a kernel instantiation on the current device (persistent grid size)
 template <typename K>
-static int resident_waves(K kernel, size_t lds_bytes)
+static int resident_waves(K kernel, size_t lds_bytes, int cus)
 {
-    int dev = 0, cus = 256, per_cu = 0;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        static thread_local int cached_dev = -1, cached_cus = 0;
-        if (cached_dev != dev) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { cached_cus = prop.multiProcessorCount; cached_dev = dev; }
-        }
-        if (cached_cus > 0) cus = cached_cus;
-    }
+    int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = 8;
-    if (per_cu > 32) per_cu = 32;
     // The occupancy query over-counts on gfx950, for two reasons found with a residency micro-kernel and confirmed by
     // the in-kernel wave-lifetime counters:
     //  * SGPRs: 800 per SIMD, and a wave is charged its SGPRs + 22 (VCC etc. + the trap handler's 16) rounded up to 16:
-    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6.  The fast basic kernel uses 73 SGPRs (8 waves),
-    //    the other instantiations 75-83 (7), now that the rarer paths read their launch arguments from the kernarg
-    //    segment; the runtime does not report SGPR counts, so the hardware maximum of 8 is assumed -- a grid slightly
+    //    highest SGPR s70 -> 8 waves per SIMD, s86 -> 7, s94 and up -> 6 (tools/resource_table.py lists every
+    //    instantiation); the runtime does not report SGPR counts, so the hardware maximum of 8 is assumed -- a grid slightly
     //    larger than what is resident only adds waves that start late and find the queue empty (measured neutral).
     //  * LDS is allocated in 1280-byte granules (5.3 KB -> 6.4 KB -> 25 workgroups per CU, not 30).
     if (per_cu > 32) per_cu = 32;
@@ -824,14 +998,13 @@ static int resident_waves(K kernel, size_t lds_bytes)
 }
 
 template <int MODEL, bool BRIDGE>
-static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, hipStream_t st)
+static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, int cus, int grid_override, hipStream_t st)
 {
     const bool cap4 = (A.max_k % 4) == 0;
     const dim3 block(WAVE);
-    const int over = g_tuning.grid_waves;   // 0 = as many waves as stay resident
 #define NDDM_LAUNCH(KERNEL)                                                                    \
     do {                                                                                       \
-        int waves = over > 0 ? over : resident_waves(KERNEL, lds_bytes);                       \
+        int waves = grid_override > 0 ? grid_override : resident_waves(KERNEL, lds_bytes, cus);\
         if (waves > n_chunks) waves = n_chunks;                                                \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
@@ -845,21 +1018,19 @@ static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chu
     return NDDM_OK;
 }
 
-static unsigned long long *g_dbg = nullptr;   // nddm_set_debug_counters (profiling aid)
-
 static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
                     int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
                     int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream)
 {
     g_err[0] = 0;
     int P;
-    bool has_z;
+    bool has_zsum;
     switch (model) {
-    case NDDM_BASIC_DDM_DC: P = 5; has_z = false; break;
-    case NDDM_SINGLE_TRIAL: P = 8; has_z = true; break;
-    case NDDM_SINGLE_TRIAL_ALT: P = 8; has_z = true; break;
-    case NDDM_ALPHA_NOT_SCALED: P = 6; has_z = false; break;
-    case NDDM_EXPLICIT_BOUNDARY: P = 4; has_z = true; break;
+    case NDDM_BASIC_DDM_DC: P = 5; has_zsum = false; break;
+    case NDDM_SINGLE_TRIAL: P = 8; has_zsum = true; break;
+    case NDDM_SINGLE_TRIAL_ALT: P = 8; has_zsum = true; break;
+    case NDDM_ALPHA_NOT_SCALED: P = 6; has_zsum = false; break;
+    case NDDM_EXPLICIT_BOUNDARY: P = 4; has_zsum = false; break;
     default: return fail(NDDM_ERR_PARAM, "unknown model%s");
     }
     if (B < 0 || n_trials <= 0 || max_steps < 0) return fail(NDDM_ERR_SHAPE, "B < 0, n_trials <= 0 or max_steps < 0%s");
@@ -876,6 +1047,23 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (!params) return fail(NDDM_ERR_NULL, "params is NULL%s");
     if (model == NDDM_EXPLICIT_BOUNDARY && !bounds) return fail(NDDM_ERR_NULL, "bounds is NULL%s");
     if (!out_trials && !out_summary && !out_ext) return fail(NDDM_ERR_NULL, "no output buffer given%s");
+    if (B * (((long long)n_trials + 511) / 512) >= (1ll << 31))
+        return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
+
+    // snapshot of the developer knobs, and the device this call runs on
+    Tuning tun;
+    unsigned long long *dbg;
+    { std::lock_guard<std::mutex> lock(g_mu); tun = g_tuning; dbg = g_dbg; }
+    int dev = 0;
+    {
+        const hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    }
+    DeviceInfo di;
+    if (!device_info(dev, &di)) return fail(NDDM_ERR_HIP, "hipGetDeviceProperties failed%s");
+    const int simds = 4 * di.cus;
+    const long long waves7 = 7ll * simds;      // a persistent grid at 7 waves per SIMD (7168 on MI355X): the sizing rules'
+    const long long waves6 = 6ll * simds;      // "resident waves"; the launch itself asks resident_waves() per kernel
 
     SimArgs A;
     memset(&A, 0, sizeof A);
@@ -884,7 +1072,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.tscale = bridge ? dt * 0.00390625f : dt;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
-    A.dbg = g_dbg;
+    A.dbg = dbg;
 
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
@@ -892,15 +1080,14 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // its time unit is 1/256 step); z columns go straight to HBM
     const bool res16 = (flags & NDDM_BRIDGE) == 0 && max_steps < 16384;
     const size_t per_trial = res16 ? 2 : 4;
-    (void)has_z;
     // small and mid-size launches are bound by latency / by the slowest set (a set of 300 slow trials keeps one wave
     // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
     // wave to balance; from ~30M trials on, one tile of up to 512 trials per set is the efficient shape
     const long long total_trials = B * (long long)n_trials;
     int tile_cap = 64;
-    while (tile_cap < 512 && (long long)tile_cap * 7168 * 8 < total_trials) tile_cap <<= 1;
-    int tiles = g_tuning.tile_trials > 0 ? (n_trials + g_tuning.tile_trials - 1) / g_tuning.tile_trials
-                                         : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
+    while (tile_cap < 512 && (long long)tile_cap * waves7 * 8 < total_trials) tile_cap <<= 1;
+    int tiles = tun.tile_trials > 0 ? (n_trials + tun.tile_trials - 1) / tun.tile_trials
+                                    : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
     const int tile_n = (n_trials + tiles - 1) / tiles;
     tiles = (n_trials + tile_n - 1) / tile_n;
     const long long vB = B * (long long)tiles;
@@ -910,12 +1097,12 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles; A.B = vB;
     // chunk = the unit a wave pulls from the global queue: small (tail of the whole launch <= one chunk), but large
     // enough that the queue's atomic counter is touched rarely (~ once per 1200+ trials per wave)
-    int spc = g_tuning.sets_per_chunk;
+    int spc = tun.sets_per_chunk;
     if (!spc) {
         spc = (1200 + tile_n - 1) / tile_n;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
-        while (spc > 1 && vB / spc < 32 * 7168) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
+        while (spc > 1 && vB / spc < 32 * waves7) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
         // ... but the queue is ONE atomic word: same-address atomics retire at ~85 M/s on MI355X (measured: 1M chunks
         // take 11.6 ms whatever the work; contention already costs 15 % at 55 M/s), so short-trial workloads (dt = .01,
         // few trials per set) must pull less often: at most ~40 M chunks/s over the shortest time the launch can take --
@@ -925,10 +1112,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         double est_steps = 0.25 / (double)dt;
         if (est_steps > (double)max_steps) est_steps = (double)max_steps;
         if (est_steps < 1.0) est_steps = 1.0;
-        const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / (1024.0 * 2.4e9)
-                             + (double)max_steps * 0.25 * 265.0 * 7.0 / 2.4e9;
+        const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / ((double)simds * di.clock_hz)
+                             + (double)max_steps * 0.25 * 265.0 * 7.0 / di.clock_hz;
         double max_chunks = t_est * 4.0e7;
-        if (max_chunks < 8.0 * 6144.0) max_chunks = 8.0 * 6144.0;
+        if (max_chunks < 8.0 * (double)waves6) max_chunks = 8.0 * (double)waves6;
         if ((double)vB / spc > max_chunks) {
             spc = (int)((double)vB / max_chunks) + 1;
             if (spc > 64) spc = 64;
@@ -940,7 +1127,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
     // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
     const auto lds_of = [&](int r) { return 112 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
-    int ring = g_tuning.ring;
+    int ring = tun.ring;
     if (!ring) {
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);
         if (ring < 4) ring = 4;
@@ -959,84 +1146,70 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // refill when this many lanes hold a finished trial: 8, or 16 where a refill is dearer relative to the stepping
     // between two refills (short trials; models whose hand-out draws per-trial auxiliary normals) -- measured +2..5 %
     const bool aux_handout = model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
-    A.res16 = res16 ? 1 : 0;
-    A.refill_thresh = g_tuning.refill_thresh ? g_tuning.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
-    A.max_blocks = g_tuning.max_blocks ? g_tuning.max_blocks : 16;
+    A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
+    A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
+    A.max_blocks = tun.max_blocks ? tun.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
-    A.open_ahead = vB >= 4 * 7168 ? 1 : 0;
+    A.open_ahead = vB >= 4 * waves7 ? 1 : 0;
     const size_t lds = lds_of(ring);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
-    // ---- per-launch device scratch -------------------------------------------------------------------------------
-    //  * one queue (chunk counter + exit counter, self-resetting), from a per-device pool of 4096 handed out round-robin;
+    // ---- per-launch device memory -----------------------------------------------------------------------------------
+    //  * the work queue (chunk counter + exit counter, self-resetting: no memset per launch);
     //  * the longest-first order (64 counters + B indices + the gathered parameter rows) for launches of >= 2048 sets;
-    //  * integer partial sums [vB, 9] whenever summaries are requested: the f64 finalisation is done by
+    //  * integer partial sums [vB, partial_words()] whenever summaries are requested: the f64 finalisation is done by
     //    combine_partials_kernel with one thread per set instead of by lane 0 of every flush (which also kept ~8 more
     //    VGPRs alive in the simulator kernel).
-    // Scratch of up to 1 MB comes from a persistent 64 MB per-device ring, also round-robin (a region is reused after
-    // >= 64 later launches; launches on one stream are ordered anyway), so that the small, fixed-shape launches of a
-    // training loop hold no allocation and can be captured in a hipGraph.  Larger scratch is stream-ordered
-    // (hipMallocAsync / hipFreeAsync) and such a launch is refused while the stream is capturing: graphs that held
-    // hipMallocAsync nodes lost the ordering between the queue-word memset and the kernel on replay (ROCm 7.2).
-    const bool want_order = B >= 2048 && g_tuning.no_order == 0;
+    // Queue words and up to 1 MB of scratch come from a LaunchSlot (see above: reused on stream order or on event
+    // completion), so the small, fixed-shape launches of a training loop allocate nothing.  Larger scratch is
+    // stream-ordered (hipMallocAsync / hipFreeAsync).  A launch under stream capture gets a dedicated allocation for
+    // everything (graph_alloc) and zeroes its queue words with a captured kernel; it is refused above GRAPH_SCRATCH_MAX.
+    const bool want_order = B >= 2048 && tun.no_order == 0;
     const bool want_partials = out_summary != nullptr;
+    const int pw = partial_words(has_zsum);
     const size_t order_bytes = want_order ? (((size_t)(64 + B + B * P) * sizeof(int) + 255) & ~(size_t)255) : 0;
-    const size_t partial_bytes = want_partials ? (size_t)vB * 9 * sizeof(long long) : 0;
+    const size_t partial_bytes = want_partials ? (size_t)vB * pw * sizeof(unsigned long long) : 0;
     const size_t scratch_bytes = order_bytes + partial_bytes;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     char *scratch = nullptr;
     bool scratch_async = false;
-    {
-        static std::mutex mu;
-        static unsigned int *pool[64] = {nullptr};
-        static unsigned int next[64] = {0};
-        static char *ring_base[64] = {nullptr};
-        static size_t ring_off[64] = {0};
-        constexpr unsigned int POOL = 4096;
-        constexpr size_t RING_BYTES = 64u << 20, RING_MAX = 1u << 20;
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess || dev < 0 || dev >= 64) return fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
-        std::lock_guard<std::mutex> lock(mu);
-        if (!pool[dev]) {
-            // keep freed stream-ordered blocks cached instead of handing them back to the OS at every synchronisation
-            hipMemPool_t mp;
-            if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess) {
-                uint64_t keep = UINT64_MAX;
-                (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            e = hipMalloc(reinterpret_cast<void **>(&pool[dev]), 2 * POOL * sizeof(unsigned int));
-            if (e == hipSuccess) e = hipMemset(pool[dev], 0, 2 * POOL * sizeof(unsigned int));
-            if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(queue words): %s", hipGetErrorString(e));
-            e = hipMalloc(reinterpret_cast<void **>(&ring_base[dev]), RING_BYTES);
-            if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMalloc(scratch ring): %s", hipGetErrorString(e));
+    LaunchSlot *slot = nullptr;
+    if (capturing) {
+        if (scratch_bytes > GRAPH_SCRATCH_MAX)
+            return fail(NDDM_ERR_PARAM, "this launch needs more than 64 MB of scratch and cannot be captured in a hipGraph%s");
+        hipError_t e;
+        char *mem = graph_alloc(dev, SLOT_QUEUE_BYTES + scratch_bytes, &e);
+        if (!mem) return fail(NDDM_ERR_HIP, "hipMalloc(captured launch): %s", hipGetErrorString(e));
+        A.chunk_counter = reinterpret_cast<unsigned int *>(mem);
+        scratch = mem + SLOT_QUEUE_BYTES;
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, A.chunk_counter);
+    } else {
+        hipError_t e;
+        slot = acquire_slot(dev, st, &e);
+        if (!slot) return fail(NDDM_ERR_HIP, "launch slot: %s", hipGetErrorString(e));
+        A.chunk_counter = reinterpret_cast<unsigned int *>(slot->base);
+        if (slot->fresh) {
+            e = hipMemsetAsync(slot->base, 0, SLOT_QUEUE_BYTES, st);
+            if (e != hipSuccess) { release_slot(slot, st); return fail(NDDM_ERR_HIP, "hipMemsetAsync(queue words): %s", hipGetErrorString(e)); }
         }
-        A.chunk_counter = pool[dev] + 2 * (next[dev]++ % POOL);
-        if (scratch_bytes && scratch_bytes <= RING_MAX) {
-            const size_t need = (scratch_bytes + 255) & ~(size_t)255;
-            if (ring_off[dev] + need > RING_BYTES) ring_off[dev] = 0;
-            scratch = ring_base[dev] + ring_off[dev];
-            ring_off[dev] += need;
+        if (scratch_bytes && scratch_bytes <= SLOT_SCRATCH) scratch = slot->base + SLOT_QUEUE_BYTES;
+        else if (scratch_bytes) {
+            e = hipMallocAsync(reinterpret_cast<void **>(&scratch), scratch_bytes, st);
+            if (e != hipSuccess) { release_slot(slot, st); return fail(NDDM_ERR_HIP, "hipMallocAsync(scratch): %s", hipGetErrorString(e)); }
+            scratch_async = true;
         }
-    }
-    if (scratch_bytes && !scratch) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(NDDM_ERR_PARAM, "this launch needs stream-ordered scratch (>= 2048 sets, or many split sets) and cannot "
-                                        "be captured in a hipGraph%s");
-        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&scratch), scratch_bytes, st);
-        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(scratch): %s", hipGetErrorString(e));
-        scratch_async = true;
     }
     int rc = NDDM_OK;
     A.order = nullptr;
-    A.partials = want_partials ? reinterpret_cast<long long *>(scratch + order_bytes) : nullptr;
+    A.partials = want_partials ? reinterpret_cast<unsigned long long *>(scratch + order_bytes) : nullptr;
     if (want_order) {
         // longest-first processing order
         int *order_ws = reinterpret_cast<int *>(scratch);
         hipError_t e = hipSuccess;
         {
-            hipLaunchKernelGGL(order_zero_kernel, dim3(1), dim3(64), 0, st, order_ws);
+            hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned int *>(order_ws));
             const int threads = 256;
             long long blocks = (B + threads - 1) / threads;
             if (blocks > 2048) blocks = 2048;
@@ -1051,26 +1224,28 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         A.params_q = reinterpret_cast<const float *>(order_ws + 64 + B);
     }
     if (rc == NDDM_OK) {
+        const int gw = tun.grid_waves;   // 0 = as many waves as stay resident
         switch (model) {
-        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, st); break;
-        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, st); break;
-        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, st); break;
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
         case NDDM_ALPHA_NOT_SCALED:
-            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, st)
-                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, st);
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, di.cus, gw, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st);
             break;
-        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, st); break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
         }
     }
     if (rc == NDDM_OK && A.partials) {
         const int tau_idx = model == NDDM_EXPLICIT_BOUNDARY ? 2 : 3;
         const int threads = 256;
         hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st,
-                           A.partials, params, P, tau_idx, (long long)B, tiles, n_trials, A.tscale, out_summary);
+                           A.partials, pw, params, P, tau_idx, (long long)B, tiles, n_trials, A.tscale, out_summary);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
     }
     if (scratch_async) (void)hipFreeAsync(scratch, st);
+    if (slot) release_slot(slot, st);
     return rc;
 }
 
@@ -1114,6 +1289,7 @@ int nddm_set_device(int device)
 int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves, int tile_trials)
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
     const int no_order = nddm::g_tuning.no_order;
     nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order};
     return NDDM_OK;
@@ -1122,6 +1298,7 @@ int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blo
 /* benchmarking aid: 1 = process the sets in the given order (no longest-first sort) */
 int nddm_set_ordering(int enabled)
 {
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
     nddm::g_tuning.no_order = enabled ? 0 : 1;
     return NDDM_OK;
 }
@@ -1130,7 +1307,21 @@ int nddm_set_ordering(int enabled)
  * s_memtime cycles, sum of per-wave s_memrealtime ticks (100 MHz), waves); NULL switches it off */
 int nddm_set_debug_counters(void *dev_u64x8)
 {
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
     nddm::g_dbg = static_cast<unsigned long long *>(dev_u64x8);
+    return NDDM_OK;
+}
+
+/* Frees the memory the library allocated for launches that were captured into hipGraphs on the current device.  The
+ * caller asserts that every graph that captured a launch of this library has been destroyed (or will not be replayed). */
+int nddm_release_graph_memory(void)
+{
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= nddm::MAX_DEVICES) return nddm::fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    nddm::GraphAlloc *list;
+    { std::lock_guard<std::mutex> lock(nddm::g_mu); list = nddm::g_graph_allocs[dev]; nddm::g_graph_allocs[dev] = nullptr; }
+    while (list) { nddm::GraphAlloc *n = list->next; (void)hipFree(list->p); delete list; list = n; }
     return NDDM_OK;
 }
 

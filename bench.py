@@ -154,13 +154,52 @@ def ks_vs_golden(engine, dt, max_steps, fast):
             "reference": "NumPy reference simulator (basic_ddm_dc.py:85-125), tests/golden/ks_hist.npz"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same command, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), wait for
+    them and exit with the worst status.  Nothing in THIS process has touched the GPU or imported torch: the workers
+    are children, never an exec of a process that initialised HIP.  Rank 0 prints the JSON line on the inherited
+    stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NDDM_BENCH_WORKER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, alive = 0, list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:                      # one rank died: the others would wait for it until a timeout
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(worst)
+
+
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
+    if a.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a.gpus)                         # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                 f"(or let `python bench.py --gpus N` start the ranks itself); refusing to measure a different job")
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU (no CPU fallback)")
     if a.share_device:

@@ -18,7 +18,21 @@
  *     depend on launch geometry, on how rows are sharded over GPUs, or on call order.
  *   - timeouts are data (choice 0 / choicert 0), never errors.
  *   - return value: NDDM_OK or an nddm_status; nddm_last_error() gives thread-local text.
- *   - re-entrant and thread-safe given distinct output buffers.
+ *   - re-entrant and thread-safe given distinct output buffers: any number of host threads may call on any streams
+ *     concurrently.  The device memory a launch needs besides the caller's buffers (work-queue words, scratch) is owned by
+ *     that launch until the work it enqueued has COMPLETED (reuse is keyed on stream order or on a completion event, never
+ *     on a launch count); the developer knobs (nddm_set_tuning, nddm_set_debug_counters) are read once, atomically, at entry.
+ *   - hipGraph: a call made while `stream` is capturing is recorded as kernels only; the memory such a launch needs is
+ *     allocated for that launch alone and lives until nddm_release_graph_memory().  Seed and set_offset are baked in.
+ *
+ * Deliberate deviations from the boundary sketched for this path:
+ *   - arithmetic is float32 on the device (state w, the Gaussian transform) with an INTEGER step index, so
+ *     rt = k*dt + tau is exact in k; the reference integrates in float64.  Parity with the reference is therefore
+ *     distributional (KS < 0.01 on the integer step grid), and bit-for-bit only against the float32 oracle (oracle/).
+ *     Parameters are taken as float32 [B, P]; there is no float64 input form.
+ *   - there are no `*_cpu` twins in this library: the CPU restatement of the same stream is test infrastructure
+ *     (oracle/ddm_oracle.c) and is never linked into, or reachable from, the product.  Without a ROCm device every entry
+ *     point fails with NDDM_ERR_HIP / NDDM_ERR_NO_DEVICE.
  */
 #ifndef NDDM_H
 #define NDDM_H
@@ -82,6 +96,9 @@ int nddm_device_count(int *count);
 int nddm_set_device(int device);
 int nddm_summary_k(void);
 int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
+/* frees the memory held for launches captured into hipGraphs on the current device; call only when every graph that
+ * captured a launch of this library has been destroyed */
+int nddm_release_graph_memory(void);
 
 /* ---- simulators --------------------------------------------------------------------
  * Common arguments:

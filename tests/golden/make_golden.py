@@ -23,8 +23,11 @@ Outputs (all under tests/golden/):
                 the alpha_not_scaled parameter ranges
   mixture.npz   2000 parameter sets drawn from the basic_ddm_dc prior x 200 reference trials each, pooled
                 histogram of the signed step index (both dt configurations)
+  ks_variants.npz  distribution tier of the misspecification / imputation simulators (_alt, _scale, _scale2,
+                explicit per-trial boundary): step-index histograms by choice + quantile tables of the external
+                datum, >= 4e5 reference trials per parameter set, both dt configurations
 
-Usage:  python tests/golden/make_golden.py [--kat] [--ks] [--ratcliff] [--priors] [--procs 8]
+Usage:  python tests/golden/make_golden.py [--kat] [--ks] [--variants] [--ratcliff] [--priors] [--procs 8]
 This only runs in the build container (it needs /root/reference); the GPU box
 only ever sees the .npz files.
 """
@@ -121,6 +124,35 @@ RATCLIFF_SETS = np.array([
     [-3.0, 1.3, 0.65, 0.50, 1.2, 0.9],
     [2.5, 1.0, 0.35, 0.45, 1.8, 1.1],
 ])
+# _alt order: drift, alpha, beta, ter, std_dc, mu_dc, sigma1 (single_trial_alpha_not_scaled.py:966)
+ALT_SETS = np.array([
+    [3.0, 1.5, 0.5, 0.40, 0.5, 1.0, 0.1],    # the KAT set
+    [0.5, 1.2, 0.4, 0.30, 1.0, 0.8, 1.0],    # high rejection rate of the per-trial dc draw
+    [-1.5, 2.0, 0.6, 0.50, 0.2, 1.5, 2.5],
+])
+# _scale order: drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, gamma (single_trial_alpha_not_scaled.py:1277)
+SCALE_SETS = np.array([
+    [3.0, 1.5, 0.5, 0.40, 1.0, 1.0, 0.1, 0.3],
+    [0.0, 1.0, 0.5, 0.50, 1.0, 1.0, 1.0, 2.0],
+])
+# _scale2 (gamma fixed at 2, :1471-1519) takes the 7 single-trial parameters
+SCALE2_SETS = np.array([
+    [-2.0, 1.2, 0.4, 0.30, 0.3, 0.8, 2.5],
+])
+# explicit per-trial boundary (imputation_from_stahl_not_scaled.py:120-148): drift, beta, ter, dc + ONE boundary vector
+EXPLICIT_SETS = np.array([
+    [1.0, 0.5, 0.30, 1.1],
+    [-0.5, 0.4, 0.20, 0.7],
+])
+EXPLICIT_NB = 400
+
+
+def explicit_bounds():
+    """The boundary vector of the explicit-boundary fixtures, drawn once (the recipe of the KAT vector, 400 long)."""
+    rs = np.random.RandomState(5)
+    return np.abs(rs.normal(1.2, 0.4, size=EXPLICIT_NB))
+
+
 DT_CONFIGS = [(0.01, 400.0), (0.001, 4000.0)]
 N_KS = 400_000
 CHUNK = 10_000
@@ -308,6 +340,79 @@ def make_ks(procs):
 
 
 # ---------------------------------------------------------------------------
+# distribution tier of the variants: _alt / _scale / _scale2 / explicit boundary
+# ---------------------------------------------------------------------------
+VARIANTS = {"alt": ("single_alt", "diffusion_trial_alt", ALT_SETS), "scale": ("single_scale", "diffusion_trial_scale", SCALE_SETS),
+            "scale2": ("single_scale2", "diffusion_trial_scale2", SCALE2_SETS),
+            "explicit": ("imputation_sim", "diffusion_trial", EXPLICIT_SETS)}
+
+
+def _variant_chunk(job):
+    name, si, ci, chunk_id, n = job
+    slice_name, fn_name, sets = VARIANTS[name]
+    dt, ms = DT_CONFIGS[ci]
+    K = int(ms)
+    if name not in _NS:
+        _NS[name] = load_slice(slice_name)
+    f = _NS[name][fn_name]
+    p = sets[si]
+    np.random.seed(300_000_000 + 10_000_000 * list(VARIANTS).index(name) + 100_000 * ci + 1000 * si + chunk_id)
+    hist = np.zeros((3, K + 1), dtype=np.int64)
+    ter = p[2] if name == "explicit" else p[3]
+    zs = None
+    if name == "explicit":
+        bounds = explicit_bounds()
+        for i in range(n):
+            crt = f(p[0], bounds[i % EXPLICIT_NB], p[1], p[2], p[3], dt=dt, max_steps=ms)
+            if crt == 0:
+                hist[2, K] += 1
+            else:
+                hist[0 if crt > 0 else 1, int(round((abs(crt) - ter) / dt))] += 1
+    else:
+        zs = np.empty(n)
+        for i in range(n):
+            crt, z = f(*p, dt=dt, max_steps=ms)
+            zs[i] = z
+            if crt == 0:
+                hist[2, K] += 1
+            else:
+                hist[0 if crt > 0 else 1, int(round((abs(crt) - ter) / dt))] += 1
+    return name, si, ci, hist, zs
+
+
+def make_variants(procs):
+    jobs = []
+    for name, (_, _, sets) in VARIANTS.items():
+        for si in range(len(sets)):
+            for ci in range(len(DT_CONFIGS)):
+                for c in range(N_KS // CHUNK):
+                    jobs.append((name, si, ci, c, CHUNK))
+    jobs.sort(key=lambda j: -j[2])
+    acc, zacc = {}, {}
+    t0 = time.time()
+    with Pool(procs) as pool:
+        for done, (name, si, ci, hist, zs) in enumerate(pool.imap_unordered(_variant_chunk, jobs, chunksize=1)):
+            key = (name, si, ci)
+            acc[key] = acc.get(key, 0) + hist
+            if zs is not None:
+                zacc.setdefault(key, []).append(zs)
+            if done % 100 == 0:
+                print(f"variants: {done}/{len(jobs)} chunks, {time.time()-t0:.0f}s", flush=True)
+    out = {"alt_sets": ALT_SETS, "scale_sets": SCALE_SETS, "scale2_sets": SCALE2_SETS, "explicit_sets": EXPLICIT_SETS,
+           "explicit_bounds": explicit_bounds(),
+           "dt": np.array([c[0] for c in DT_CONFIGS]), "max_steps": np.array([c[1] for c in DT_CONFIGS])}
+    q = np.linspace(0, 1, 2001)
+    for (name, si, ci), h in acc.items():
+        out[f"{name}_hist_s{si}_c{ci}"] = h.astype(np.int32)
+        if (name, si, ci) in zacc:
+            z = np.concatenate(zacc[(name, si, ci)])
+            out[f"{name}_zq_s{si}_c{ci}"] = np.quantile(z, q)
+            out[f"{name}_zmom_s{si}_c{ci}"] = np.array([z.mean(), z.var(), len(z)])
+    np.savez_compressed(os.path.join(OUT, "ks_variants.npz"), **out)
+    print("ks_variants.npz written", time.time() - t0, "s")
+
+
+# ---------------------------------------------------------------------------
 # prior-mixture tier: many parameter sets drawn from the prior, pooled distribution of the signed step index
 # ---------------------------------------------------------------------------
 def mixture_params(n_sets=2000, seed=99):
@@ -393,13 +498,14 @@ if __name__ == "__main__":
     ap.add_argument("--kat", action="store_true")
     ap.add_argument("--priors", action="store_true")
     ap.add_argument("--ks", action="store_true")
+    ap.add_argument("--variants", action="store_true")
     ap.add_argument("--ratcliff", action="store_true")
     ap.add_argument("--mixture", action="store_true")
     ap.add_argument("--procs", type=int, default=8)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}; fixtures can only be regenerated in the build container")
-    everything = not (a.kat or a.priors or a.ks or a.ratcliff or a.mixture)
+    everything = not (a.kat or a.priors or a.ks or a.variants or a.ratcliff or a.mixture)
     if a.kat or everything:
         make_kat()
     if a.priors or everything:
@@ -410,3 +516,5 @@ if __name__ == "__main__":
         make_mixture(a.procs)
     if a.ks or everything:
         make_ks(a.procs)
+    if a.variants or everything:
+        make_variants(a.procs)

@@ -86,6 +86,40 @@ def test_ks_single_trial_vs_reference(ci, fast):
         assert abs(s[:, 8].mean() / zm[1] - 1) < 0.03                              # fused var z
 
 
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("ci", [0, 1])
+def test_ks_variants_vs_reference(ci, fast):
+    """The misspecification / imputation simulators on the GPU (_alt, _scale, _scale2, explicit per-trial boundary)
+    against >= 4e5 trials of the reference's own functions per parameter set (tests/golden/ks_variants.npz): KS of the
+    signed step index, |dP(choice)|, and KS of the external datum, all < 0.01."""
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    from test_oracle_golden import variant_cases
+    gold = _gold("ks_variants.npz")
+    dt, ms = float(gold["dt"][ci]), float(gold["max_steps"][ci])
+    mods = {"alt": engine.SINGLE_TRIAL_ALT, "single": engine.SINGLE_TRIAL, "explicit": engine.EXPLICIT_BOUNDARY}
+    for idx, (name, model, p, bounds, ter_i) in enumerate(variant_cases(gold, mods)):
+        if bounds is None:
+            B, N, bnd = 2048, 200, None
+        else:
+            B, N = 1024, len(bounds)
+            bnd = np.tile(bounds, (B, 1))
+        r = engine.simulate(model, np.tile(p, (B, 1)), N, dt=dt, max_steps=ms, seed=47, set_offset=idx * 10000, fast=fast,
+                            bounds=bnd, want_summary=True)
+        t = r["trials"].cpu().numpy()
+        h = dg.step_hist_from_trials(t, float(np.float32(p[ter_i])), dt, int(ms), signed=True)
+        g = gold[name.format("hist") + f"_c{ci}"]
+        assert dg.ks_signed(h, g) < KS_BAR, (name, dg.ks_signed(h, g))
+        assert np.max(np.abs(dg.choice_probs(h) - dg.choice_probs(g))) < KS_BAR, name
+        zq = name.format("zq") + f"_c{ci}"
+        if zq in gold:
+            assert dg.ks_quantile_table(t[..., 1].ravel(), gold[zq]) < KS_BAR, name
+            zm = gold[name.format("zmom") + f"_c{ci}"]
+            s = r["summary"].cpu().numpy()
+            assert abs(s[:, 7].mean() - zm[0]) < 0.02 * max(1.0, np.sqrt(zm[1])), name      # fused mean z vs reference
+        else:
+            assert np.array_equal(t[..., 1], bnd.astype(np.float32))
+
+
 def test_alpha_not_scaled_em_vs_exact_sampler():
     """Config 3: the Euler-Maruyama process vs the reference's generator simulratcliff, an EXACT first-passage
     sampler.  Discrete monitoring of the boundaries delays detection by ~0.58*sigma*sqrt(dt) per boundary, so the
