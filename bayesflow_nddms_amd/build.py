@@ -8,7 +8,8 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libnddm_hip.so")
+# NDDM_HIP_LIB: developer override (A/B runs of differently built libraries); the product path is the in-tree library
+SO_PATH = os.environ.get("NDDM_HIP_LIB") or os.path.join(_HERE, "libnddm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "nddm_kernels.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "nddm_rng.h"),
            os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
@@ -24,6 +25,8 @@ def _hipcc():
 
 
 def is_stale():
+    if os.environ.get("NDDM_HIP_LIB"):
+        return False
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)

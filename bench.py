@@ -2,22 +2,30 @@
 """bench.py -- simulated DDM trials per second (BASELINE.json metric) on N MI355X GPUs of one node.
 
 One "step" = one pass of the hot path over one batch: `--sets` parameter sets x `--trials` trials of the
-basic_ddm_dc Euler-Maruyama simulator at dt=0.001 / max_steps=4000 (BASELINE.json configs[1]: 1M x 300), parameters
-already resident in HBM, output = float32 (rt, choice) pairs [B, 300, 2] + fused per-set summaries [B, 10].
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); the batch shards embarrassingly --
-rank r simulates global set indices [r*B, (r+1)*B) of each step with no data-path collective (weak scaling);
-`--gather summary|trials` adds the RCCL all-gather that reassembles a training minibatch (north_star) to the
-timed region.
+Euler-Maruyama simulator at dt=0.001 / max_steps=4000 (BASELINE.json configs[1]: basic_ddm_dc, 1M x 300; `--model
+single` = configs[3], `--model alpha_ns|alpha_ns_bridge` = configs[2]), parameters already resident in HBM, output =
+float32 pairs [B, 300, 2] + fused per-set summaries [B, 10].
 
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `python bench.py --gpus N` starts the N ranks
+itself (fresh child processes, before anything touches the GPU); under `torch.distributed.run --nproc-per-node N` it
+joins the ranks it is given.  The batch shards embarrassingly -- rank r simulates global set indices [r*B, (r+1)*B) of
+each step with no data-path collective (weak scaling); `--gather summary|trials` adds the RCCL all-gather that
+reassembles a training minibatch (north_star) to the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
   roofline      HBM view of the dominant kernel (algorithmic bytes / measured kernel time vs 8 TB/s) -- tiny by
                 construction: 8 B are written per trial for ~246 Gaussian draws
-  roofline_valu the binding resource: vector-ALU issue cycles (instruction mix of the step loop x measured
-                per-instruction issue cost) -- see DESIGN.md section 6
+  roofline_valu the binding resource, vector-ALU issue, against two ceilings: (i) the same kernel's step loop with
+                every lane useful, MEASURED in this run (a lockstep workload, outside the timed region); (ii) the ISA-level
+                issue model of the shipped library (tools/isa_mix.py x tools/ubench_valu, profiles/*_issue_model.json)
   cpu_baseline  the CPU oracle (C restatement, same Philox stream) timed on this box's host cores on a bounded
                 sample of the same workload; plus the pure-Python/NumPy port the reference runs without numba
+
+`--train` measures BASELINE config 5 instead (online simulation feeding the PyTorch-ROCm amortizer): iterations/s,
+microseconds per simulate launch (eager and hipGraph), simulator share of a step, prefetch on/off.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -29,35 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU ceiling model: issue cycles per wave64 for one Philox block = 4 E-M steps, fast Gaussian
-# mode, from the ISA of sim_kernel<basic, fast> x the measured per-instruction issue cost (tools/ubench_valu)
-VALU_MODEL = {
-    "clock_ghz": 2.4, "simds": 1024,
-    # SIMD cycles (at 2.4 GHz) one wave64 needs per Philox block (4 E-M steps x 64 lanes) when EVERY lane is useful:
-    # measured with tools/quick_time.py's lockstep run (all trials run to the step cap: no refill, no idle lanes, same
-    # kernel, same residency): 2.48e12 E-M steps/s at lane efficiency 0.981 = 2.53e12 with every lane useful = 249 cycles
-    # per block (fast); 1.231e12 at 0.979 = 500 cycles (exact) -- profiles/r1_summary.md.  The sum of the isolated
-    # per-instruction issue costs of the loop (tools/isa_mix.py x profiles/r1_ubench_valu.txt) is 274 / 595: the real
-    # loop issues better than that sum, so the measured figure is the tighter ceiling.
-    "cycles_per_block_fast": 249.0, "cycles_per_block_exact": 500.0,
-    "sum_of_issue_costs_fast": 274.0, "sum_of_issue_costs_exact": 595.0,
+CLOCK_GHZ = 2.4                # nominal engine clock the cycle figures are quoted at
+ARITHMETIC = "f32 state and Gaussian transform, integer step index (rt = k*dt + tau exact in k); the reference integrates in f64"
+
+MODELS = {  # bench name -> (engine model attribute, bridge, host prior matrix, oracle model attribute, index of tau)
+    "basic": ("BASIC_DDM_DC", False, "basic_prior_matrix", "M_BASIC", 3),
+    "single": ("SINGLE_TRIAL", False, "single_prior_matrix", "M_SINGLE", 3),
+    "alpha_ns": ("ALPHA_NOT_SCALED", False, "alpha_ns_prior_matrix", "M_ALPHA_NS", 3),
+    "alpha_ns_bridge": ("ALPHA_NOT_SCALED", True, "alpha_ns_prior_matrix", "M_ALPHA_NS", 3),
 }
-
-
-def pmc_traffic(B, N):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc.json, made by tools/gpu_profile.sh + tools/summarize_profile.py): WRITE_SIZE is exact for streaming
-    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if no matching profile."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-            if d["sets_per_gpu"] == B and d["n_trials"] == N and "WRITE_SIZE" in d["pmc_per_launch"]:
-                c = d["pmc_per_launch"]
-                return {"bytes": (2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, "source": os.path.basename(path)}
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+# every trial runs to the step cap (zero drift, boundary 50): no refill, no idle lane -- the step loop alone
+LOCKSTEP_ROW = {"basic": [0.0, 50.0, 0.5, 0.3, 1.0], "single": [0.0, 50.0, 0.5, 0.3, 0.01, 1.0, 1.0, 1.0],
+                "alpha_ns": [0.0, 50.0, 0.5, 0.3, 0.0, 1.0], "alpha_ns_bridge": [0.0, 50.0, 0.5, 0.3, 0.0, 1.0]}
+KERNEL_NAME = {"basic": "nddm::sim_kernel<0 (basic_ddm_dc), %s>", "single": "nddm::sim_kernel<1 (single_trial), %s>",
+               "alpha_ns": "nddm::sim_kernel<3 (alpha_not_scaled), %s>", "alpha_ns_bridge": "nddm::sim_kernel<3 (alpha_not_scaled), %s, bridge>"}
 
 
 def parse():
@@ -70,90 +63,27 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.001)
     ap.add_argument("--max-steps", type=float, default=4000.0)
     ap.add_argument("--gauss", choices=["fast", "exact"], default="fast")
-    ap.add_argument("--model", choices=["basic", "single", "alpha_ns", "alpha_ns_bridge"], default="basic",
+    ap.add_argument("--model", choices=list(MODELS), default="basic",
                     help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns* = configs[2]")
     ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
     ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle baseline sample")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="BASELINE configs[0] at its stated size: the NumPy port on 500 sets x 300 trials at dt=.001/4000 and "
+                         "dt=.01/400 (about a minute of CPU time)")
     ap.add_argument("--no-ks", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the lockstep run that measures the VALU ceiling")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --share-device rehearse the multi-process path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--train", action="store_true", help="BASELINE config 5: online simulation feeding the amortizer")
+    ap.add_argument("--train-iters", type=int, default=150)
+    ap.add_argument("--batch", type=int, default=32, help="--train: parameter sets per rank per training step")
     return ap.parse_args()
 
 
-def cpu_baseline(params, n_trials, dt, max_steps, target_s):
-    """Time the CPU oracle (kind 'port': our C restatement on the same Philox stream) on a bounded sample of the
-    same workload: the first S parameter sets, S sized from a pilot so that the single-thread run takes ~target_s."""
-    import oracle
-    from oracle import numpy_port
-    oracle.build()
-    # threads actually used for the multi-core figure: the GPU box grants a CPU share of 16 cores per GPU, whatever
-    # os.cpu_count() says (256 there)
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
-    pilot = 64
-    t0 = time.perf_counter()
-    oracle.philox_simulate(oracle.M_BASIC, params[:pilot], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=1)
-    t_pilot = time.perf_counter() - t0
-    S = int(max(pilot, min(len(params), pilot * target_s / max(t_pilot, 1e-6))))
-    t0 = time.perf_counter()
-    oracle.philox_simulate(oracle.M_BASIC, params[:S], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=1)
-    t1 = time.perf_counter() - t0
-    v1 = S * n_trials / t1
-    # all host cores, same sample scaled up
-    Sm = int(min(len(params), S * cores))
-    t0 = time.perf_counter()
-    oracle.philox_simulate(oracle.M_BASIC, params[:Sm], n_trials, dt=dt, max_steps=max_steps, seed=1, threads=cores)
-    tm = time.perf_counter() - t0
-    vm = Sm * n_trials / tm
-    # the pure-Python/NumPy algorithm the reference runs when numba is absent (numba is not installed here)
-    Sp = 12
-    np.random.seed(2023)
-    t0 = time.perf_counter()
-    for i in range(Sp):
-        numpy_port.basic_simulate_trials(params[i].astype(np.float64), n_trials, dt=dt, max_steps=max_steps)
-    tp = time.perf_counter() - t0
-    return {"value": v1, "unit": "trials/s", "cores": 1, "kind": "port",
-            "sample": f"first {S} of the step's parameter sets x {n_trials} trials, C oracle (Philox stream), "
-                      f"{t1:.1f} s single thread",
-            "all_cores": {"value": vm, "cores": cores, "host_cpu_count": os.cpu_count(),
-                          "sample": f"{Sm} sets, OpenMP over sets with {cores} threads, {tm:.1f} s"},
-            "numpy_port": {"value": Sp * n_trials / tp, "cores": 1,
-                           "sample": f"{Sp} sets x {n_trials} trials, pure-Python/NumPy statement of "
-                                     f"basic_ddm_dc.py:85-125 (numba not installed), {tp:.1f} s"}}
-
-
-def ks_vs_golden(engine, dt, max_steps, fast):
-    """KS distance of the signed RT distribution vs the golden histograms made from the reference's NumPy
-    simulator (tests/golden/ks_hist.npz), >= 4e5 trials per side, all fixed basic_ddm_dc parameter sets."""
-    from bayesflow_nddms_amd import diagnostics as dg
-    path = os.path.join(ROOT, "tests", "golden", "ks_hist.npz")
-    if not os.path.exists(path):
-        return None
-    gold = np.load(path)
-    dts = list(gold["dt"])
-    if dt not in dts:
-        return None
-    ci = dts.index(dt)
-    if float(gold["max_steps"][ci]) != float(max_steps):
-        return None
-    K = int(max_steps)
-    worst, per = 0.0, []
-    for si, p in enumerate(gold["basic_sets"]):
-        key = f"basic_hist_s{si}_c{ci}"
-        if key not in gold:
-            continue
-        r = engine.simulate(engine.BASIC_DDM_DC, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=max_steps,
-                            seed=777, set_offset=si * 4096, fast=fast, want_summary=False)
-        h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K)
-        ks = dg.ks_signed(h, gold[key])
-        per.append(round(ks, 5))
-        worst = max(worst, ks)
-    return {"max": worst, "per_set": per, "n_trials_per_side": 409600, "bar": 0.01,
-            "reference": "NumPy reference simulator (basic_ddm_dc.py:85-125), tests/golden/ks_hist.npz"}
-
-
+# --------------------------------------------------------------------------------------------------- launcher
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same command, one per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), wait for
@@ -168,7 +98,7 @@ def launch_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), NDDM_BENCH_WORKER="1")
+                   MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst, alive = 0, list(procs)
@@ -186,12 +116,182 @@ def launch_ranks(n):
     sys.exit(worst)
 
 
-def main():
-    a = parse()
-    if a.gpus < 1:
-        sys.exit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        launch_ranks(a.gpus)                         # does not return
+# --------------------------------------------------------------------------------------------------- CPU legs
+def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
+    """Time the CPU oracle (kind 'port': our C restatement on the same Philox stream) on a bounded sample of the
+    same workload: the first S parameter sets, S sized from a pilot so that the single-thread run takes ~target_s."""
+    import oracle
+    from oracle import numpy_port
+    oracle.build()
+    om = getattr(oracle, MODELS[model_name][3])
+    bridge = MODELS[model_name][1]
+    sim = lambda p, threads: oracle.philox_simulate(om, p, n_trials, dt=dt, max_steps=max_steps, seed=1, bridge=bridge,
+                                                    threads=threads)
+    # threads actually used for the multi-core figure: the GPU box grants a CPU share of 16 cores per GPU, whatever
+    # os.cpu_count() says (256 there)
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    pilot = 64
+    t0 = time.perf_counter()
+    sim(params[:pilot], 1)
+    t_pilot = time.perf_counter() - t0
+    S = int(max(pilot, min(len(params), pilot * target_s / max(t_pilot, 1e-6))))
+    t0 = time.perf_counter()
+    sim(params[:S], 1)
+    t1 = time.perf_counter() - t0
+    v1 = S * n_trials / t1
+    Sm = int(min(len(params), S * cores))            # all host cores, same sample scaled up
+    t0 = time.perf_counter()
+    sim(params[:Sm], cores)
+    tm = time.perf_counter() - t0
+    vm = Sm * n_trials / tm
+    out = {"value": v1, "unit": "trials/s", "cores": 1, "kind": "port",
+           "sample": f"first {S} of the step's parameter sets x {n_trials} trials, C oracle of the {model_name} model "
+                     f"(Philox stream, f32), {t1:.1f} s single thread",
+           "all_cores": {"value": vm, "cores": cores, "host_cpu_count": os.cpu_count(),
+                         "sample": f"{Sm} sets, OpenMP over sets with {cores} threads, {tm:.1f} s"}}
+    # the pure-Python/NumPy algorithm the reference runs when numba is absent (numba is not installed here): BASELINE
+    # configs[0].  Default: a bounded sample at the bench's dt and at the reference default dt=.01/400; --cpu-full: the
+    # stated 500 sets x 300 trials at both step sizes.
+    port = {"basic": numpy_port.basic_simulate_trials, "single": numpy_port.single_simulate_trials}.get(model_name)
+    if port is not None:
+        legs = {}
+        for tag, (pdt, pms, n_sets) in {"bench_dt": (dt, max_steps, 500 if a.cpu_full else 12),
+                                        "reference_default_dt.01_max400": (0.01, 400.0, 500 if a.cpu_full else 60)}.items():
+            np.random.seed(2023)
+            rows = params[:n_sets, :7].astype(np.float64) if model_name == "single" else params[:n_sets].astype(np.float64)
+            t0 = time.perf_counter()
+            for row in rows:
+                port(row, n_trials, dt=pdt, max_steps=pms)
+            tp = time.perf_counter() - t0
+            legs[tag] = {"value": len(rows) * n_trials / tp, "cores": 1, "dt": pdt, "max_steps": pms,
+                         "sample": f"{len(rows)} sets x {n_trials} trials, {tp:.1f} s"}
+        out["numpy_port"] = dict(legs["bench_dt"], what="pure-Python/NumPy statement of the reference simulator "
+                                 "(basic_ddm_dc.py:85-125 / single_trial_alpha_not_scaled.py:107-155; numba not installed)",
+                                 host_cpu_count=os.cpu_count(), reference_default=legs["reference_default_dt.01_max400"],
+                                 full_config_1=bool(a.cpu_full))
+    return out
+
+
+def ks_vs_golden(engine, model_name, dt, max_steps, fast):
+    """KS distance vs the golden fixtures made from the reference (tests/golden/): the signed step index against
+    ks_hist.npz (basic, single; >= 4e5 trials per side per parameter set), the signed RT against the exact sampler's
+    quantile tables ratcliff.npz (alpha_not_scaled; 2e5 reference draws per set)."""
+    from bayesflow_nddms_amd import diagnostics as dg
+    K = int(max_steps)
+    per = []
+    if model_name in ("basic", "single"):
+        path = os.path.join(ROOT, "tests", "golden", "ks_hist.npz")
+        if not os.path.exists(path):
+            return None
+        gold = np.load(path)
+        dts = list(gold["dt"])
+        if dt not in dts or float(gold["max_steps"][dts.index(dt)]) != float(max_steps):
+            return None
+        ci = dts.index(dt)
+        for si, p in enumerate(gold[f"{model_name}_sets"]):
+            row = p if model_name == "basic" else np.append(p, 1.0)
+            r = engine.simulate(getattr(engine, MODELS[model_name][0]), np.tile(row, (2048, 1)), 200, dt=dt,
+                                max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, want_summary=False)
+            h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K, signed=model_name == "single")
+            per.append(round(dg.ks_signed(h, gold[f"{model_name}_hist_s{si}_c{ci}"]), 5))
+        return {"max": max(per), "per_set": per, "n_trials_per_side": 409600, "bar": 0.01,
+                "reference": f"NumPy reference simulator run on {len(per)} fixed parameter sets, tests/golden/ks_hist.npz"}
+    path = os.path.join(ROOT, "tests", "golden", "ratcliff.npz")
+    if not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    bridge = MODELS[model_name][1]
+    for si, p in enumerate(gold["sets"]):
+        r = engine.simulate(engine.ALPHA_NOT_SCALED, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=8.0 / dt, seed=777,
+                            set_offset=si * 4096, fast=fast, bridge=bridge, want_summary=False)
+        per.append(round(dg.ks_quantile_table(r["trials"][..., 0].cpu().numpy().ravel(), gold[f"yq_s{si}"]), 5))
+    return {"max": max(per), "per_set": per, "n_trials_per_side": "409600 vs 2e5", "bar": 0.01 if bridge else 0.10,
+            "reference": "simulratcliff (pyhddmjagsutils.py:47-176, the EXACT first-passage sampler alpha_not_scaled.py runs), "
+                         "tests/golden/ratcliff.npz" + ("" if bridge else "; plain Euler-Maruyama detects crossings O(sqrt(dt)) late: "
+                                                        "stated tolerance 0.10, the bridge mode meets 0.01")}
+
+
+def pmc_traffic(model_name, B, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc.json, made by tools/gpu_profile.sh + tools/summarize_profile.py): WRITE_SIZE is exact for streaming
+    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if no matching profile."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if (d.get("model", "basic") == model_name and d["sets_per_gpu"] == B and d["n_trials"] == N
+                    and "WRITE_SIZE" in d["pmc_per_launch"]):
+                c = d["pmc_per_launch"]
+                return {"bytes": (2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, "source": os.path.basename(path)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def issue_model(model_name, fast):
+    """ISA-level ceiling of the shipped library's step loop (tools/isa_mix.py), if the committed file matches the .so."""
+    import hashlib
+    from bayesflow_nddms_amd.build import SO_PATH
+    key = model_name if fast else model_name + "_exact"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            k = d["kernels"][key]
+            same = d.get("library_sha256_16") == hashlib.sha256(open(SO_PATH, "rb").read()).hexdigest()[:16]
+            return {"cycles_per_block": k["cycles_per_block"], "valu_per_block": k["valu"], "source": os.path.basename(path),
+                    "issue_costs_from": d.get("issue_costs_from"), "library_matches": same}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+# --------------------------------------------------------------------------------------------------- worker
+def em_steps_of(summary, tau, dt, max_k, bridge):
+    """Executed Euler-Maruyama steps of one launch from the fused summaries (exact integer sums inside)."""
+    import torch
+    s = summary.double()
+    tau = tau.double() - (0.5 * dt if bridge else 0.0)   # RTs carry a uniform sub-step jitter in bridge mode (mean -dt/2)
+    n_resp = s[:, 0] + s[:, 1]
+    mean_k = torch.where(n_resp > 0, (s[:, 3] - tau) / dt, torch.zeros_like(tau))
+    return float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
+
+
+def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast):
+    """The step loop with every lane useful: the SAME kernel on a workload whose trials all run to the step cap
+    (no refill, no idle lanes, same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane
+    efficiency it was measured at (executed-block counter of the kernel)."""
+    max_k = engine.max_k_of(a.max_steps)
+    N = a.trials
+    B = int(max(2048, min(400_000, 4.8e10 / (N * max_k))))
+    p = torch.tensor([LOCKSTEP_ROW[a.model]] * B, dtype=torch.float32, device=dev)
+    summ = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    _lib.check(L.nddm_set_tuning(1, 0, 64, 64, 0, 0))          # never leave the loop early: refill only when all lanes are done
+    try:
+        run = lambda: engine.simulate(model_id, p, N, dt=a.dt, max_steps=a.max_steps, seed=7, set_offset=0, fast=fast,
+                                      out_summary=summ, want_trials=False, bridge=bridge)
+        run()
+        dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+        L.nddm_set_debug_counters(dbg.data_ptr())
+        run()
+        torch.cuda.synchronize()
+        L.nddm_set_debug_counters(None)
+        blocks = float(dbg[0].item())
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+    finally:
+        L.nddm_set_tuning(0, 0, 0, 0, 0, 0)
+    steps = float(B) * N * max_k
+    lane_eff = steps / (blocks * 256.0)
+    sps = steps / (best * 1e-3)
+    return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
+            "kernel_ms": best, "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
+
+
+def worker(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,18 +312,38 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    from bayesflow_nddms_amd import engine
+    from bayesflow_nddms_amd import _lib, engine
     from bayesflow_nddms_amd import priors as prior_util
+    ctx = dict(world=world, rank=rank, local_rank=local_rank, dev=dev, torch=torch, dist=dist, engine=engine, _lib=_lib,
+               prior_util=prior_util)
+    if a.train:
+        train_bench(a, ctx)
+    else:
+        simulate_bench(a, ctx)
+    if world > 1:
+        barrier(a, ctx)
+        dist.destroy_process_group()
 
+
+def barrier(a, ctx):
+    if ctx["world"] > 1:
+        if a.backend == "nccl":
+            ctx["dist"].barrier(device_ids=[ctx["local_rank"]])
+        else:
+            ctx["dist"].barrier()
+    ctx["torch"].cuda.synchronize()
+
+
+def simulate_bench(a, ctx):
+    world, rank, dev, torch, dist, engine, _lib, prior_util = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine",
+                                                                                   "_lib", "prior_util"))
     B, N = a.sets, a.trials
     fast = a.gauss == "fast"
+    model_attr, bridge, prior_fn, _, tau_i = MODELS[a.model]
+    model_id = getattr(engine, model_attr)
     # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
     # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
-    model_id = {"basic": engine.BASIC_DDM_DC, "single": engine.SINGLE_TRIAL, "alpha_ns": engine.ALPHA_NOT_SCALED,
-                "alpha_ns_bridge": engine.ALPHA_NOT_SCALED}[a.model]
-    bridge = a.model == "alpha_ns_bridge"
-    p_host = {"basic": prior_util.basic_prior_matrix, "single": prior_util.single_prior_matrix,
-              "alpha_ns": prior_util.alpha_ns_prior_matrix, "alpha_ns_bridge": prior_util.alpha_ns_prior_matrix}[a.model](B, 2023 + rank)
+    p_host = getattr(prior_util, prior_fn)(B, 2023 + rank)
     p_dev = torch.as_tensor(p_host).to(dev)
     out_trials = None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev)
     out_summary = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
@@ -244,112 +364,236 @@ def main():
             else:                                                       # gloo rehearsal: list form
                 dist.all_gather(list(gathered.unbind(0)), src)
 
-    def barrier():
-        if world > 1:
-            if a.backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(a.warmup):
         step(i)
-    barrier()
+    barrier(a, ctx)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record()              # torch's current stream == the stream the kernel is launched on
         step(a.warmup + i)
         ev[i][1].record()
-    barrier()
+    barrier(a, ctx)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    if rank != 0:
+        return
 
-    # executed Euler-Maruyama steps of the last step, from the fused summaries (exact integer sums)
-    s = out_summary.double()
-    tau = p_dev[:, 3].double()
-    if bridge:
-        tau = tau - 0.5 * a.dt      # RTs carry a uniform sub-step jitter in bridge mode (mean -dt/2)
-    n_resp = s[:, 0] + s[:, 1]
     max_k = engine.max_k_of(a.max_steps)
-    mean_k = torch.where(n_resp > 0, (s[:, 3] - tau) / a.dt, torch.zeros_like(tau))
-    em_steps = float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
-    p_missing = float((s[:, 2].sum() / (B * N)).item())
-
-    if rank == 0:
-        trials_per_step = world * B * N
-        value = trials_per_step * a.steps / elapsed
-        alg_bytes = B * N * (0 if a.summary_only else 8) + B * (p_host.shape[1] * 4 + engine.SUMMARY_K * 4)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        res = {
-            "metric": f"simulated DDM trials/sec at n_trials={N} dt={a.dt:g} ({a.model if a.model != 'basic' else 'basic_ddm_dc'}, max_steps={a.max_steps:g})",
-            "value": value, "unit": "trials/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'basic_ddm_dc' if a.model == 'basic' else a.model} HIP simulator, {B} parameter sets x {N} trials per GPU per step, "
-                                   f"dt={a.dt}, max_steps={a.max_steps:g}, params ~ reference prior (default_rng 2023)",
-                       "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
-                       "gauss": a.gauss, "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
-                       "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "nddm::sim_kernel<%s, %s>" % (a.model, "fast" if fast else "exact"),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
-            "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
-            "p_missing": p_missing,
-        }
-        tr = None if (a.summary_only or a.model != "basic") else pmc_traffic(B, N)
-        if tr:
-            res["roofline"]["traffic"] = tr["bytes"]
-            res["roofline"]["traffic_source"] = tr["source"]
-        cpb = VALU_MODEL["cycles_per_block_fast" if fast else "cycles_per_block_exact"]
-        if cpb and a.model == "basic":
-            # a wave64 advances 64 lanes x 4 steps per block; ceiling assumes every lane useful
-            peak_steps = VALU_MODEL["simds"] * VALU_MODEL["clock_ghz"] * 1e9 / cpb * 64 * 4
-            res["roofline_valu"] = {"bound": "valu", "achieved": em_steps / (kern_ms * 1e-3) / 1e9,
-                                    "peak": peak_steps / 1e9, "unit": "G E-M steps/s",
-                                    "frac": em_steps / (kern_ms * 1e-3) / peak_steps,
-                                    "issue_cycles_per_block": cpb, "clock_ghz": VALU_MODEL["clock_ghz"],
-                                    "ceiling": "step loop with every lane useful (measured lockstep run)",
-                                    "sum_of_isolated_issue_costs": VALU_MODEL["sum_of_issue_costs_fast" if fast
-                                                                              else "sum_of_issue_costs_exact"]}
-        if world == 1 and "roofline_valu" in res:
-            # steps the lanes actually EXECUTED (incl. lanes idling on a finished trial until the next refill): one more
-            # launch of the last batch, outside the timed region, with the kernel's debug counters switched on
-            from bayesflow_nddms_amd import _lib
-            dbg = torch.zeros(8, dtype=torch.int64, device=dev)
-            _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d0.record()
-            step(a.warmup + a.steps - 1)
-            d1.record()
-            torch.cuda.synchronize()
-            dbg_ms = d0.elapsed_time(d1)
-            _lib.lib().nddm_set_debug_counters(None)
-            d = dbg.cpu().numpy().astype(np.float64)
-            res["roofline_valu"].update({"executed_lane_steps_per_launch": d[0] * 256.0,
-                                         "lane_efficiency": em_steps / (d[0] * 256.0),
-                                         "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
-            cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
-            resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / (4.0 * cus)
-            res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": int(d[4]),
-                                "limit": "SGPR file: 73 SGPRs per wave -> 8 wave64 per SIMD for this kernel, 75-83 -> 7 for the other models (DESIGN.md 5.1)",
-                                "note": "from in-kernel wave lifetimes; PMC SQ_WAVE_CYCLES agrees (profiles/r1_summary.md)"}
-        if world == 1 and not a.no_ks and a.model == "basic":
-            res["ks_vs_ref"] = ks_vs_golden(engine, a.dt, a.max_steps, fast)
-        if world == 1 and not a.no_cpu_baseline and a.model == "basic":
-            res["cpu_baseline"] = cpu_baseline(p_host, N, a.dt, a.max_steps, a.cpu_seconds)
+    em_steps = em_steps_of(out_summary, p_dev[:, tau_i], a.dt, max_k, bridge)      # of the last step's launch
+    p_missing = float((out_summary[:, 2].sum() / (B * N)).item())
+    trials_per_step = world * B * N
+    value = trials_per_step * a.steps / elapsed
+    P = p_host.shape[1]
+    alg_bytes = B * N * (0 if a.summary_only else 8) + B * (P * 4 + engine.SUMMARY_K * 4)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    name = "basic_ddm_dc" if a.model == "basic" else a.model
+    res = {
+        "metric": f"simulated DDM trials/sec at n_trials={N} dt={a.dt:g} ({name}, max_steps={a.max_steps:g})",
+        "value": value, "unit": "trials/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name} HIP simulator, {B} parameter sets x {N} trials per GPU per step, "
+                               f"dt={a.dt}, max_steps={a.max_steps:g}, params ~ reference prior (default_rng 2023)",
+                   "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
+                   "gauss": a.gauss, "arithmetic": ARITHMETIC,
+                   "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
+                   "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": KERNEL_NAME[a.model] % ("fast" if fast else "exact"),
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
+        "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
+        "p_missing": p_missing,
+    }
+    tr = None if a.summary_only else pmc_traffic(a.model, B, N)
+    if tr:
+        res["roofline"]["traffic"] = tr["bytes"]
+        res["roofline"]["traffic_source"] = tr["source"]
+    if world == 1:
+        achieved_steps = em_steps / (kern_ms * 1e-3)
+        rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
+        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        if not a.no_ceiling:
+            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast)
+            peak = c["steps_per_s_all_lanes_useful"]
+            rv.update({"peak": peak / 1e9, "frac": achieved_steps / peak,
+                       "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
+                       "ceiling_measured_steps_per_s": c["steps_per_s"], "ceiling_lane_efficiency": c["lane_efficiency"],
+                       "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"],
+                       "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 256.0 / peak})
+        im = issue_model(a.model, fast)
+        if im:
+            peak_im = simds * CLOCK_GHZ * 1e9 / im["cycles_per_block"] * 256.0
+            rv.update({"issue_model": im, "peak_issue_model": peak_im / 1e9, "frac_vs_issue_model": achieved_steps / peak_im})
+            if "frac" not in rv:
+                rv.update({"peak": peak_im / 1e9, "frac": achieved_steps / peak_im, "ceiling": "ISA issue model (no lockstep run)"})
+        res["roofline_valu"] = rv
+        # steps the lanes actually EXECUTED (incl. lanes idling on a finished trial until the next refill): one more
+        # launch of the last batch, outside the timed region, with the kernel's debug counters switched on
+        dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+        _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0.record()
+        step(a.warmup + a.steps - 1)
+        d1.record()
+        torch.cuda.synchronize()
+        dbg_ms = d0.elapsed_time(d1)
+        _lib.lib().nddm_set_debug_counters(None)
+        d = dbg.cpu().numpy().astype(np.float64)
+        lane_steps = d[0] * 256.0
+        rv.update({"executed_lane_steps_per_launch": lane_steps, "lane_efficiency": em_steps / lane_steps,
+                   "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
+        resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / (4.0 * cus)
+        res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": int(d[4]),
+                            "limit": "SGPR file (800 per SIMD, a wave is charged its SGPRs + 22 rounded up to 16): <= 74 SGPRs -> 8 wave64 "
+                                     "per SIMD; tools/resource_table.py lists every kernel",
+                            "note": "from in-kernel wave lifetimes (s_memrealtime); PMC SQ_WAVE_CYCLES in profiles/ agrees"}
+        if not a.no_ks:
+            res["ks_vs_ref"] = ks_vs_golden(engine, a.model, a.dt, a.max_steps, fast)
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a, p_host, a.model, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        barrier()
-        dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
+
+
+# --------------------------------------------------------------------------------------------------- config 5
+def train_bench(a, ctx):
+    """BASELINE config 5: basic_ddm_dc online simulation feeding the amortizer (PyTorch-ROCm DeepSet + coupling flow),
+    the reference's training loop shape (basic_ddm_dc.py:199-202: batch 32, N ~ U{60..300} shared by the batch, dt=.01
+    / max_steps=400), simulation sharded over the ranks with ONE all-gather per minibatch.  Per rank and step: draw 32
+    parameter sets on the device (counter-based prior), simulate them, all-gather trials + parameters, one Adam step on
+    the gathered minibatch of 32*G sets (every rank holds the same batch and the same weights: no gradient exchange).
+    Reports iterations/s for prefetch off/on, the simulate launch in isolation (eager and as a hipGraph replay), and the
+    simulator's share of a step."""
+    world, rank, dev, torch, dist, engine = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine"))
+    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    from bayesflow_nddms_amd.distributed import shared_prior_N
+    from bayesflow_nddms_amd.priors import DevicePrior
+    Bl = a.batch
+    results = {}
+    for tag, dt, ms in (("dt.01_max400", 0.01, 400.0), ("dt.001_max4000", 0.001, 4000.0)):
+        prior = DevicePrior("basic", seed=2023)
+        counter = {"i": 0}
+
+        def generative_model(batch_size, dt=dt, ms=ms, prior=prior, counter=counter):
+            i = counter["i"]; counter["i"] += 1
+            n = shared_prior_N(2023, i)                                   # batch-shared N, no communication
+            base = i * batch_size * world
+            p = prior(batch_size, set_offset=base + rank * batch_size)    # this rank's rows of the global batch
+            r = engine.simulate(engine.BASIC_DDM_DC, p, n, dt=dt, max_steps=ms, seed=2023,
+                                set_offset=base + rank * batch_size, fast=True, want_summary=False)
+            data, pd = r["trials"], p
+            if world > 1:
+                gd = torch.empty((world,) + tuple(data.shape), dtype=torch.float32, device=dev)
+                gp = torch.empty((world,) + tuple(p.shape), dtype=torch.float32, device=dev)
+                if a.backend == "nccl":
+                    dist.all_gather_into_tensor(gd, data); dist.all_gather_into_tensor(gp, p)
+                else:
+                    dist.all_gather(list(gd.unbind(0)), data); dist.all_gather(list(gp.unbind(0)), p)
+                data, pd = gd.reshape(-1, n, 2), gp.reshape(-1, p.shape[1])
+            return {"prior_draws": pd, "sim_data": data, "sim_non_batchable_context": n}
+
+        leg = {}
+        for prefetch in (False, True):
+            torch.manual_seed(0)
+            amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+            trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, device=dev)
+            counter["i"] = 0
+            trainer.train_online(epochs=1, iterations_per_epoch=10, batch_size=Bl, save_checkpoint=False, prefetch=prefetch)
+            barrier(a, ctx)
+            t0 = time.perf_counter()
+            trainer.train_online(epochs=1, iterations_per_epoch=a.train_iters, batch_size=Bl, save_checkpoint=False,
+                                 prefetch=prefetch)
+            barrier(a, ctx)
+            el = time.perf_counter() - t0
+            h = trainer.loss_history
+            leg["prefetch_on" if prefetch else "prefetch_off"] = {
+                "iterations_per_s": a.train_iters / el, "ms_per_iteration": el / a.train_iters * 1e3,
+                "loss_first10": float(np.mean(h[10:20])), "loss_last10": float(np.mean(h[-10:]))}
+        # training step alone on a fixed batch (no simulation): what is left of an iteration is the simulator's share
+        fixed = basic_ddm_dc.configurator(generative_model(Bl))
+        for _ in range(5):
+            trainer._step(fixed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.train_iters):
+            trainer._step(fixed)
+        torch.cuda.synchronize()
+        t_train = (time.perf_counter() - t0) / a.train_iters
+        leg["train_step_alone_ms"] = t_train * 1e3
+        leg["simulator_share_of_step_no_prefetch"] = max(0.0, 1.0 - t_train / (leg["prefetch_off"]["ms_per_iteration"] * 1e-3))
+        leg["simulator_share_of_step_prefetch"] = max(0.0, 1.0 - t_train / (leg["prefetch_on"]["ms_per_iteration"] * 1e-3))
+        # the simulate launch in isolation at the mean shape (Bl sets x 180 trials, device-resident): eager vs graph replay
+        p = prior(Bl, set_offset=0)
+        out = torch.empty((Bl, 180, 2), dtype=torch.float32, device=dev)
+        kw = dict(dt=dt, max_steps=ms, seed=2023, set_offset=0, fast=True, out_trials=out, want_summary=False)
+        for _ in range(20):
+            engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+        torch.cuda.synchronize()
+        n_rep = 500
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+        t_host = (time.perf_counter() - t0) / n_rep                     # host time to enqueue
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t0) / n_rep
+        side = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+        torch.cuda.synchronize()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            g.replay()
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / n_rep
+        # one launch, GPU time only
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        leg["simulate_launch_us"] = {"shape": f"{Bl} sets x 180 trials, device-resident parameters", "eager_back_to_back": t_eager * 1e6,
+                                     "eager_host_enqueue": t_host * 1e6, "hipgraph_replay": t_graph * 1e6,
+                                     "gpu_time_back_to_back": e0.elapsed_time(e1) / 50 * 1e3}
+        del g
+        results[tag] = leg
+    if rank == 0:
+        ref = results["dt.01_max400"]["prefetch_on"]
+        print(json.dumps({
+            "metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE config 5)",
+            "value": ref["iterations_per_s"], "unit": "iterations/s", "n_gpus": world, "steps": a.train_iters, "warmup": 10,
+            "ms_per_step": ref["ms_per_iteration"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"basic_ddm_dc online training feed: {Bl} sets per rank per step (minibatch {Bl * world}), "
+                                   f"N ~ U{{60..300}} per batch, dt=.01/max 400 (reference default; dt=.001/4000 also reported), "
+                                   f"device prior -> simulate -> all-gather -> DeepSet + 6-layer coupling flow, Adam",
+                       "arithmetic": ARITHMETIC, "parallelism": f"dp{world}: simulation sharded, one all-gather per minibatch, "
+                                                                  f"replicated training step", "backend": a.backend},
+            "train": results}), flush=True)
+
+
+def main():
+    a = parse()
+    if a.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a.gpus)                         # does not return
+    worker(a)
 
 
 if __name__ == "__main__":

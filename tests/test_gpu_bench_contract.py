@@ -29,4 +29,74 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["ks_vs_ref"]["max"] < 0.01
-    assert 0 < d["roofline_valu"]["frac"] < 1.0
+    rv = d["roofline_valu"]
+    assert 0 < rv["frac"] < 1.05 and rv["ceiling_measured_steps_per_s"] > 0           # ceiling measured in the same run
+    assert "arithmetic" in d["config"] and d["cpu_baseline"]["numpy_port"]["reference_default"]["dt"] == 0.01
+
+
+@pytest.mark.parametrize("model", ["single", "alpha_ns_bridge"])
+def test_bench_other_models_carry_the_same_objects(model):
+    """configs[2] / configs[3] are measured the way configs[1] is: KS against the reference fixtures, CPU oracle
+    baseline of the same model, lockstep ceiling."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--steps", "2", "--warmup", "1",
+                        "--sets", "30000", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert model in d["metric"] and d["ks_vs_ref"]["max"] < 0.01 and d["cpu_baseline"]["value"] > 0
+    assert 0 < d["roofline_valu"]["frac"] < 1.05 and d["occupancy"]["resident_waves_per_simd"] > 3
+
+
+def _bench(*args, timeout=600, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("gather", ["none", "summary"])
+def test_bench_gpus_2_starts_two_ranks(gather):
+    """`python bench.py --gpus 2` starts its two ranks itself (fresh processes) and rank 0 prints ONE line with n_gpus 2
+    and the aggregate of both ranks.  On a one-GPU box the ranks share cuda:0 over gloo (the rehearsal mode)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = _bench("--gpus", "2", "--share-device", "--backend", "gloo", "--sets", "20000", "--steps", "2", "--warmup", "1",
+               "--gather", gather, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and f"gather={gather}" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 20000 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for():
+    """--gpus N must describe the job that runs: under a launcher with another WORLD_SIZE the bench exits non-zero instead
+    of silently measuring something else."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = _bench("--gpus", "2", "--sets", "1000", "--steps", "1", "--warmup", "0", env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_fresh_ranks_union_equals_unsharded(tmp_path):
+    """Two fresh child ranks (gloo, both on cuda:0) simulate their shards with the HIP engine: what every rank holds after
+    the all-gather -- and the concatenation of the ungathered shards -- equals the unsharded launch bit for bit."""
+    import socket
+    import torch
+    import prior_util
+    from bayesflow_nddms_amd import engine
+    B, N = 1001, 77
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(tmp_path), str(B), str(N)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    p_dev = torch.as_tensor(prior_util.basic_prior(B, 21)).cuda()
+    full = engine.simulate(engine.BASIC_DDM_DC, p_dev, N, seed=31, set_offset=12345, dt=0.001, max_steps=4000, fast=True)
+    ft, fs = full["trials"].cpu(), torch.nan_to_num(full["summary"].cpu())
+    shards = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2)]
+    for sh in shards:
+        assert torch.equal(sh["both"]["trials"], ft) and torch.equal(torch.nan_to_num(sh["both"]["summary"]), fs)
+    assert shards[0]["none"]["rows"] == (0, 501) and shards[1]["none"]["rows"] == (501, 1001)
+    assert torch.equal(torch.cat([sh["none"]["trials"] for sh in shards]), ft)
+    assert torch.equal(torch.nan_to_num(torch.cat([sh["none"]["summary"] for sh in shards])), fs)

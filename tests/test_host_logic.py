@@ -203,3 +203,21 @@ def test_shard_bounds_cover_and_partition():
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert shared_prior_N(3, 5) == shared_prior_N(3, 5) and 60 <= shared_prior_N(3, 6) <= 300
+
+
+def test_bench_launcher_without_gpu_fails_loudly():
+    """bench.py --gpus 2 starts two fresh ranks; on a box without a GPU both refuse loudly (no CPU fallback) and the
+    launcher exits non-zero; a WORLD_SIZE that contradicts --gpus is refused before anything else happens."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sets", "10", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stderr.count("needs a ROCm GPU") >= 1 and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--sets", "10", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr

@@ -1,92 +1,183 @@
 #!/usr/bin/env python3
-"""VALU issue-cost model of the step loop: tally the instructions of the innermost loop of a sim_kernel
-instantiation (from hipcc -S) and weight them with the per-instruction issue costs measured by tools/ubench_valu
-(profiles/*_ubench_valu.txt, 8 waves/SIMD column).  Prints SIMD cycles per wave64 Philox block (= 4 E-M steps x 64 lanes).
+"""First-principles VALU issue model of the step loop, from the SHIPPED library.
 
-Usage: python tools/isa_mix.py [mangled-kernel-substring]   (default: basic_ddm_dc, fast, CAP4, no bridge)
+Carves the gfx950 code object out of bayesflow_nddms_amd/libnddm_hip.so (the clang offload bundle inside the ELF),
+disassembles it with llvm-objdump, finds the step loop of a sim_kernel instantiation -- the smallest backward-branch
+region holding the 16 Philox multiplies -- tallies its instructions and weights them with the per-instruction issue
+costs measured by tools/ubench_valu on the MI355X (profiles/*_ubench_valu.txt, 8 waves/SIMD column).  The result is SIMD
+cycles per wave64 Philox block (= 4 Euler-Maruyama steps x 64 lanes): an ISA-level ceiling that does not come from timing
+the kernel itself.  bench.py reads profiles/<tag>_issue_model.json and reports `roofline_valu.frac_vs_issue_model`.
+
+Usage: python tools/isa_mix.py [--json profiles/r2_issue_model.json] [--ubench profiles/r2_ubench_valu.txt] [kernel ...]
+       kernel = basic | single | single_alt | alpha_ns | alpha_ns_bridge | explicit (fast transform), or *_exact
 """
 import collections
+import glob
+import hashlib
+import json
 import os
 import re
+import struct
 import subprocess
 import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# measured on MI355X (profiles/r1_ubench_valu.txt), cycles per wave64 instruction per SIMD at 8 waves/SIMD
-COST = {"v_mad_u64_u32": 4.67, "v_xor_b32": 2.32, "v_cvt_f32_u32": 4.12, "v_cvt_f32_i32": 4.12, "v_log_f32": 8.17,
-        "v_sqrt_f32": 8.19, "v_sin_f32": 8.14, "v_cos_f32": 8.15, "v_exp_f32": 8.15, "v_rcp_f32": 8.14,
-        "v_fma_f32": 3.77, "v_fmamk_f32": 3.77, "v_fmac_f32": 2.34, "v_fmaak_f32": 3.77, "v_add_f32": 2.26,
-        "v_sub_f32": 2.26, "v_mul_f32": 2.24, "v_add_u32": 2.35, "v_sub_u32": 2.35, "v_subrev_u32": 2.35,
-        "v_lshrrev_b32": 2.32, "v_lshlrev_b32": 2.32, "v_and_b32": 2.32, "v_or_b32": 2.32, "v_alignbit_b32": 2.32,
-        "v_cndmask_b32": 2.32, "v_add3_u32": 2.35, "v_mov_b32": 2.32, "v_cmp": 4.13, "v_mul_lo_u32": 4.23,
-        "v_mul_hi_u32": 4.26, "v_bfe_u32": 2.32, "v_and_or_b32": 2.32, "v_floor_f32": 2.3, "v_cvt_i32_f32": 4.12,
-        "v_lshl_add_u32": 4.2, "v_addc_co_u32": 4.2, "v_max_f32": 2.26, "v_min_f32": 2.26, "v_med3_f32": 3.77}
-# measured: a VOP2 integer/float op that reads an SGPR (or VCC) operand, and the 3-operand integer VOP3 forms, issue at
-# ~4.2 cycles instead of ~2.3 (profiles/r1_ubench_valu.txt rows "v_xor_b32 (sgpr)", v_add3_u32, v_alignbit_b32,
-# "v_cndmask_e64 (s)")
-COST.update({"v_add3_u32": 4.22, "v_alignbit_b32": 4.15, "v_cndmask_b32": 4.22, "v_pk_fma_f32": 4.19, "v_pk_mul_f32": 4.19,
-             "v_pk_add_f32": 4.20, "v_bitop3_b32": 3.84, "v_add_co_u32": 4.23})
-SGPR_OPERAND_COST = 4.16
+SO = os.path.join(ROOT, "bayesflow_nddms_amd", "libnddm_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+# template arguments <MODEL, FAST, CAP4, BRIDGE> of the instantiations the named workloads launch (max_steps % 4 == 0)
+KERNELS = {"basic": (0, 1, 1, 0), "single": (1, 1, 1, 0), "single_alt": (2, 1, 1, 0), "alpha_ns": (3, 1, 1, 0),
+           "alpha_ns_bridge": (3, 1, 1, 1), "explicit": (4, 1, 1, 0)}
+KERNELS.update({k + "_exact": (m, 0, c, b) for k, (m, f, c, b) in list(KERNELS.items())})
+
+# fallback costs (profiles/r1_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
+COST = {"v_mad_u64_u32": 4.69, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
+        "v_sqrt_f32": 8.15, "v_sin_f32": 8.11, "v_cos_f32": 8.23, "v_exp_f32": 8.21, "v_rcp_f32": 8.21,
+        "v_fma_f32": 3.82, "v_fmamk_f32": 3.82, "v_fmac_f32": 2.34, "v_fmaak_f32": 3.82, "v_add_f32": 2.27,
+        "v_sub_f32": 2.27, "v_mul_f32": 2.27, "v_add_u32": 2.35, "v_sub_u32": 2.35, "v_subrev_u32": 2.35,
+        "v_lshrrev_b32": 2.34, "v_lshlrev_b32": 2.34, "v_and_b32": 2.34, "v_or_b32": 2.34, "v_mov_b32": 2.34,
+        "v_cmp": 4.05, "v_mul_lo_u32": 4.47, "v_mul_hi_u32": 4.22, "v_bfe_u32": 4.19, "v_and_or_b32": 4.19,
+        "v_cvt_i32_f32": 4.13, "v_lshl_add_u32": 4.19, "v_addc_co_u32": 4.22, "v_max_f32": 2.27, "v_min_f32": 2.27,
+        "v_med3_f32": 3.82, "v_add3_u32": 4.49, "v_alignbit_b32": 4.19, "v_cndmask_b32": 4.23, "v_pk_fma_f32": 4.16,
+        "v_pk_mul_f32": 4.23, "v_pk_add_f32": 4.21, "v_bitop3_b32": 3.81, "v_add_co_u32": 4.22, "v_lshl_or_b32": 4.19}
+SGPR_OPERAND_COST = 4.16           # a full-rate VOP2 op that reads an SGPR / VCC operand ("v_xor_b32 (sgpr)" row)
 FULL_RATE = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_add_f32", "v_sub_f32",
-             "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"}
+             "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32", "v_fmac_f32", "v_max_f32", "v_min_f32"}
 DEFAULT = 2.4
+UBENCH_ROWS = {"v_fma_f32": ["v_fma_f32", "v_fmamk_f32", "v_fmaak_f32", "v_med3_f32"], "v_add_f32": ["v_add_f32", "v_sub_f32", "v_max_f32", "v_min_f32"],
+               "v_mul_f32": ["v_mul_f32"], "v_xor_b32": ["v_xor_b32", "v_and_b32", "v_or_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"],
+               "v_add_u32": ["v_add_u32", "v_sub_u32", "v_subrev_u32"], "v_mul_lo_u32": ["v_mul_lo_u32"], "v_mul_hi_u32": ["v_mul_hi_u32"],
+               "v_mad_u64_u32": ["v_mad_u64_u32"], "v_log_f32": ["v_log_f32", "v_exp_f32"], "v_sqrt_f32": ["v_sqrt_f32"],
+               "v_sin_f32": ["v_sin_f32"], "v_cos_f32": ["v_cos_f32"], "v_rcp_f32": ["v_rcp_f32"],
+               "v_cvt_f32_u32": ["v_cvt_f32_u32", "v_cvt_f32_i32", "v_cvt_i32_f32"], "v_cmp_lt_f32": ["v_cmp"],
+               "v_add3_u32": ["v_add3_u32"], "v_alignbit_b32": ["v_alignbit_b32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_lshl_or_b32"],
+               "v_cndmask_e64 (s)": ["v_cndmask_b32"], "v_pk_fma_f32": ["v_pk_fma_f32"], "v_pk_mul_f32": ["v_pk_mul_f32"],
+               "v_pk_add_f32": ["v_pk_add_f32"], "v_bitop3_b32 (xor3)": ["v_bitop3_b32"], "v_fmac_f32": ["v_fmac_f32"],
+               "v_add_co_u32_e64": ["v_add_co_u32", "v_addc_co_u32"]}
+
+
+def load_ubench(path):
+    """Per-instruction issue costs from a tools/ubench_valu run (last numeric column = 8 waves/SIMD)."""
+    cost, sgpr = dict(COST), SGPR_OPERAND_COST
+    if not path or not os.path.exists(path):
+        return cost, sgpr, None
+    for line in open(path):
+        m = re.match(r"^(.+?)\s{2,}([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+clock", line)
+        if not m:
+            continue
+        name, c8 = m.group(1).strip(), float(m.group(5))
+        if name == "v_xor_b32 (sgpr)":
+            sgpr = c8
+        for op in UBENCH_ROWS.get(name, []):
+            cost[op] = c8
+    return cost, sgpr, os.path.basename(path)
+
+
+def code_object(so_path):
+    """The gfx950 code object inside the library's clang offload bundle."""
+    data = open(so_path, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    if i < 0:
+        raise RuntimeError("no offload bundle in " + so_path)
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, s, tl = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        triple = data[off:off + tl].decode()
+        off += tl
+        if "gfx950" in triple:
+            return data[i + o:i + o + s], hashlib.sha256(data).hexdigest()[:16]
+    raise RuntimeError("no gfx950 code object in " + so_path)
+
+
+def disassemble(so_path=SO):
+    co, digest = code_object(so_path)
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "k.co")
+        open(p, "wb").write(co)
+        txt = subprocess.run([OBJDUMP, "-d", p], capture_output=True, text=True, check=True).stdout
+    return txt, digest
+
+
+def kernel_insts(txt, targs):
+    """[(address, mnemonic, operand text, branch target or None)] of one sim_kernel instantiation."""
+    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
+    lines = txt.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.endswith(f"<{sym}>:"))
+    insts = []
+    for l in lines[start + 1:]:
+        if re.match(r"^[0-9a-f]+ <", l):
+            break
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*// ([0-9A-F]+):", l)
+        if not m:
+            continue
+        tgt = re.search(r"<" + re.escape(sym) + r"\+0x([0-9a-f]+)>", l)
+        insts.append((int(m.group(3), 16), m.group(1), m.group(2), None if not tgt else int(tgt.group(1), 16)))
+    base = insts[0][0]
+    return [(a - base, op, args, t) for a, op, args, t in insts]
+
+
+def step_loop(insts):
+    """Smallest backward-branch region with >= 16 v_mad_u64_u32 and two Box-Muller pairs (2 v_sqrt_f32): the step loop
+    (the rejection loop of the per-trial latent also holds a Philox block, but one pair)."""
+    best = None
+    for a, op, args, t in insts:
+        if op.startswith(("s_cbranch", "s_branch")) and t is not None and t <= a:
+            body = [x for x in insts if t <= x[0] <= a]
+            if (sum(x[1].startswith("v_mad_u64_u32") for x in body) >= 16 and sum(x[1].startswith("v_sqrt_f32") for x in body) >= 2
+                    and (best is None or len(body) < len(best))):
+                best = body
+    if best is None:
+        raise RuntimeError("step loop not found")
+    return best
+
+
+def tally(body, cost, sgpr_cost):
+    t = collections.Counter()
+    for _, op, args, _ in body:
+        op = re.sub(r"_e(32|64)$", "", op)
+        if op.startswith("v_cmp"):
+            op = "v_cmp"
+        if op in FULL_RATE and re.search(r"\bs\d+\b|s\[|vcc|exec", args.split(",", 1)[1] if "," in args else ""):
+            op += " (sgpr)"
+        t[op] += 1
+    valu = {k: v for k, v in t.items() if k.startswith("v_")}
+    c = lambda k: sgpr_cost if k.endswith(" (sgpr)") else cost.get(k, DEFAULT)
+    rows = sorted(((k, v, c(k), k in cost or k.endswith(" (sgpr)")) for k, v in valu.items()), key=lambda r: -r[1] * r[2])
+    return {"valu": sum(valu.values()), "salu": sum(v for k, v in t.items() if k.startswith("s_")),
+            "lds": sum(v for k, v in t.items() if k.startswith("ds_")),
+            "vmem": sum(v for k, v in t.items() if k.startswith(("global_", "flat_", "buffer_", "scratch_"))),
+            "cycles_per_block": sum(v * cc for _, v, cc, _ in rows),
+            "mix": [{"op": k, "n": v, "cycles_each": cc, "costed": known} for k, v, cc, known in rows]}
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "sim_kernelILi0ELb1ELb1ELb0EE"
-    src = os.path.join(ROOT, "bayesflow_nddms_amd", "csrc", "nddm_kernels.hip")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        subprocess.check_call(["hipcc", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-std=c++17", "-S",
-                               "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
-        lines = open(out).read().splitlines()
-    # kernel body
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4nddm") and want in l and l.rstrip().endswith(":") or (want in l and ": " in l and l.startswith("_ZN4nddm")))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    body = lines[start:end]
-    # group basic blocks by the loop LLVM's asm comments assign them to ("in Loop: Header=BBx_y" / "Inner Loop Header");
-    # the step loop is the INNERMOST-loop group holding the Philox multiplies
-    groups, cur, headers = collections.defaultdict(list), None, set()
-    for i, l in enumerate(body):
-        if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
-            nxt = body[i + 1] if i + 1 < len(body) else ""
-            m = re.search(r"Header=(BB\d+_\d+)", l)
-            if l.startswith(".LBB") and "Inner Loop Header" in (l + nxt):
-                cur = l.split(":")[0][2:]
-                headers.add(cur)
-            elif m:
-                cur = m.group(1)
-            else:
-                cur = None
-        if cur is not None:
-            groups[cur].append(l)
-    inner = {h: seg for h, seg in groups.items() if h in headers}
-    best = max(inner.values(), key=lambda seg: sum("v_mad_u64_u32" in x for x in seg), default=None)
-    if best is None or sum("v_mad_u64_u32" in x for x in best) < 16:
-        sys.exit("step loop not found")
-    tally = collections.Counter()
-    for l in best:
-        t = l.strip().split()
-        if not t or t[0].startswith((";", ".")) or t[0].endswith(":"):
-            continue
-        op = t[0]
-        if op.startswith("v_cmp"):
-            op = "v_cmp"
-        op = re.sub(r"_e(32|64)$", "", op)
-        if op in FULL_RATE and re.search(r"\bs\d+\b|s\[|vcc|exec", " ".join(t[2:])):
-            op = op + " (sgpr)"
-        tally[op] += 1
-    valu = {k: v for k, v in tally.items() if k.startswith("v_")}
-    def cost(k):
-        return SGPR_OPERAND_COST if k.endswith(" (sgpr)") else COST.get(k, DEFAULT)
-    cyc = sum(cost(k) * v for k, v in valu.items())
-    print(f"kernel {want}: innermost step loop = {len(best)} lines")
-    for k, v in sorted(valu.items(), key=lambda kv: -cost(kv[0]) * kv[1]):
-        print(f"  {k:22s} x{v:3d}  {cost(k):5.2f} cyc  = {cost(k) * v:7.1f}" + ("" if (k in COST or k.endswith(" (sgpr)")) else "   (default cost)"))
-    print(f"VALU instructions per block: {sum(valu.values())}; SALU: {sum(v for k, v in tally.items() if k.startswith('s_'))}")
-    print(f"VALU issue cycles per wave64 block (4 steps x 64 lanes): {cyc:.0f}")
-    print(f"ceiling at 2.4 GHz x 1024 SIMDs: {1024 * 2.4e9 / cyc * 256 / 1e12:.3f} T E-M steps/s")
+    args = sys.argv[1:]
+    out_json = ubench = None
+    if "--json" in args:
+        i = args.index("--json"); out_json = args[i + 1]; del args[i:i + 2]
+    if "--ubench" in args:
+        i = args.index("--ubench"); ubench = args[i + 1]; del args[i:i + 2]
+    if ubench is None:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_ubench_valu.txt")))
+        ubench = cands[-1] if cands else None
+    names = args or ["basic"]
+    cost, sgpr_cost, src = load_ubench(ubench)
+    txt, digest = disassemble()
+    result = {"library_sha256_16": digest, "issue_costs_from": src or "built-in table (profiles/r1_ubench_valu.txt)",
+              "unit": "SIMD cycles per wave64 Philox block (4 E-M steps x 64 lanes), sum of isolated issue costs", "kernels": {}}
+    for name in names:
+        r = tally(step_loop(kernel_insts(txt, KERNELS[name])), cost, sgpr_cost)
+        result["kernels"][name] = r
+        print(f"{name}: step loop = {r['valu']} VALU / {r['salu']} SALU / {r['lds']} LDS / {r['vmem']} VMEM instructions per block")
+        for m in r["mix"]:
+            print(f"  {m['op']:24s} x{m['n']:3d}  {m['cycles_each']:5.2f} cyc  = {m['n'] * m['cycles_each']:7.1f}" + ("" if m["costed"] else "   (default cost)"))
+        print(f"  VALU issue cycles per block: {r['cycles_per_block']:.0f}")
+    if out_json:
+        with open(out_json, "w") as f:
+            json.dump(result, f, indent=1)
+        print("wrote", out_json)
 
 
 if __name__ == "__main__":
