@@ -178,10 +178,28 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
     o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
 }
 
+// Fixed-point terms of the external datum's sums: trunc(z * 2^32) and trunc(z^2 * 2^24) with z clamped to +-2^18, as the
+// oracle computes them through doubles -- here by integer arithmetic on the float's bits (gfx950 has no f64 -> i64
+// conversion: the double route is ~80 instructions per hand-out, this one ~20).  |z| * 2^32 = m * 2^(e-118) with the
+// 24-bit significand m and biased exponent e <= 145: (m << 29) >> (147 - e); z^2 * 2^24 = m^2 * 2^(2e-276):
+// (m^2 << 15) >> (291 - 2e).  Shift counts are clamped to 63, where the (< 2^63) operand has become 0 as it should.
+__device__ __forceinline__ void z_fixed_point(float z, long long &fz, long long &fzz)
+{
+    z = fminf(fmaxf(z, -262144.0f), 262144.0f);
+    const uint32_t b = __float_as_uint(z);
+    const uint32_t e = (b >> 23) & 0xffu;
+    const uint32_t m = (b & 0x007fffffu) | 0x00800000u;
+    const uint32_t s1 = 147u - e, s2 = 291u - 2u * e;
+    const unsigned long long mag = ((unsigned long long)m << 29) >> (s1 < 63u ? s1 : 63u);
+    fz = (b >> 31) ? -(long long)mag : (long long)mag;
+    fzz = (long long)((((unsigned long long)m * m) << 15) >> (s2 < 63u ? s2 : 63u));
+}
+
 // Sum of a 32-bit value over the 64 lanes, in the vector ALU's data-parallel-primitive lanes (no LDS traffic, six adds):
 // row_shr 1, 2, 4, 8 leave each 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it into the next rows; lanes
 // whose DPP source lies outside the row read the `old` operand, 0.  The wave's total ends up in lane 63.  Needs all 64
-// lanes active.  (The shuffle-based wave_sum above costs six ds_bpermute round trips per value.)
+// lanes active; the caller reads the result in lane 63.  (The shuffle-based wave_sum above costs six ds_bpermute round
+// trips per value.)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
 {
@@ -195,7 +213,7 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
     v = dpp_add<0x118, 0xf>(v);        // row_shr:8
     v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
     v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return v;                          // lane 63 holds the total (kept in a VGPR: SGPRs are what limits residency)
 }
 
 // Integer partial sums of one tile, as the simulator leaves them for combine_partials_kernel (which adds the tiles of a
@@ -263,21 +281,27 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
         }
     }
     if (Ap->out_summary) {
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
         if constexpr (SMALL) {
             cnt3 = wave_sum_dpp(cnt3);
-            n_up = (int)(cnt3 & 1023u); n_lo = (int)((cnt3 >> 10) & 1023u); n_miss = (int)(cnt3 >> 20);
-            sk = wave_sum_dpp(sk32); sk_up = wave_sum_dpp(sk_up32);
-            sk2 = ((unsigned long long)wave_sum_dpp(sk2_32 >> 16) << 16) + wave_sum_dpp(sk2_32 & 0xffffu);
-            sk2_up = ((unsigned long long)wave_sum_dpp(sk2_up32 >> 16) << 16) + wave_sum_dpp(sk2_up32 & 0xffffu);
+            sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
+            const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
+            const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
+            if (lane == WAVE - 1) {                          // the DPP reductions leave the totals in the last lane
+                q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
+                       ((unsigned long long)(cnt3 >> 20) << 42);
+                q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
+                q[3] = sk_up32; q[4] = ((unsigned long long)u_hi << 16) + u_lo;
+                if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
+            }
         } else {
             n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
             sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-        }
-        if (lane == 0) {
-            unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
-            q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
-            q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
-            if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
+            if (lane == 0) {
+                q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
+                q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
+                if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
+            }
         }
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
@@ -305,14 +329,17 @@ enum { D_MU = 0, D_INVS = 1, D_H = 2, D_W0 = 3,      // (in noise units) drift*d
        D_BCA = 12, D_BCB = 13, D_BHP1K = 14, D_BX1 = 15, // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
        DV = 16 };                                    // tile within its set, in-call set index
 
-// MODEL: enum nddm_model.  FAST: Gaussian transform.  CAP4: max_steps is a multiple of 4, so the step cap is tested
+// MODEL: enum nddm_model.  FAST: Gaussian transform.  SMALL: see below.  CAP4: max_steps is a multiple of 4, so the step cap is tested
 // once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
 // points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
 // the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
 // generator is an exact first-passage sampler.
 // (Tried and dropped: Philox round keys in VGPRs.  A VOP2 xor that reads an SGPR issues at ~4.2 instead of ~2.3
 // cycles on gfx950, but the 20 extra VGPRs cut residency from 7 to 5 waves per SIMD and the net was neutral.)
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE>
+// SMALL: results staged as 16-bit words and at most 512 trials per tile -- the shape of every launch that matters for
+// throughput.  A kernel that carries BOTH flush paths (32-bit DPP sums / 64-bit shuffles) needs 79 SGPRs and 60 VGPRs; the
+// SMALL one alone 72 and 44, which is what keeps 8 waves per SIMD resident (the SGPR file limits these kernels).
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -448,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
             const int slot = tile & ring_mask;
-            if (fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
+            if (SMALL || fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
             else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
             atomicAdd(&cnt[slot], 1);
         }
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
-                if (fresh_args(Ak)->res16 == 2)
+                if constexpr (SMALL)
                     flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
                                                  res_h + (size_t)slot * N, zsum + 2 * slot, kbase);
                 else
@@ -554,13 +581,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                         if (H->out_trials) H->out_trials[((long long)d2.w * H->n_total + trial) * 2 + 1] = zout;
                         if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
                             if (H->out_summary) {
-                                double zd = (double)zout;
-                                zd = zd > 1.0e6 ? 1.0e6 : zd;
-                                zd = zd < -1.0e6 ? -1.0e6 : zd;
-                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]),
-                                          (unsigned long long)(long long)(zd * 4294967296.0));
-                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]),
-                                          (unsigned long long)(long long)((zd * zd) * 16777216.0));
+                                long long fz, fzz;
+                                z_fixed_point(zout, fz, fzz);
+                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]), (unsigned long long)fz);
+                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]), (unsigned long long)fzz);
                             }
                         }
                     }
@@ -1008,10 +1032,21 @@ static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chu
         if (waves > n_chunks) waves = n_chunks;                                                \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
-    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE>));
-    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE>));
-    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE>));
-    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE>));
+    const bool small = A.res16 == 2;
+    if constexpr (!BRIDGE) {
+        if (small) {
+            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true>));
+            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true>));
+            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true>));
+            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true>));
+        }
+    }
+    if (BRIDGE || !small) {
+        if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, false>));
+        else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, false>));
+        else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, false>));
+        else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, false>));
+    }
 #undef NDDM_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
