@@ -64,8 +64,8 @@ struct SimArgs {
     int n_total;              // trials per set (row stride of out_trials / bounds)
     int tiles_per_set;
     unsigned long long *partials;   // [B * tiles_per_set, partial_words()] integer partial sums of the tiles (summaries requested), else null
-    const int *order;         // [B] processing order of the sets (longest expected trials first) or null = as given
-    const float *params_q;    // [B, P] parameter rows gathered into that order (sequential reads when a tile opens)
+    const uint32_t *recs;     // [B, REC] per-set hand-out records in PROCESSING order (longest expected trials first when
+                              // the launch is large enough to be sorted, else as given): make_record() / prep_kernel
     int max_k;
     float dt;
     float sqrt_dt;
@@ -230,7 +230,7 @@ __host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum
 // Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
 // each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
 template <int MODEL, bool FAST, bool SMALL>
-__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, const float *pp,
+__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, float tau,
                                           const void *res, const long long *zsum, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
@@ -240,7 +240,6 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     const long long set_in_call = TPS == 1 ? vset : vset / TPS;
     const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
     const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
-    const float tau = pp[T::TAU];
     uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
     int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
@@ -308,7 +307,7 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
         if (Ap->out_ext && lane == 0 && t0 == 0) {
             const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
             AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
-            const float loc = (Ap->ext_mode == 0) ? pp[1] : 1.0f;
+            const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
             Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
         }
     }
@@ -321,13 +320,56 @@ __device__ __forceinline__ bool in_range(float w, float h)
     return __builtin_fabsf(w) < h;
 }
 
-// Per-set constants of the trial hand-out, computed ONCE when a tile opens (a hand-out then costs three LDS reads and an
-// xor instead of ~15 VALU instructions per refill): dword index into the tile's DV-dword LDS record.
-enum { D_MU = 0, D_INVS = 1, D_H = 2, D_W0 = 3,      // (in noise units) drift*dt, 1 / unit, boundary/2, centred start point
-       D_CA = 4, D_CB = 5, D_HP1K = 6, D_X1 = 7,     // Philox constants of the set (PathSet in nddm_rng.h)
-       D_C3 = 8, D_SETLO = 9, D_TBASE = 10, D_SIC = 11, // high set word (28 bits), low set word, first trial of the
-       D_BCA = 12, D_BCB = 13, D_BHP1K = 14, D_BX1 = 15, // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
-       DV = 16 };                                    // tile within its set, in-call set index
+// Per-set constants of the trial hand-out.  Everything that is floating-point arithmetic on the parameter row is done
+// ONCE per set by a pre-pass (prep_kernel, or the scatter pass of the longest-first sort) into a REC-dword record, stored
+// in PROCESSING order so that a wave streams them sequentially; the simulator loads the record of the next tile one tile
+// ahead (one 48-byte vector load, consumed a few thousand cycles later) and never reads the parameter rows itself:
+//   r[0..3]  A   basic / alpha_ns / explicit: drift*dt/S (alpha_ns: Nu; per-trial drift), 1/S, a/(2S), (a*beta - a/2)/S
+//                (explicit: beta, 0 in the last two);  single: drift*dt/S, 1/S, std_alpha, mu_alpha;
+//                single_alt (noise scale per trial): drift, alpha, beta, std_dc
+//   r[4..7]  B   single: sigma1, gamma, beta;  single_alt: mu_dc, sigma1, gamma;  alpha_ns: Eta
+//   r[8]     the set's row index in the caller's arrays, r[9] tau
+// S = noise_unit(sqrt(dt) * dc): the state is carried in noise units (nddm_rng.h).
+enum { REC = 12, R_A = 0, R_B = 4, R_SET = 8, R_TAU = 9 };
+
+__device__ __forceinline__ void make_record(int model, bool fast, const float *row, float dt, float sqrt_dt, int set,
+                                            uint32_t *r)
+{
+    float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 1.0f, tau;
+    float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+    switch (model) {
+    case NDDM_BASIC_DDM_DC: drift = row[0]; a = row[1]; beta = row[2]; tau = row[3]; sig_c = row[4]; break;
+    case NDDM_SINGLE_TRIAL: drift = row[0]; beta = row[2]; tau = row[3]; sig_c = row[5]; b0 = row[6]; b1 = row[7]; b2 = row[2]; break;
+    case NDDM_SINGLE_TRIAL_ALT: tau = row[3]; b0 = row[5]; b1 = row[6]; b2 = row[7]; break;
+    case NDDM_ALPHA_NOT_SCALED: a = row[1]; beta = row[2]; tau = row[3]; sig_c = row[5]; b0 = row[4]; break;
+    default: drift = row[0]; beta = row[1]; tau = row[2]; sig_c = row[3]; break;
+    }
+    const float unit = sqrt_dt * sig_c;
+    const float inv_s = 1.0f / (fast ? noise_unit<true>(unit) : noise_unit<false>(unit));
+    const float hv = 0.5f * a;
+    float a0 = (drift * dt) * inv_s, a1 = inv_s, a2 = hv * inv_s, a3 = (a * beta - hv) * inv_s;
+    if (model == NDDM_SINGLE_TRIAL) { a2 = row[4]; a3 = row[1]; }
+    else if (model == NDDM_SINGLE_TRIAL_ALT) { a0 = row[0]; a1 = row[1]; a2 = row[2]; a3 = row[4]; }
+    else if (model == NDDM_ALPHA_NOT_SCALED) { a0 = row[0]; }
+    else if (model == NDDM_EXPLICIT_BOUNDARY) { a2 = beta; a3 = 0.0f; }
+    r[0] = __float_as_uint(a0); r[1] = __float_as_uint(a1); r[2] = __float_as_uint(a2); r[3] = __float_as_uint(a3);
+    r[4] = __float_as_uint(b0); r[5] = __float_as_uint(b1); r[6] = __float_as_uint(b2); r[7] = 0u;
+    r[8] = (uint32_t)set; r[9] = __float_as_uint(tau); r[10] = 0u; r[11] = 0u;
+}
+
+// The tile's record in LDS, as the hand-out reads it (ds_read_b128 each): dword index into its DV dwords.  The first REC
+// dwords are the set's record as loaded (one masked store), the rest is filled in by lane 0 when the tile opens.
+enum { D_A = 0, D_B = 4,                             // r[0..3], r[4..7]
+       D_SIC = 8, D_TAU = 9, D_TBASE = 10, D_VSET = 11, // in-call set index, tau, first trial of the tile within its set,
+                                                     // virtual set (set * tiles_per_set + tile)
+       D_CA = 12, D_CB = 13, D_HP1K = 14, D_X1 = 15, // Philox constants of the set (PathSet in nddm_rng.h)
+       D_C3 = 16, D_SETLO = 17, D_CNT = 18,          // high set word (28 bits), low set word (auxiliary stream's counter);
+                                                     // trials of the tile retired so far
+       D_ZSUM = 20,                                  // [20..23] fixed-point sums of z and z^2 (models with a z summary), or
+       D_BCA = 20, D_BCB = 21, D_BHP1K = 22, D_BX1 = 23 }; // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
+constexpr int DV = 24;                               // one layout for every model: only two LDS base addresses stay live
+static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the loaded record");
+constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,26) | kC kD kE [28,31)
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  SMALL: see below.  CAP4: max_steps is a multiple of 4, so the step cap is tested
 // once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
@@ -351,10 +393,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     const int N = A.n_trials;
     const int ring = A.ring, ring_mask = A.ring - 1;
 
-    // LDS carve-up, one ring slot per in-flight parameter set ("tile"):
-    //   per-set constants of the hand-out | raw parameter row | in-call set index | retire counter | z sums | packed results
-    // bytes [0, 80): the ten Philox round-key pairs (philox4x32_10_ldskeys)
+    // LDS carve-up.  Header (128 bytes): the ten Philox round-key pairs [0, 80) (philox4x32_10_path), debug stamps
+    // [80, 104), the three round keys that fold into the per-trial constants [112, 124).  Then one ring slot per
+    // in-flight parameter set ("tile"): its DV-dword record (hand-out constants, counters, z sums), then the packed results
     if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
+    if (lane == 0) { lds_raw[28] = A.k0 + 2u * PHILOX_W0; lds_raw[29] = A.k1 + 2u * PHILOX_W1; lds_raw[30] = A.k0 + 3u * PHILOX_W0; }
     // LDS byte address of the key table in a VGPR (the low 32 bits of a flat LDS address are the LDS offset); the asm
     // keeps it opaque so that every ds_read in the step loop uses this one register + an immediate offset
     uint32_t kbase;
@@ -362,21 +405,17 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t off = (uint32_t)(size_t)lds_raw;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
     }
-    uint32_t *dv = lds_raw + 28;                                       // [ring][DV], 16-byte aligned (bytes [80, 112): debug stamps)
-    float *lp = reinterpret_cast<float *>(dv + ring * DV);
-    int *slot_set = reinterpret_cast<int *>(lp + ring * P);
-    int *cnt = slot_set + ring;
-    long long *zsum = reinterpret_cast<long long *>(cnt + ring);      // [ring][2]: fixed-point sums of z and z^2
+    uint32_t *dv = lds_raw + LDS_HEADER_DWORDS;                        // [ring][DV], 16-byte aligned
     // staged results: one 32-bit word per trial, or one 16-bit word when the step cap allows (halves the LDS footprint,
-    // which is what lets a 7th wave per SIMD stay resident at 300 trials per set)
-    uint32_t *res = reinterpret_cast<uint32_t *>(zsum + 2 * ring);
+    // which is what lets the 7th and 8th wave per SIMD stay resident at 300 trials per set)
+    uint32_t *res = dv + ring * DV;
     uint16_t *res_h = reinterpret_cast<uint16_t *>(res);
 
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
     float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
     int k = 0;
-    uint32_t trial = 0, set_lo = 0, c3 = 0, jit = 0;   // trial: index within the set (keys the random stream)
+    uint32_t jit = 0;
     uint32_t ltrial = 0;     // index within the tile (LDS slot position)
     int tile = 0;            // wave-local sequence number of the set this lane works on
     bool invalid = false;
@@ -391,14 +430,18 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int flushed = 0;         // tiles already flushed
     int next_tile = 0, next_trial = 0;            // next unassigned trial of the wave's stream
     // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
-    unsigned int retired = 0;                     // trials retired so far
-    unsigned int gate = (unsigned int)N;          // the oldest tile cannot be complete before retired >= gate
+    int to_retire = N;                            // the oldest tile cannot be complete before this many more trials retire
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
-    unsigned int dbg_blocks = 0;                           // per-wave, < 2^32 (the refill count lives in LDS: dbg_stamp[2])
-    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // start clocks, parked in LDS
+    // debug counters live in LDS (SGPRs are scarce): dbg_stamp[2] = refill phases << 32 | step-loop blocks
+    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks
     if (lane == 0) { dbg_stamp[2] = 0; if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); } }
 
-    // open tiles (fetch chunk ids from the global queue, stage the parameter row of each new tile) while ring slots
+    // The record of the NEXT tile of the current chunk, loaded when the tile before it is opened (lanes < REC hold one
+    // dword each): by the time it is consumed the load has long completed, so opening a tile never waits on memory.
+    uint32_t pre = 0u;
+    int pre_row = -1;                             // queue row `pre` belongs to (-1: none)
+
+    // open tiles (fetch chunk ids from the global queue, stage the hand-out record of each new tile) while ring slots
     // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
     // sets its neighbours could be working on (with an eager ring fill, 10,000 sets ended up on 2,500 of the
     // 7,168 waves: 6x slower for mid-size batches)
@@ -416,49 +459,39 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
             }
             const int slot = tile_open & ring_mask;
-            // queue position -> virtual set (set * tiles_per_set + tile), through the longest-first order if present
-            int vset = chunk_set, prow = chunk_set;
-            if (R->tiles_per_set != 1) prow = chunk_set / R->tiles_per_set;
-            const float *row = R->params + (long long)prow * P;
-            if (R->order) {
-                const int qt = chunk_set - prow * R->tiles_per_set;      // tile within the set (0 when not tiled)
-                row = R->params_q + (long long)prow * P;                 // rows are stored in queue order: sequential
-                vset = R->order[prow] * R->tiles_per_set + qt;
+            // queue position -> queue row (position / tiles_per_set) -> its record
+            const int TPS = R->tiles_per_set;
+            const int prow = TPS == 1 ? chunk_set : chunk_set / TPS;
+            const int qt = chunk_set - prow * TPS;                       // tile within the set (0 when not tiled)
+            uint32_t rec = pre;
+            if (pre_row != prow) rec = lane < REC ? R->recs[(long long)prow * REC + lane] : 0u;
+            if (chunk_left > 1) {                                        // prefetch the next tile's record
+                const int nrow = TPS == 1 ? chunk_set + 1 : (chunk_set + 1) / TPS;
+                if (nrow != prow) pre = lane < REC ? R->recs[(long long)nrow * REC + lane] : 0u;
+                else pre = rec;
+                pre_row = nrow;
             }
-            if (lane < P) lp[slot * P + lane] = row[lane];
-            if (lane == 0) { slot_set[slot] = vset; cnt[slot] = 0; zsum[2 * slot] = 0; zsum[2 * slot + 1] = 0; }
-            {
-                // everything here is wave-uniform (row is a uniform pointer: scalar loads)
-                const int sic = R->tiles_per_set == 1 ? vset : vset / R->tiles_per_set;
+            const int sic = __builtin_amdgcn_readlane((int)rec, R_SET);  // the set's row in the caller's arrays
+            const int vset = sic * TPS + qt;
+            uint32_t *d = dv + slot * DV;
+            if (lane < REC) d[lane] = rec;
+            if (lane == 0) {
+                d[D_VSET] = (uint32_t)vset; d[D_CNT] = 0u;
+                if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) { d[D_ZSUM] = 0u; d[D_ZSUM + 1] = 0u; d[D_ZSUM + 2] = 0u; d[D_ZSUM + 3] = 0u; }
+                // everything here is wave-uniform: scalar arithmetic
                 const unsigned long long gset = R->set_offset + (unsigned long long)sic;
                 const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
                 PathSet ps;
                 ps.init(s_lo, s_hi, R->k0, R->k1);              // stream 0: no tag bits in c2
-                float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 0.0f;       // the per-SET ones of the model
-                if constexpr (MODEL == NDDM_BASIC_DDM_DC) { drift = row[0]; a = row[1]; beta = row[2]; sig_c = row[4]; }
-                else if constexpr (MODEL == NDDM_SINGLE_TRIAL) { drift = row[0]; beta = row[2]; sig_c = row[5]; }
-                else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) { drift = row[0]; a = row[1]; beta = row[2]; }
-                else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { a = row[1]; beta = row[2]; sig_c = row[5]; }
-                else { drift = row[0]; beta = row[1]; sig_c = row[3]; }
-                const float inv_s = 1.0f / noise_unit<FAST>(R->sqrt_dt * sig_c);
-                const float hv = 0.5f * a;
-                if (lane == 0) {
-                    uint32_t *d = dv + slot * DV;
-                    d[D_MU] = __float_as_uint((drift * R->dt) * inv_s);
-                    d[D_INVS] = __float_as_uint(inv_s);
-                    d[D_H] = __float_as_uint(hv * inv_s);
-                    d[D_W0] = __float_as_uint((a * beta - hv) * inv_s);
-                    d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
-                    if constexpr (BRIDGE) {
-                        PathSet pb;
-                        pb.init(s_lo, s_hi | 0x30000000u, R->k0, R->k1);
-                        d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
-                    }
-                    d[D_SETLO] = s_lo;
-                    d[D_C3] = s_hi;
-                    d[D_TBASE] = (uint32_t)((vset - sic * R->tiles_per_set) * N);
-                    d[D_SIC] = (uint32_t)sic;
+                d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
+                if constexpr (BRIDGE) {
+                    PathSet pb;
+                    pb.init(s_lo, s_hi | 0x30000000u, R->k0, R->k1);
+                    d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
                 }
+                d[D_SETLO] = s_lo;
+                d[D_C3] = s_hi;
+                d[D_TBASE] = (uint32_t)(qt * N);
             }
             chunk_set++; chunk_left--; tile_open++;
         }
@@ -469,7 +502,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     while (true) {
         // ------------------------------------------------------------ retire finished trials
         const unsigned long long fin_mask0 = has_m & ~act_m;
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned int *>(dbg_stamp + 2), 1u);      // refill phases (no-return LDS atomic)
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
             const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
@@ -477,29 +509,29 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             const int slot = tile & ring_mask;
             if (SMALL || fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
             else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
-            atomicAdd(&cnt[slot], 1);
+            atomicAdd(dv + slot * DV + D_CNT, 1u);
         }
         has_m &= ~fin_mask0;
-        retired += (unsigned int)__popcll(fin_mask0);
+        to_retire -= (int)__popcll(fin_mask0);
         // ------------------------------------------------------------ flush complete sets, in order (rare path:
         // only entered when enough trials have retired for the oldest tile to possibly be complete)
-        if ((int)(retired - gate) >= 0) {
+        if (to_retire <= 0) {
             __syncthreads();
             while (flushed < tile_open) {
                 const int slot = flushed & ring_mask;
-                const int c = __builtin_amdgcn_readfirstlane(cnt[slot]);
+                const int c = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_CNT]);
                 if (c != N) break;
-                const int set_in_call = __builtin_amdgcn_readfirstlane(slot_set[slot]);
+                const int set_in_call = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_VSET]);
                 if constexpr (SMALL)
-                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
-                                                 res_h + (size_t)slot * N, zsum + 2 * slot, kbase);
+                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, __uint_as_float(dv[slot * DV + D_TAU]),
+                                                 res_h + (size_t)slot * N, reinterpret_cast<const long long *>(dv + slot * DV + D_ZSUM), kbase);
                 else
-                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, lp + slot * P,
+                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, __uint_as_float(dv[slot * DV + D_TAU]),
                                                   fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
                                                                         : static_cast<const void *>(res + (size_t)slot * N),
-                                                  zsum + 2 * slot, kbase);
+                                                  reinterpret_cast<const long long *>(dv + slot * DV + D_ZSUM), kbase);
                 flushed++;
-                gate += (unsigned int)N;
+                to_retire += N;
             }
             __syncthreads();
             open_tiles();
@@ -525,74 +557,89 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 tile = tl;
                 ltrial = (uint32_t)tr;
                 const int slot = tl & ring_mask;
-                const float *pp = lp + slot * P;
-                const uint4 d0 = *reinterpret_cast<const uint4 *>(dv + slot * DV);
-                const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 4);
-                const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 8);
-                trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
-                set_lo = d2.y;
-                c3 = d2.x;
-                mu_dt = __uint_as_float(d0.x);
-                const float inv_s = __uint_as_float(d0.y);       // per-set where the model's noise scale is per set
-                h = __uint_as_float(d0.z);
-                w = __uint_as_float(d0.w);
+                const uint4 d0 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_A);
+                const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_CA);
+                const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_SIC);      // set index, tau, TBASE
+                const float a0 = __uint_as_float(d0.x), a1 = __uint_as_float(d0.y), a2 = __uint_as_float(d0.z),
+                            a3 = __uint_as_float(d0.w);                  // the model's A constants (make_record)
+                const uint32_t trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
+                [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;       // the auxiliary stream's set words
+                if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT || MODEL == NDDM_ALPHA_NOT_SCALED) {
+                    const uint2 sw = *reinterpret_cast<const uint2 *>(dv + slot * DV + D_C3);
+                    c3 = sw.x; set_lo = sw.y;
+                }
                 invalid = false;
                 [[maybe_unused]] float zout = 0.0f;
-                if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
+                if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
+                    mu_dt = a0; h = a2; w = a3;
+                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
+                    // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
+                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
                     float z0, z1;
                     aux.first_pair(z0, z1);                 // normal 0: datum noise; normals 1, 2, ...: rejection draws
-                    float a = __builtin_fmaf(pp[4], z1, pp[1]);
-                    for (uint32_t ai = 2; !(a > 0.0f) && ai <= MAX_REJECT; ++ai) a = __builtin_fmaf(pp[4], aux.normal(ai), pp[1]);
+                    float a = __builtin_fmaf(a2, z1, a3);
+                    for (uint32_t ai = 2; !(a > 0.0f) && ai <= MAX_REJECT; ++ai) a = __builtin_fmaf(a2, aux.normal(ai), a3);
                     if (!(a > 0.0f)) a = fabsf(a);
-                    zout = __builtin_fmaf(pp[6], z0, pp[7] * a);
+                    zout = __builtin_fmaf(__uint_as_float(d3.x), z0, __uint_as_float(d3.y) * a);
                     const float hv = 0.5f * a;
-                    h = hv * inv_s;
-                    w = (a * pp[2] - hv) * inv_s;
+                    mu_dt = a0;
+                    h = hv * a1;
+                    w = (a * __uint_as_float(d3.z) - hv) * a1;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
+                    // A = drift, alpha, beta, std_dc;  B = mu_dc, sigma1, gamma
+                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
                     float z0, z1;
                     aux.first_pair(z0, z1);
-                    float sig_c = __builtin_fmaf(pp[4], z1, pp[5]);
-                    for (uint32_t ai = 2; !(sig_c > 0.0f) && ai <= MAX_REJECT; ++ai) sig_c = __builtin_fmaf(pp[4], aux.normal(ai), pp[5]);
+                    const float mu_dc = __uint_as_float(d3.x);
+                    float sig_c = __builtin_fmaf(a3, z1, mu_dc);
+                    for (uint32_t ai = 2; !(sig_c > 0.0f) && ai <= MAX_REJECT; ++ai) sig_c = __builtin_fmaf(a3, aux.normal(ai), mu_dc);
                     if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
-                    zout = __builtin_fmaf(pp[6], z0, pp[7] * sig_c);
+                    zout = __builtin_fmaf(__uint_as_float(d3.y), z0, __uint_as_float(d3.z) * sig_c);
                     const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);      // per-trial noise scale
-                    const float hv = 0.5f * pp[1];
-                    mu_dt = (pp[0] * H->dt) * inv_t;
+                    const float hv = 0.5f * a1;
+                    mu_dt = (a0 * H->dt) * inv_t;
                     h = hv * inv_t;
-                    w = (pp[1] * pp[2] - hv) * inv_t;
+                    w = (a1 * a2 - hv) * inv_t;
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
+                    // A = Nu, 1/S, a/(2S), w0;  B = Eta
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    mu_dt = (__builtin_fmaf(pp[4], aux.normal(0), pp[0]) * H->dt) * inv_s;
+                    const float eta = __uint_as_float(dv[slot * DV + D_B]);
+                    mu_dt = (__builtin_fmaf(eta, aux.normal(0), a0) * H->dt) * a1;
+                    h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
-                    const float a = trial < (uint32_t)H->n_total ? H->bounds[(long long)d2.w * H->n_total + trial] : 1.0f;   // padded trial of a last tile
+                    // A = drift*dt/S, 1/S, beta
+                    const float a = trial < (uint32_t)H->n_total ? H->bounds[(long long)d2.x * H->n_total + trial] : 1.0f;   // padded trial of a last tile
                     zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                     const float hv = 0.5f * a;
-                    h = invalid ? 0.0f : hv * inv_s;
-                    w = (a * pp[1] - hv) * inv_s;
+                    mu_dt = a0;
+                    h = invalid ? 0.0f : hv * a1;
+                    w = (a * a2 - hv) * a1;
                 }
                 if constexpr (T::HAS_Z) {
                     // column 1 (external datum / the boundary given) is known before the path is simulated: it goes
                     // to HBM here, where the lanes of a hand-out hold CONSECUTIVE trials (one or two 128-byte lines per
                     // store instruction instead of one line per lane at retire time), and its fixed-point sums to LDS
                     if (trial < (uint32_t)H->n_total) {           // not a padding trial of a split set's last tile
-                        if (H->out_trials) H->out_trials[((long long)d2.w * H->n_total + trial) * 2 + 1] = zout;
+                        if (H->out_trials) H->out_trials[((long long)d2.x * H->n_total + trial) * 2 + 1] = zout;
                         if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
                             if (H->out_summary) {
                                 long long fz, fzz;
                                 z_fixed_point(zout, fz, fzz);
-                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot]), (unsigned long long)fz);
-                                atomicAdd(reinterpret_cast<unsigned long long *>(&zsum[2 * slot + 1]), (unsigned long long)fzz);
+                                unsigned long long *zs = reinterpret_cast<unsigned long long *>(dv + slot * DV + D_ZSUM);
+                                atomicAdd(zs, (unsigned long long)fz);
+                                atomicAdd(zs + 1, (unsigned long long)fzz);
                             }
                         }
                     }
                 }
-                pc.init(d1.x, d1.y, d1.z, d1.w, trial, H->k0, H->k1);
+                const uint4 kq = *reinterpret_cast<const uint4 *>(lds_raw + 28);       // kC, kD, kE of PathCtr::init
+                pc.init(d1.x, d1.y, d1.z, d1.w, trial, kq.x, kq.y, kq.z);
                 if constexpr (BRIDGE) {
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + 12);
-                    pcb.init(d3.x, d3.y, d3.z, d3.w, trial, H->k0, H->k1);
+                    const uint4 d4 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_BCA);
+                    pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
                 }
                 k = 0;
                 jit = 0;
@@ -602,8 +649,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
-        for (int it = 0; it < A.max_blocks; ++it) {
-            dbg_blocks++;
+        int it = 0;
+        for (; it < A.max_blocks; ++it) {
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
             // counter word 0 of the path stream = index of the block's first step (a multiple of 4: a lane only starts
             // a block after taking all four steps of the previous one), so no shift is needed
@@ -656,6 +703,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
         }
+        // one refill phase, `it + 1` blocks (max_blocks if the loop ran out): a no-return 64-bit LDS add
+        if (lane == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it < A.max_blocks ? it + 1 : it));
     }
     // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
@@ -667,8 +716,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     }
     unsigned long long *const dbg = fresh_args(Ak)->dbg;
     if (dbg && lane == 0) {
-        atomicAdd(dbg + 0, (unsigned long long)dbg_blocks);
-        atomicAdd(dbg + 1, dbg_stamp[2]);
+        atomicAdd(dbg + 0, dbg_stamp[2] & 0xffffffffull);
+        atomicAdd(dbg + 1, dbg_stamp[2] >> 32);
         atomicAdd(dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
         atomicAdd(dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
         atomicAdd(dbg + 4, 1ull);
@@ -719,8 +768,8 @@ __global__ void order_hist_kernel(int model, const float *params, int P, int B, 
     if (threadIdx.x < ORDER_BUCKETS && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ void order_scatter_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws, int *order,
-                                     float *params_q)
+__global__ void order_scatter_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
+                                     int *ws, uint32_t *recs)
 {
     __shared__ int start[ORDER_BUCKETS], lh[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
     if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += ws[b]; } }
@@ -738,12 +787,18 @@ __global__ void order_scatter_kernel(int model, const float *params, int P, int 
             lbase[threadIdx.x] = atomicAdd(&ws[ORDER_BUCKETS + threadIdx.x], lh[threadIdx.x]);
         __syncthreads();
         if (i < B) {
-            const int q = start[b] + lbase[b] + r;
-            order[q] = i;
-            for (int j = 0; j < P; ++j) params_q[(long long)q * P + j] = params[(long long)i * P + j];
+            const int q = start[b] + lbase[b] + r;      // position of set i in the processing order
+            make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)q * REC);
         }
         __syncthreads();
     }
+}
+
+// launches too small to be worth sorting: records in the given order
+__global__ void prep_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, uint32_t *recs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)i * REC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1161,7 +1216,9 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // 7 % of lane efficiency, more than 1024 buys nothing).  But the LDS footprint must leave 7 waves per SIMD resident
     // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
     // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
-    const auto lds_of = [&](int r) { return 112 + (size_t)r * (nddm::DV * 4 + P * 4 + 8 + 16) + (size_t)r * tile_n * per_trial; };
+    const auto lds_of = [&](int r) {
+        return (size_t)LDS_HEADER_DWORDS * 4 + (size_t)r * (DV * 4) + (size_t)r * tile_n * per_trial;
+    };
     int ring = tun.ring;
     if (!ring) {
         ring = round_up_pow2((480 + tile_n - 1) / tile_n);
@@ -1203,7 +1260,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     const bool want_order = B >= 2048 && tun.no_order == 0;
     const bool want_partials = out_summary != nullptr;
     const int pw = partial_words(has_zsum);
-    const size_t order_bytes = want_order ? (((size_t)(64 + B + B * P) * sizeof(int) + 255) & ~(size_t)255) : 0;
+    const size_t order_bytes = (((want_order ? 64 : 0) + (size_t)B * REC) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [counters] | records
     const size_t partial_bytes = want_partials ? (size_t)vB * pw * sizeof(unsigned long long) : 0;
     const size_t scratch_bytes = order_bytes + partial_bytes;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1237,26 +1294,31 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         }
     }
     int rc = NDDM_OK;
-    A.order = nullptr;
     A.partials = want_partials ? reinterpret_cast<unsigned long long *>(scratch + order_bytes) : nullptr;
-    if (want_order) {
-        // longest-first processing order
-        int *order_ws = reinterpret_cast<int *>(scratch);
+    {
+        // pre-pass: one hand-out record per set (make_record), in processing order -- longest expected trials first when
+        // the launch is large enough for the order to matter, else as given
+        const int threads = 256;
+        long long blocks = (B + threads - 1) / threads;
         hipError_t e = hipSuccess;
-        {
-            hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned int *>(order_ws));
-            const int threads = 256;
-            long long blocks = (B + threads - 1) / threads;
+        if (want_order) {
+            int *order_ws = reinterpret_cast<int *>(scratch);
+            uint32_t *recs = reinterpret_cast<uint32_t *>(order_ws + 64);
             if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned int *>(order_ws));
             hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
                                (int)max_steps, order_ws);
-            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
-                               (int)max_steps, order_ws, order_ws + 64, reinterpret_cast<float *>(order_ws + 64 + B));
-            e = hipGetLastError();
+            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P,
+                               (int)B, dt, A.sqrt_dt, (int)max_steps, order_ws, recs);
+            A.recs = recs;
+        } else {
+            uint32_t *recs = reinterpret_cast<uint32_t *>(scratch);
+            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P, (int)B, dt,
+                               A.sqrt_dt, recs);
+            A.recs = recs;
         }
-        if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "ordering pre-pass: %s", hipGetErrorString(e));
-        A.order = order_ws + 64;
-        A.params_q = reinterpret_cast<const float *>(order_ws + 64 + B);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "pre-pass (hand-out records): %s", hipGetErrorString(e));
     }
     if (rc == NDDM_OK) {
         const int gw = tun.grid_waves;   // 0 = as many waves as stay resident

@@ -71,15 +71,17 @@ struct PathSet {
 
 struct PathCtr {
     uint32_t cA, cB, cC, cD, cE;
+    // kC = k0 + 2 W0, kD = k1 + 2 W1, kE = k0 + 3 W0: the round keys that fold into the per-trial constants (the kernel
+    // keeps them in its LDS header next to the key table: a hand-out must not cost a scalar-memory round trip)
     __device__ __forceinline__ void init(uint32_t sA, uint32_t sB, uint32_t hP1k, uint32_t X1, uint32_t trial,
-                                         uint32_t k0, uint32_t k1)
+                                         uint32_t kC, uint32_t kD, uint32_t kE)
     {
         cA = sA; cB = sB;
         const uint64_t Q0 = (uint64_t)PHILOX_M0 * (hP1k ^ trial);                  // round 1, constant half
         const uint64_t S1 = (uint64_t)PHILOX_M1 * ((uint32_t)(Q0 >> 32) ^ X1);     // round 2, constant half
-        cC = (uint32_t)(S1 >> 32) ^ (k0 + 2u * PHILOX_W0);    // round 2: c0[3] = lo(Q1) ^ cC
-        cD = (uint32_t)Q0 ^ (k1 + 2u * PHILOX_W1);            // round 2: c2[3] = hi(S0) ^ cD
-        cE = (uint32_t)S1 ^ (k0 + 3u * PHILOX_W0);            // round 3: c0[4] = hi(T1) ^ cE
+        cC = (uint32_t)(S1 >> 32) ^ kC;                       // round 2: c0[3] = lo(Q1) ^ cC
+        cD = (uint32_t)Q0 ^ kD;                               // round 2: c2[3] = hi(S0) ^ cD
+        cE = (uint32_t)S1 ^ kE;                               // round 3: c0[4] = hi(T1) ^ cE
     }
 };
 
