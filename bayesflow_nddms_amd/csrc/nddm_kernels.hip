@@ -83,7 +83,7 @@ struct SimArgs {
     int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384;
                               // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
-    int max_blocks;           // ... or after this many Philox blocks (4 steps each)
+    int max_blocks;           // (unused by the kernels: the block limit is 16, switched off by refill_thresh >= 64)
 };
 
 // The launch arguments as they sit in the kernarg segment (constant address space: scalar loads).  The rarely executed
@@ -178,148 +178,6 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
     o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
 }
 
-// Fixed-point terms of the external datum's sums: trunc(z * 2^32) and trunc(z^2 * 2^24) with z clamped to +-2^18, as the
-// oracle computes them through doubles -- here by integer arithmetic on the float's bits (gfx950 has no f64 -> i64
-// conversion: the double route is ~80 instructions per hand-out, this one ~20).  |z| * 2^32 = m * 2^(e-118) with the
-// 24-bit significand m and biased exponent e <= 145: (m << 29) >> (147 - e); z^2 * 2^24 = m^2 * 2^(2e-276):
-// (m^2 << 15) >> (291 - 2e).  Shift counts are clamped to 63, where the (< 2^63) operand has become 0 as it should.
-__device__ __forceinline__ void z_fixed_point(float z, long long &fz, long long &fzz)
-{
-    z = fminf(fmaxf(z, -262144.0f), 262144.0f);
-    const uint32_t b = __float_as_uint(z);
-    const uint32_t e = (b >> 23) & 0xffu;
-    const uint32_t m = (b & 0x007fffffu) | 0x00800000u;
-    const uint32_t s1 = 147u - e, s2 = 291u - 2u * e;
-    const unsigned long long mag = ((unsigned long long)m << 29) >> (s1 < 63u ? s1 : 63u);
-    fz = (b >> 31) ? -(long long)mag : (long long)mag;
-    fzz = (long long)((((unsigned long long)m * m) << 15) >> (s2 < 63u ? s2 : 63u));
-}
-
-// Sum of a 32-bit value over the 64 lanes, in the vector ALU's data-parallel-primitive lanes (no LDS traffic, six adds):
-// row_shr 1, 2, 4, 8 leave each 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it into the next rows; lanes
-// whose DPP source lies outside the row read the `old` operand, 0.  The wave's total ends up in lane 63.  Needs all 64
-// lanes active; the caller reads the result in lane 63.  (The shuffle-based wave_sum above costs six ds_bpermute round
-// trips per value.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
-{
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
-{
-    v = dpp_add<0x111, 0xf>(v);        // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);        // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);        // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);        // row_shr:8
-    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
-    return v;                          // lane 63 holds the total (kept in a VGPR: SGPRs are what limits residency)
-}
-
-// Integer partial sums of one tile, as the simulator leaves them for combine_partials_kernel (which adds the tiles of a
-// set up and finalises the summary row in f64 with one THREAD per set instead of one lane per flush): PW 64-bit words
-//   [0] n_upper | n_lower << 21 | n_missing << 42   [1] sum k   [2] sum k^2   [3] sum k (upper)   [4] sum k^2 (upper)
-//   [5] sum z (fixed point, 2^-32)   [6] sum z^2 (2^-24)                     -- models with an external datum only
-__host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum ? 7 : 5; }
-
-// The fused epilogue of one tile (= one parameter set unless the set is split): coalesced (col0, col1) stores +
-// summary reduction.  vset = set * tiles_per_set + tile.  Models with an external datum (z1 / the explicit boundary)
-// wrote column 1 straight to HBM when each trial was handed out and keep only integer sums of it in LDS (zsum), so that
-// their LDS footprint -- and with it the occupancy -- equals the basic model's; their column 0 is stored here with stride 2.
-// SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
-// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
-// each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
-template <int MODEL, bool FAST, bool SMALL>
-__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, float tau,
-                                          const void *res, const long long *zsum, uint32_t kbase)
-{
-    using T = ModelTraits<MODEL>;
-    constexpr bool ZSUM = MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT;
-    const int N = Ap->n_trials;
-    const int TPS = Ap->tiles_per_set;
-    const long long set_in_call = TPS == 1 ? vset : vset / TPS;
-    const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
-    const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
-    uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
-    int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
-    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
-    float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
-    for (int j = lane; j < n_here; j += WAVE) {
-        uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
-        if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
-            const uint32_t v = static_cast<const uint16_t *>(res)[j];
-            k = v & 0x3fffu; code = v >> 14;
-        } else {
-            const uint32_t v = static_cast<const uint32_t *>(res)[j];
-            k = v & 0x3fffffffu; code = v >> 30;
-        }
-        const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
-        const float rt = __builtin_fmaf((float)k, Ap->tscale, tau);
-        float2 o;
-        if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
-        else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
-        else { o.x = ch * rt; o.y = 0.0f; }
-        if (code == 3u) o.x = __builtin_nanf("");
-        if (out) {
-            if constexpr (T::HAS_Z) reinterpret_cast<float *>(out)[2 * j] = o.x;     // column 1 is already in place
-            else out[j] = o;
-        }
-        if (Ap->out_summary) {
-            if constexpr (SMALL) {
-                const uint32_t kk = k * k;                                           // < 2^28
-                const bool up = code == 1u, resp = up || code == 2u;
-                cnt3 += up ? 1u : (code == 2u ? (1u << 10) : (1u << 20));
-                sk32 += resp ? k : 0u; sk2_32 += resp ? kk : 0u;
-                sk_up32 += up ? k : 0u; sk2_up32 += up ? kk : 0u;
-            } else {
-                const unsigned long long kk = (unsigned long long)k * k;
-                if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
-                else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
-                else n_miss++;
-            }
-        }
-    }
-    if (Ap->out_summary) {
-        unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
-        if constexpr (SMALL) {
-            cnt3 = wave_sum_dpp(cnt3);
-            sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
-            const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
-            const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
-            if (lane == WAVE - 1) {                          // the DPP reductions leave the totals in the last lane
-                q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
-                       ((unsigned long long)(cnt3 >> 20) << 42);
-                q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
-                q[3] = sk_up32; q[4] = ((unsigned long long)u_hi << 16) + u_lo;
-                if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
-            }
-        } else {
-            n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
-            sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-            if (lane == 0) {
-                q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
-                q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
-                if constexpr (ZSUM) { q[5] = (unsigned long long)zsum[0]; q[6] = (unsigned long long)zsum[1]; }
-            }
-        }
-    }
-    if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-        if (Ap->out_ext && lane == 0 && t0 == 0) {
-            const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
-            AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
-            const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
-            Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
-        }
-    }
-}
-
-// The evidence is carried CENTRED: w = x - a/2, h = a/2, so that (x > 0) && (x < a) is the single compare |w| < h
-// (v_cmp_lt_f32 with the |.| source modifier; false for NaN and for h == 0).
-__device__ __forceinline__ bool in_range(float w, float h)
-{
-    return __builtin_fabsf(w) < h;
-}
-
 // Per-set constants of the trial hand-out.  Everything that is floating-point arithmetic on the parameter row is done
 // ONCE per set by a pre-pass (prep_kernel, or the scatter pass of the longest-first sort) into a REC-dword record, stored
 // in PROCESSING order so that a wave streams them sequentially; the simulator loads the record of the next tile one tile
@@ -370,6 +228,196 @@ enum { D_A = 0, D_B = 4,                             // r[0..3], r[4..7]
 constexpr int DV = 24;                               // one layout for every model: only two LDS base addresses stay live
 static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the loaded record");
 constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,26) | kC kD kE [28,31)
+
+// The per-trial latent of the single-trial family and the external datum that goes with it: a pure function of
+// (set, trial) and the set's record, so the hand-out (which needs the latent) and the flush (which writes the datum next
+// to the choice-RT, one whole float2 per trial) each evaluate it where they need it; the part a caller does not use is
+// dead code there.  Normal 0 of the auxiliary stream is the datum's noise, normals 1, 2, ... the rejection draws.
+//   single:     latent = boundary ~ N(mu_alpha, std_alpha) > 0 (single_trial_alpha_not_scaled.py:113-116),  z1 ~ N(gamma * boundary, sigma1) (:134)
+//   single_alt: latent = dc       ~ N(mu_dc, std_dc) > 0       (:932-935),                                z1 ~ N(gamma * dc, sigma1)
+template <int MODEL, bool FAST>
+__device__ __forceinline__ void trial_latent(const uint4 dA, const uint4 dB, uint32_t set_lo, uint32_t c3, uint32_t trial,
+                                             uint32_t kbase, float &latent, float &z)
+{
+    static_assert(MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT, "models with a per-trial latent");
+    // single: A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
+    // alt:    A = drift, alpha, beta, std_dc;            B = mu_dc, sigma1, gamma
+    const float sd = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dA.z) : __uint_as_float(dA.w);
+    const float mean = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dA.w) : __uint_as_float(dB.x);
+    const float sigma1 = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dB.x) : __uint_as_float(dB.y);
+    const float gamma = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dB.y) : __uint_as_float(dB.z);
+    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
+    float z0, z1;
+    aux.first_pair(z0, z1);
+    float v = __builtin_fmaf(sd, z1, mean);
+    for (uint32_t ai = 2; !(v > 0.0f) && ai <= MAX_REJECT; ++ai) v = __builtin_fmaf(sd, aux.normal(ai), mean);
+    if (!(v > 0.0f)) v = fabsf(v);
+    latent = v;
+    z = __builtin_fmaf(sigma1, z0, gamma * v);
+}
+
+// Fixed-point terms of the external datum's sums: trunc(z * 2^32) and trunc(z^2 * 2^24) with z clamped to +-2^18, as the
+// oracle computes them through doubles -- here by integer arithmetic on the float's bits (gfx950 has no f64 -> i64
+// conversion: the double route is ~80 instructions per hand-out, this one ~20).  |z| * 2^32 = m * 2^(e-118) with the
+// 24-bit significand m and biased exponent e <= 145: (m << 29) >> (147 - e); z^2 * 2^24 = m^2 * 2^(2e-276):
+// (m^2 << 15) >> (291 - 2e).  Shift counts are clamped to 63, where the (< 2^63) operand has become 0 as it should.
+__device__ __forceinline__ void z_fixed_point(float z, long long &fz, long long &fzz)
+{
+    z = fminf(fmaxf(z, -262144.0f), 262144.0f);
+    const uint32_t b = __float_as_uint(z);
+    const uint32_t e = (b >> 23) & 0xffu;
+    const uint32_t m = (b & 0x007fffffu) | 0x00800000u;
+    const uint32_t s1 = 147u - e, s2 = 291u - 2u * e;
+    const unsigned long long mag = ((unsigned long long)m << 29) >> (s1 < 63u ? s1 : 63u);
+    fz = (b >> 31) ? -(long long)mag : (long long)mag;
+    fzz = (long long)((((unsigned long long)m * m) << 15) >> (s2 < 63u ? s2 : 63u));
+}
+
+// Sum of a 32-bit value over the 64 lanes, in the vector ALU's data-parallel-primitive lanes (no LDS traffic, six adds):
+// row_shr 1, 2, 4, 8 leave each 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it into the next rows; lanes
+// whose DPP source lies outside the row read the `old` operand, 0.  The wave's total ends up in lane 63.  Needs all 64
+// lanes active; the caller reads the result in lane 63.  (The shuffle-based wave_sum above costs six ds_bpermute round
+// trips per value.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    v = dpp_add<0x111, 0xf>(v);        // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);        // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);        // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);        // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
+    return v;                          // lane 63 holds the total (kept in a VGPR: SGPRs are what limits residency)
+}
+
+// Integer partial sums of one tile, as the simulator leaves them for combine_partials_kernel (which adds the tiles of a
+// set up and finalises the summary row in f64 with one THREAD per set instead of one lane per flush): PW 64-bit words
+//   [0] n_upper | n_lower << 21 | n_missing << 42   [1] sum k   [2] sum k^2   [3] sum k (upper)   [4] sum k^2 (upper)
+//   [5] sum z (fixed point, 2^-32)   [6] sum z^2 (2^-24)                     -- models with an external datum only
+__host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum ? 7 : 5; }
+
+// The fused epilogue of one tile (= one parameter set unless the set is split): coalesced float2 (col0, col1) stores --
+// 512 B per wave instruction, every line written whole, once -- + summary reduction.  vset = set * tiles_per_set + tile,
+// d = the tile's LDS record.  Column 1 of the models with an external datum is NOT staged in LDS (their LDS footprint,
+// and with it the occupancy, equals the basic model's): z1 is recomputed here from the trial's auxiliary stream
+// (trial_latent), the explicit boundary is re-read from the caller's array.  (Writing it when the trial is handed out
+// or retired instead made every 64-byte sector of the output a partial write, twice: WRITE_SIZE 1.93x the output.)
+// SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
+// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
+// each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
+template <int MODEL, bool FAST, bool SMALL>
+__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, uint32_t *d, const void *res, uint32_t kbase)
+{
+    using T = ModelTraits<MODEL>;
+    constexpr bool ZSUM = MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT;
+    const float tau = __uint_as_float(d[D_TAU]);
+    [[maybe_unused]] uint4 dA = {0u, 0u, 0u, 0u}, dB = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;
+    [[maybe_unused]] long long acc_z = 0, acc_zz = 0;
+    if constexpr (ZSUM) {
+        dA = *reinterpret_cast<const uint4 *>(d + D_A); dB = *reinterpret_cast<const uint4 *>(d + D_B);
+        c3 = d[D_C3]; set_lo = d[D_SETLO];
+    }
+    const int N = Ap->n_trials;
+    const int TPS = Ap->tiles_per_set;
+    const long long set_in_call = TPS == 1 ? vset : vset / TPS;
+    const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
+    const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
+    uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
+    int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
+    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
+    float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
+    for (int j = lane; j < n_here; j += WAVE) {
+        uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
+        if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
+            const uint32_t v = static_cast<const uint16_t *>(res)[j];
+            k = v & 0x3fffu; code = v >> 14;
+        } else {
+            const uint32_t v = static_cast<const uint32_t *>(res)[j];
+            k = v & 0x3fffffffu; code = v >> 30;
+        }
+        const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
+        const float rt = __builtin_fmaf((float)k, Ap->tscale, tau);
+        float2 o;
+        if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
+        else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
+        else {
+            o.x = ch * rt;
+            if constexpr (ZSUM) {
+                float latent;
+                trial_latent<MODEL, FAST>(dA, dB, set_lo, c3, (uint32_t)(t0 + j), kbase, latent, o.y);
+                if (Ap->out_summary) { long long fz, fzz; z_fixed_point(o.y, fz, fzz); acc_z += fz; acc_zz += fzz; }
+            } else {
+                o.y = out ? Ap->bounds[set_in_call * Ap->n_total + t0 + j] : 0.0f;       // the boundary that was given
+            }
+        }
+        if (code == 3u) o.x = __builtin_nanf("");
+        if (out) out[j] = o;
+        if (Ap->out_summary) {
+            if constexpr (SMALL) {
+                const uint32_t kk = k * k;                                           // < 2^28
+                const bool up = code == 1u, resp = up || code == 2u;
+                cnt3 += up ? 1u : (code == 2u ? (1u << 10) : (1u << 20));
+                sk32 += resp ? k : 0u; sk2_32 += resp ? kk : 0u;
+                sk_up32 += up ? k : 0u; sk2_up32 += up ? kk : 0u;
+            } else {
+                const unsigned long long kk = (unsigned long long)k * k;
+                if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
+                else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
+                else n_miss++;
+            }
+        }
+    }
+    if (Ap->out_summary) {
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
+        [[maybe_unused]] unsigned long long *zsum = reinterpret_cast<unsigned long long *>(d + D_ZSUM);
+        if constexpr (ZSUM) {          // 64-bit sums: no-return LDS adds by every lane; a wave's LDS operations complete in order
+            atomicAdd(zsum, (unsigned long long)acc_z);
+            atomicAdd(zsum + 1, (unsigned long long)acc_zz);
+        }
+        if constexpr (SMALL) {
+            cnt3 = wave_sum_dpp(cnt3);
+            sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
+            const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
+            const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
+            if (lane == WAVE - 1) {                          // the DPP reductions leave the totals in the last lane
+                q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
+                       ((unsigned long long)(cnt3 >> 20) << 42);
+                q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
+                q[3] = sk_up32; q[4] = ((unsigned long long)u_hi << 16) + u_lo;
+                if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
+            }
+        } else {
+            n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
+            sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
+            if (lane == 0) {
+                q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
+                q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
+                if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
+            }
+        }
+    }
+    if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
+        if (Ap->out_ext && lane == 0 && t0 == 0) {
+            const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
+            AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
+            const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
+            Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
+        }
+    }
+}
+
+// The evidence is carried CENTRED: w = x - a/2, h = a/2, so that (x > 0) && (x < a) is the single compare |w| < h
+// (v_cmp_lt_f32 with the |.| source modifier; false for NaN and for h == 0).
+__device__ __forceinline__ bool in_range(float w, float h)
+{
+    return __builtin_fabsf(w) < h;
+}
+
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  SMALL: see below.  CAP4: max_steps is a multiple of 4, so the step cap is tested
 // once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
@@ -438,8 +486,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     // The record of the NEXT tile of the current chunk, loaded when the tile before it is opened (lanes < REC hold one
     // dword each): by the time it is consumed the load has long completed, so opening a tile never waits on memory.
+    // It is valid whenever the chunk has tiles left (the record of chunk position `chunk_set`).
     uint32_t pre = 0u;
-    int pre_row = -1;                             // queue row `pre` belongs to (-1: none)
 
     // open tiles (fetch chunk ids from the global queue, stage the hand-out record of each new tile) while ring slots
     // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
@@ -448,6 +496,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     auto open_tiles = [&]() {
         const ArgsPtr R = fresh_args(Ak);
         while (tile_open < flushed + ring && tile_open <= next_tile + R->open_ahead) {
+            const bool have_pre = chunk_left > 0;                        // mid-chunk: this tile's record was prefetched
             if (chunk_left <= 0) {
                 if (chunk_left < 0) break;
                 unsigned int c = 0;
@@ -464,12 +513,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             const int prow = TPS == 1 ? chunk_set : chunk_set / TPS;
             const int qt = chunk_set - prow * TPS;                       // tile within the set (0 when not tiled)
             uint32_t rec = pre;
-            if (pre_row != prow) rec = lane < REC ? R->recs[(long long)prow * REC + lane] : 0u;
+            if (!have_pre) rec = lane < REC ? R->recs[(long long)prow * REC + lane] : 0u;
             if (chunk_left > 1) {                                        // prefetch the next tile's record
                 const int nrow = TPS == 1 ? chunk_set + 1 : (chunk_set + 1) / TPS;
                 if (nrow != prow) pre = lane < REC ? R->recs[(long long)nrow * REC + lane] : 0u;
                 else pre = rec;
-                pre_row = nrow;
             }
             const int sic = __builtin_amdgcn_readlane((int)rec, R_SET);  // the set's row in the caller's arrays
             const int vset = sic * TPS + qt;
@@ -523,13 +571,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 if (c != N) break;
                 const int set_in_call = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_VSET]);
                 if constexpr (SMALL)
-                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, __uint_as_float(dv[slot * DV + D_TAU]),
-                                                 res_h + (size_t)slot * N, reinterpret_cast<const long long *>(dv + slot * DV + D_ZSUM), kbase);
+                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV, res_h + (size_t)slot * N, kbase);
                 else
-                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, __uint_as_float(dv[slot * DV + D_TAU]),
+                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV,
                                                   fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
-                                                                        : static_cast<const void *>(res + (size_t)slot * N),
-                                                  reinterpret_cast<const long long *>(dv + slot * DV + D_ZSUM), kbase);
+                                                                        : static_cast<const void *>(res + (size_t)slot * N), kbase);
                 flushed++;
                 to_retire += N;
             }
@@ -539,7 +585,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         }
         if (flushed == tile_open && chunk_left < 0) break;
         // ------------------------------------------------------------ hand out new trials
-        if (tile_open <= next_tile + A.open_ahead && tile_open < flushed + ring && chunk_left >= 0) {
+        if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + ring && chunk_left >= 0) {
             open_tiles();
             __syncthreads();
         }
@@ -569,19 +615,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     c3 = sw.x; set_lo = sw.y;
                 }
                 invalid = false;
-                [[maybe_unused]] float zout = 0.0f;
                 if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
                     mu_dt = a0; h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
                     const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
-                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    float z0, z1;
-                    aux.first_pair(z0, z1);                 // normal 0: datum noise; normals 1, 2, ...: rejection draws
-                    float a = __builtin_fmaf(a2, z1, a3);
-                    for (uint32_t ai = 2; !(a > 0.0f) && ai <= MAX_REJECT; ++ai) a = __builtin_fmaf(a2, aux.normal(ai), a3);
-                    if (!(a > 0.0f)) a = fabsf(a);
-                    zout = __builtin_fmaf(__uint_as_float(d3.x), z0, __uint_as_float(d3.y) * a);
+                    float a, z_unused;
+                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, a, z_unused);      // per-trial boundary
                     const float hv = 0.5f * a;
                     mu_dt = a0;
                     h = hv * a1;
@@ -589,15 +629,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     // A = drift, alpha, beta, std_dc;  B = mu_dc, sigma1, gamma
                     const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
-                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    float z0, z1;
-                    aux.first_pair(z0, z1);
-                    const float mu_dc = __uint_as_float(d3.x);
-                    float sig_c = __builtin_fmaf(a3, z1, mu_dc);
-                    for (uint32_t ai = 2; !(sig_c > 0.0f) && ai <= MAX_REJECT; ++ai) sig_c = __builtin_fmaf(a3, aux.normal(ai), mu_dc);
-                    if (!(sig_c > 0.0f)) sig_c = fabsf(sig_c);
-                    zout = __builtin_fmaf(__uint_as_float(d3.y), z0, __uint_as_float(d3.z) * sig_c);
-                    const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);      // per-trial noise scale
+                    float sig_c, z_unused;
+                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, sig_c, z_unused);  // per-trial noise scale
+                    const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);
                     const float hv = 0.5f * a1;
                     mu_dt = (a0 * H->dt) * inv_t;
                     h = hv * inv_t;
@@ -611,29 +645,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
                     // A = drift*dt/S, 1/S, beta
                     const float a = trial < (uint32_t)H->n_total ? H->bounds[(long long)d2.x * H->n_total + trial] : 1.0f;   // padded trial of a last tile
-                    zout = a;
                     invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
                     const float hv = 0.5f * a;
                     mu_dt = a0;
                     h = invalid ? 0.0f : hv * a1;
                     w = (a * a2 - hv) * a1;
-                }
-                if constexpr (T::HAS_Z) {
-                    // column 1 (external datum / the boundary given) is known before the path is simulated: it goes
-                    // to HBM here, where the lanes of a hand-out hold CONSECUTIVE trials (one or two 128-byte lines per
-                    // store instruction instead of one line per lane at retire time), and its fixed-point sums to LDS
-                    if (trial < (uint32_t)H->n_total) {           // not a padding trial of a split set's last tile
-                        if (H->out_trials) H->out_trials[((long long)d2.x * H->n_total + trial) * 2 + 1] = zout;
-                        if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                            if (H->out_summary) {
-                                long long fz, fzz;
-                                z_fixed_point(zout, fz, fzz);
-                                unsigned long long *zs = reinterpret_cast<unsigned long long *>(dv + slot * DV + D_ZSUM);
-                                atomicAdd(zs, (unsigned long long)fz);
-                                atomicAdd(zs + 1, (unsigned long long)fzz);
-                            }
-                        }
-                    }
                 }
                 const uint4 kq = *reinterpret_cast<const uint4 *>(lds_raw + 28);       // kC, kD, kE of PathCtr::init
                 pc.init(d1.x, d1.y, d1.z, d1.w, trial, kq.x, kq.y, kq.z);
@@ -649,8 +665,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
+        // leave the loop for a refill once refill_thresh lanes hold a finished trial, or none is stepping, or after
+        // MAX_BLOCKS blocks (so that a few finished lanes never wait long for company; a threshold >= 64 -- the lockstep
+        // measurement -- switches that exit off)
+        constexpr int MAX_BLOCKS = 16;
         int it = 0;
-        for (; it < A.max_blocks; ++it) {
+        for (;; ++it) {
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
             // counter word 0 of the path stream = index of the block's first step (a multiple of 4: a lane only starts
             // a block after taking all four steps of the previous one), so no shift is needed
@@ -702,9 +722,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
+            if (it >= MAX_BLOCKS - 1 && A.refill_thresh < WAVE) break;
         }
-        // one refill phase, `it + 1` blocks (max_blocks if the loop ran out): a no-return 64-bit LDS add
-        if (lane == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it < A.max_blocks ? it + 1 : it));
+        // one refill phase of `it + 1` blocks: a no-return 64-bit LDS add
+        if (lane == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it + 1));
     }
     // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
