@@ -6,7 +6,7 @@ import os
 from .build import SO_PATH
 
 NDDM_OK, NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM, NDDM_ERR_HIP, NDDM_ERR_NO_DEVICE = range(6)
-GAUSS_EXACT, GAUSS_FAST, BRIDGE = 0, 1, 2
+GAUSS_EXACT, GAUSS_FAST, BRIDGE, GAUSS_PACKED = 0, 1, 2, 4
 ABI_VERSION = 1
 
 _lib = None

@@ -429,7 +429,9 @@ __device__ __forceinline__ bool in_range(float w, float h)
 // SMALL: results staged as 16-bit words and at most 512 trials per tile -- the shape of every launch that matters for
 // throughput.  A kernel that carries BOTH flush paths (32-bit DPP sums / 64-bit shuffles) needs 79 SGPRs and 60 VGPRs; the
 // SMALL one alone 72 and 44, which is what keeps 8 waves per SIMD resident (the SGPR file limits these kernels).
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL>
+// PACKED: NDDM_GAUSS_PACKED -- 8 Euler-Maruyama steps per Philox block (polar_pair_packed in nddm_rng.h); CAP4 then means
+// "max_steps is a multiple of 8".
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -672,23 +674,32 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         int it = 0;
         for (;; ++it) {
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
-            // counter word 0 of the path stream = index of the block's first step (a multiple of 4: a lane only starts
-            // a block after taking all four steps of the previous one), so no shift is needed
+            // counter word 0 of the path stream = index of the block's first step (a multiple of NS: a lane only starts
+            // a block after taking all NS steps of the previous one), so no shift is needed
+            constexpr int NS = PACKED ? 8 : 4;
             const uint32_t blk = (uint32_t)k;
             const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
-            // noise of the four steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
+            // noise of the NS steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
             // v_fmac_f32 + v_add_f32 (2.3 issue cycles each; a three-address v_fma_f32 costs 3.8)
-            float rr[4], tt[4];
-            polar_pair<FAST>(rb.x, rb.y, rr[0], tt[0], tt[1]);
-            polar_pair<FAST>(rb.z, rb.w, rr[2], tt[2], tt[3]);
-            rr[1] = rr[0]; rr[3] = rr[2];
+            float rr[NS], tt[NS];
+            if constexpr (PACKED) {
+                polar_pair_packed<FAST>(rb.x, rr[0], tt[0], tt[1]);
+                polar_pair_packed<FAST>(rb.y, rr[2], tt[2], tt[3]);
+                polar_pair_packed<FAST>(rb.z, rr[4], tt[4], tt[5]);
+                polar_pair_packed<FAST>(rb.w, rr[6], tt[6], tt[7]);
+                rr[1] = rr[0]; rr[3] = rr[2]; rr[5] = rr[4]; rr[7] = rr[6];
+            } else {
+                polar_pair<FAST>(rb.x, rb.y, rr[0], tt[0], tt[1]);
+                polar_pair<FAST>(rb.z, rb.w, rr[2], tt[2], tt[3]);
+                rr[1] = rr[0]; rr[3] = rr[2];
+            }
             uint32_t ub[4] = {0u, 0u, 0u, 0u};
             if constexpr (BRIDGE) {
                 const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);          // stream 3, same constant folding as the path stream
                 ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 if (active) {
                     // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
                     // each on gfx950) cost more VALU issue than the predicated add / count they would replace
@@ -704,15 +715,15 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                             float pu, pl;
                             if constexpr (FAST) { pu = __builtin_amdgcn_exp2f(eu); pl = __builtin_amdgcn_exp2f(el); }
                             else { pu = exact_expf_neg(eu); pl = exact_expf_neg(el); }
-                            const float uu = (float)(ub[j] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
+                            const float uu = (float)(ub[j & 3] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
                             if (uu < pu) w1 = h;
                             else if (uu >= 1.0f - pl) w1 = -h;
                         }
-                        jit = ub[j] & 0xffu;
+                        jit = ub[j & 3] & 0xffu;
                     }
                     w = w1;
                     k++;
-                    if (j < 3) {
+                    if (j < NS - 1) {
                         if constexpr (CAP4) active = in_range(w, h);
                         else active = in_range(w, h) && (k < A.max_k);
                     }
@@ -1098,9 +1109,10 @@ static int resident_waves(K kernel, size_t lds_bytes, int cus)
 }
 
 template <int MODEL, bool BRIDGE>
-static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chunks, int cus, int grid_override, hipStream_t st)
+static int launch_model(const SimArgs &A, bool fast, bool packed, size_t lds_bytes, int n_chunks, int cus, int grid_override,
+                        hipStream_t st)
 {
-    const bool cap4 = (A.max_k % 4) == 0;
+    const bool cap4 = (A.max_k % (packed ? 8 : 4)) == 0;     // the step cap falls on a block boundary
     const dim3 block(WAVE);
 #define NDDM_LAUNCH(KERNEL)                                                                    \
     do {                                                                                       \
@@ -1110,18 +1122,23 @@ static int launch_model(const SimArgs &A, bool fast, size_t lds_bytes, int n_chu
     } while (0)
     const bool small = A.res16 == 2;
     if constexpr (!BRIDGE) {
-        if (small) {
-            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true>));
-            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true>));
-            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true>));
-            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true>));
+        if (packed) {               // NDDM_GAUSS_PACKED (the host has checked small)
+            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true, true>));
+            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true, true>));
+            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true, true>));
+            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true, true>));
+        } else if (small) {
+            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true, false>));
+            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true, false>));
+            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true, false>));
+            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true, false>));
         }
     }
-    if (BRIDGE || !small) {
-        if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, false>));
-        else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, false>));
-        else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, false>));
-        else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, false>));
+    if (BRIDGE || (!small && !packed)) {
+        if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, false, false>));
+        else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, false, false>));
+        else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, false, false>));
+        else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, false, false>));
     }
 #undef NDDM_LAUNCH
     const hipError_t e = hipGetLastError();
@@ -1149,8 +1166,11 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (set_offset >= (1ull << 60) || set_offset + (uint64_t)B > (1ull << 60))
         return fail(NDDM_ERR_SHAPE, "set_offset + B must be <= 2^60 (the random stream is keyed by 60 bits of the set index)%s");
     if (!(dt > 0.0f) || !isfinite(dt)) return fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
-    if (flags > 3u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
+    if (flags > 7u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
     const bool bridge = (flags & NDDM_BRIDGE) != 0;
+    const bool packed = (flags & NDDM_GAUSS_PACKED) != 0;
+    if (packed && (bridge || max_steps >= 16384))
+        return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs max_steps < 2^14 and cannot be combined with NDDM_BRIDGE%s");
     if (bridge && model != NDDM_ALPHA_NOT_SCALED)
         return fail(NDDM_ERR_PARAM, "NDDM_BRIDGE is only available for NDDM_ALPHA_NOT_SCALED%s");
     if (bridge && max_steps >= (1 << 22)) return fail(NDDM_ERR_SHAPE, "max_steps must be < 2^22 with NDDM_BRIDGE%s");
@@ -1260,6 +1280,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // between two refills (short trials; models whose hand-out draws per-trial auxiliary normals) -- measured +2..5 %
     const bool aux_handout = model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
     A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
+    if (packed && A.res16 != 2) return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs tiles of <= 512 trials (tuning override?)%s");
     A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
     A.max_blocks = tun.max_blocks ? tun.max_blocks : 16;
     const long long n_chunks = (vB + spc - 1) / spc;
@@ -1344,14 +1365,14 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (rc == NDDM_OK) {
         const int gw = tun.grid_waves;   // 0 = as many waves as stay resident
         switch (model) {
-        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
-        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
-        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
         case NDDM_ALPHA_NOT_SCALED:
-            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, lds, (int)n_chunks, di.cus, gw, st)
-                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st);
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st);
             break;
-        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, lds, (int)n_chunks, di.cus, gw, st); break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
         }
     }
     if (rc == NDDM_OK && A.partials) {

@@ -254,6 +254,29 @@ __device__ __forceinline__ void polar_pair(uint32_t xa, uint32_t xb, float &r, f
     }
 }
 
+// PACKED layout: one u32 per Box-Muller pair, so a Philox block yields FOUR pairs = 8 normals and the generator's cost
+// per Euler-Maruyama step halves.  The word's high 16 bits are the radius uniform, its low 16 bits the angle:
+//   u   = 2 - [1,2)-float built from x >> 9   (the 16 random bits on top, dithered by the angle's top 7 bits below
+//         them: u is uniform on a 2^-16 grid whose offset inside a cell depends on the angle), u in [2^-23, 1]
+//   ang = (x & 0xffff) / 2^16 turns
+// Against the 32 + 23 bit layout above: P(r > r0) is reproduced on a 2^-16 grid, |z| <= 5.65 (exact: 5.65; the mass
+// beyond 4.7 sigma, 2^-16 per pair, follows the dither rather than fresh bits).  Opt-in (NDDM_GAUSS_PACKED); KS of the
+// first-passage distributions against the reference is at the two-sample noise floor like the default layout's.
+template <bool FAST>
+__device__ __forceinline__ void polar_pair_packed(uint32_t x, float &r, float &cs, float &sn)
+{
+    const float u = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, x, 9u));      // (0x3f800000 | x >> 9) in [1, 2)
+    if constexpr (FAST) {
+        r = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
+        const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, x << 16, 9u));  // [1, 2): 16 angle bits on top
+        cs = __builtin_amdgcn_cosf(ang);
+        sn = __builtin_amdgcn_sinf(ang);
+    } else {
+        r = exact_sqrtf(-2.0f * exact_logf(u));
+        exact_sincos_turn(x << 16, sn, cs);
+    }
+}
+
 // 4 standard normals of one Philox block
 template <bool FAST>
 __device__ __forceinline__ void normals4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -91,11 +91,14 @@ def validate_params_host(model, params):
 
 
 def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
-             bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, want_trials=True, want_summary=True, want_ext=False,
+             bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, packed=False, want_trials=True, want_summary=True, want_ext=False,
              out_trials=None, out_summary=None, stream_state=None, device=None):
     """Run one batched simulation on the current ROCm device.
 
     params: array-like or torch tensor [B, P] (or [P]) in the reference's parameter order.
+    packed=True selects NDDM_GAUSS_PACKED (include/nddm.h): 8 normals per Philox block from 16 + 16 bit pairs, ~25 % faster,
+    a different random stream; not with the bridge, max_steps < 2^14.
+
     Returns a dict of torch tensors on the device: 'trials' f32 [B, n_trials, 2], 'summary' f32 [B, 10],
     'ext' f32 [B] (alpha_not_scaled only), plus 'seed' / 'set_offset' actually used.
     """
@@ -149,7 +152,7 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     set_offset = int(set_offset) & 0xFFFFFFFFFFFFFFFF
     fast = DEFAULT_FAST if fast is None else bool(fast)
-    flags = (_lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT) | (_lib.BRIDGE if bridge else 0)
+    flags = (_lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT) | (_lib.BRIDGE if bridge else 0) | (_lib.GAUSS_PACKED if packed else 0)
     if bridge and model != ALPHA_NOT_SCALED:
         raise ValueError("the Brownian-bridge correction is only available for the alpha_not_scaled model")
 

@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--dt", type=float, default=0.001)
     ap.add_argument("--max-steps", type=float, default=4000.0)
-    ap.add_argument("--gauss", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--gauss", choices=["fast", "exact", "packed"], default="fast",
+                    help="fast (product default) | exact (bit-reproducible on a CPU) | packed = fast transform on the opt-in "
+                         "NDDM_GAUSS_PACKED layout (8 normals per Philox block from 16 + 16 bit pairs; include/nddm.h)")
     ap.add_argument("--model", choices=list(MODELS), default="basic",
                     help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns* = configs[2]")
     ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
@@ -126,7 +128,7 @@ def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
     om = getattr(oracle, MODELS[model_name][3])
     bridge = MODELS[model_name][1]
     sim = lambda p, threads: oracle.philox_simulate(om, p, n_trials, dt=dt, max_steps=max_steps, seed=1, bridge=bridge,
-                                                    threads=threads)
+                                                    packed=a.gauss == "packed", threads=threads)
     # threads actually used for the multi-core figure: the GPU box grants a CPU share of 16 cores per GPU, whatever
     # os.cpu_count() says (256 there)
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
@@ -172,7 +174,7 @@ def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
     return out
 
 
-def ks_vs_golden(engine, model_name, dt, max_steps, fast):
+def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
     """KS distance vs the golden fixtures made from the reference (tests/golden/): the signed step index against
     ks_hist.npz (basic, single; >= 4e5 trials per side per parameter set), the signed RT against the exact sampler's
     quantile tables ratcliff.npz (alpha_not_scaled; 2e5 reference draws per set)."""
@@ -191,7 +193,7 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast):
         for si, p in enumerate(gold[f"{model_name}_sets"]):
             row = p if model_name == "basic" else np.append(p, 1.0)
             r = engine.simulate(getattr(engine, MODELS[model_name][0]), np.tile(row, (2048, 1)), 200, dt=dt,
-                                max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, want_summary=False)
+                                max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, packed=packed, want_summary=False)
             h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K, signed=model_name == "single")
             per.append(round(dg.ks_signed(h, gold[f"{model_name}_hist_s{si}_c{ci}"]), 5))
         return {"max": max(per), "per_set": per, "n_trials_per_side": 409600, "bar": 0.01,
@@ -203,7 +205,7 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast):
     bridge = MODELS[model_name][1]
     for si, p in enumerate(gold["sets"]):
         r = engine.simulate(engine.ALPHA_NOT_SCALED, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=8.0 / dt, seed=777,
-                            set_offset=si * 4096, fast=fast, bridge=bridge, want_summary=False)
+                            set_offset=si * 4096, fast=fast, bridge=bridge, packed=packed, want_summary=False)
         per.append(round(dg.ks_quantile_table(r["trials"][..., 0].cpu().numpy().ravel(), gold[f"yq_s{si}"]), 5))
     return {"max": max(per), "per_set": per, "n_trials_per_side": "409600 vs 2e5", "bar": 0.01 if bridge else 0.10,
             "reference": "simulratcliff (pyhddmjagsutils.py:47-176, the EXACT first-passage sampler alpha_not_scaled.py runs), "
@@ -227,17 +229,18 @@ def pmc_traffic(model_name, B, N):
     return None
 
 
-def issue_model(model_name, fast):
+def issue_model(model_name, gauss):
     """ISA-level ceiling of the shipped library's step loop (tools/isa_mix.py), if the committed file matches the .so."""
     import hashlib
     from bayesflow_nddms_amd.build import SO_PATH
-    key = model_name if fast else model_name + "_exact"
+    key = model_name + {"fast": "", "exact": "_exact", "packed": "_packed"}[gauss]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), reverse=True):
         try:
             d = json.load(open(path))
             k = d["kernels"][key]
             same = d.get("library_sha256_16") == hashlib.sha256(open(SO_PATH, "rb").read()).hexdigest()[:16]
-            return {"cycles_per_block": k["cycles_per_block"], "valu_per_block": k["valu"], "source": os.path.basename(path),
+            return {"cycles_per_block": k["cycles_per_block"], "valu_per_block": k["valu"], "steps_per_block": k.get("steps_per_block", 4),
+                    "source": os.path.basename(path),
                     "issue_costs_from": d.get("issue_costs_from"), "library_matches": same}
         except (OSError, KeyError, ValueError):
             continue
@@ -255,7 +258,7 @@ def em_steps_of(summary, tau, dt, max_k, bridge):
     return float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
 
 
-def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast):
+def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed):
     """The step loop with every lane useful: the SAME kernel on a workload whose trials all run to the step cap
     (no refill, no idle lanes, same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane
     efficiency it was measured at (executed-block counter of the kernel)."""
@@ -268,7 +271,7 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast):
     _lib.check(L.nddm_set_tuning(1, 0, 64, 64, 0, 0))          # never leave the loop early: refill only when all lanes are done
     try:
         run = lambda: engine.simulate(model_id, p, N, dt=a.dt, max_steps=a.max_steps, seed=7, set_offset=0, fast=fast,
-                                      out_summary=summ, want_trials=False, bridge=bridge)
+                                      out_summary=summ, want_trials=False, bridge=bridge, packed=packed)
         run()
         dbg = torch.zeros(8, dtype=torch.int64, device=dev)
         L.nddm_set_debug_counters(dbg.data_ptr())
@@ -285,7 +288,7 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast):
     finally:
         L.nddm_set_tuning(0, 0, 0, 0, 0, 0)
     steps = float(B) * N * max_k
-    lane_eff = steps / (blocks * 256.0)
+    lane_eff = steps / (blocks * 64.0 * (8 if packed else 4))
     sps = steps / (best * 1e-3)
     return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
             "kernel_ms": best, "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
@@ -338,7 +341,9 @@ def simulate_bench(a, ctx):
     world, rank, dev, torch, dist, engine, _lib, prior_util = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine",
                                                                                    "_lib", "prior_util"))
     B, N = a.sets, a.trials
-    fast = a.gauss == "fast"
+    fast, packed = a.gauss != "exact", a.gauss == "packed"
+    if packed and MODELS[a.model][1]:
+        sys.exit("--gauss packed cannot be combined with the bridge correction")
     model_attr, bridge, prior_fn, _, tau_i = MODELS[a.model]
     model_id = getattr(engine, model_attr)
     # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
@@ -356,7 +361,7 @@ def simulate_bench(a, ctx):
         # every step is a fresh batch: global set index = (i*world + rank)*B + row, one seed
         engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
                         set_offset=(i * world + rank) * B, fast=fast, out_trials=out_trials, out_summary=out_summary,
-                        want_trials=not a.summary_only, bridge=bridge)
+                        want_trials=not a.summary_only, bridge=bridge, packed=packed)
         if gathered is not None:
             src = out_summary if a.gather == "summary" else out_trials
             if a.backend == "nccl":
@@ -405,7 +410,7 @@ def simulate_bench(a, ctx):
                    "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": KERNEL_NAME[a.model] % ("fast" if fast else "exact"),
+                     "kernel": KERNEL_NAME[a.model] % a.gauss,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
         "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
@@ -419,17 +424,18 @@ def simulate_bench(a, ctx):
         achieved_steps = em_steps / (kern_ms * 1e-3)
         rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        spb = 8 if packed else 4                     # Euler-Maruyama steps per Philox block
         if not a.no_ceiling:
-            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast)
+            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed)
             peak = c["steps_per_s_all_lanes_useful"]
             rv.update({"peak": peak / 1e9, "frac": achieved_steps / peak,
                        "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
                        "ceiling_measured_steps_per_s": c["steps_per_s"], "ceiling_lane_efficiency": c["lane_efficiency"],
                        "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"],
-                       "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 256.0 / peak})
-        im = issue_model(a.model, fast)
+                       "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 64.0 * spb / peak, "steps_per_block": spb})
+        im = issue_model(a.model, a.gauss)
         if im:
-            peak_im = simds * CLOCK_GHZ * 1e9 / im["cycles_per_block"] * 256.0
+            peak_im = simds * CLOCK_GHZ * 1e9 / im["cycles_per_block"] * 64.0 * im["steps_per_block"]
             rv.update({"issue_model": im, "peak_issue_model": peak_im / 1e9, "frac_vs_issue_model": achieved_steps / peak_im})
             if "frac" not in rv:
                 rv.update({"peak": peak_im / 1e9, "frac": achieved_steps / peak_im, "ceiling": "ISA issue model (no lockstep run)"})
@@ -446,7 +452,7 @@ def simulate_bench(a, ctx):
         dbg_ms = d0.elapsed_time(d1)
         _lib.lib().nddm_set_debug_counters(None)
         d = dbg.cpu().numpy().astype(np.float64)
-        lane_steps = d[0] * 256.0
+        lane_steps = d[0] * 64.0 * spb
         rv.update({"executed_lane_steps_per_launch": lane_steps, "lane_efficiency": em_steps / lane_steps,
                    "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -457,7 +463,7 @@ def simulate_bench(a, ctx):
                                      "per SIMD; tools/resource_table.py lists every kernel",
                             "note": "from in-kernel wave lifetimes (s_memrealtime); PMC SQ_WAVE_CYCLES in profiles/ agrees"}
         if not a.no_ks:
-            res["ks_vs_ref"] = ks_vs_golden(engine, a.model, a.dt, a.max_steps, fast)
+            res["ks_vs_ref"] = ks_vs_golden(engine, a.model, a.dt, a.max_steps, fast, packed)
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, p_host, a.model, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]

@@ -82,6 +82,10 @@ enum nddm_status {
 enum nddm_flags {
     NDDM_GAUSS_EXACT = 0,     /* Box-Muller from IEEE add/mul/fma/sqrt only: bit-reproducible on a CPU (oracle) */
     NDDM_GAUSS_FAST = 1,      /* Box-Muller on v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 */
+    NDDM_GAUSS_PACKED = 4,    /* opt-in, with either transform, not with NDDM_BRIDGE, max_steps < 2^14: one 32-bit Philox word per
+                                 Box-Muller pair (16-bit radius uniform + 16-bit angle) instead of two, i.e. 8 normals per
+                                 Philox block instead of 4 -- ~25 % faster.  The path noise then has |z| <= 5.65 and a 2^-16
+                                 grid in the radius; a different (equally reproducible) random stream than the default */
     NDDM_BRIDGE = 2           /* (alpha_not_scaled only) Brownian-bridge boundary correction: between two grid points
                                  inside (0, a) the path crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt));
                                  removes the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama against the exact

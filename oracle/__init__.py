@@ -118,7 +118,7 @@ def mt_ratcliff(N=100, Alpha=1, Tau=.4, Nu=1, Beta=.5, rangeTau=0, rangeBeta=0, 
 
 # ----------------------------------------------------------------------------- Philox mode
 def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, set_offset=0, bounds=None,
-                    ext_sigma=0.0, ext_mode=0, bridge=False, want_trials=True, want_k=False, want_summary=True,
+                    ext_sigma=0.0, ext_mode=0, bridge=False, packed=False, want_trials=True, want_k=False, want_summary=True,
                     want_ext=False, threads=1):
     """The device stream on the CPU: element-wise checker of the HIP kernels.
 
@@ -140,7 +140,7 @@ def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, s
     summ = np.empty((B, SUMMARY_K), np.float32) if want_summary else None
     ext = np.empty((B,), np.float32) if want_ext else None
     rc = L.oracle_philox_simulate(
-        model, int(bool(bridge)), _fptr(p), _fptr(bnd), B, n_trials, np.float32(dt), max_k, seed, set_offset,
+        model, int(bool(bridge)) | (2 if packed else 0), _fptr(p), _fptr(bnd), B, n_trials, np.float32(dt), max_k, seed, set_offset,
         np.float32(ext_sigma), ext_mode, _fptr(trials),
         None if k is None else k.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _fptr(summ), _fptr(ext),
         threads)

@@ -26,7 +26,7 @@ def _params(model, B, seed):
     return p[:, [0, 2, 3, 4]]                 # drift, beta, ter, dc
 
 
-def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, bridge=False, **kw):
+def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, bridge=False, packed=False, **kw):
     import oracle
     from bayesflow_nddms_amd import engine
     p = _params(model, B, 1234 + B)
@@ -35,10 +35,10 @@ def _run_both(model, B, N, dt, max_steps, seed, set_offset=0, fast=False, bridge
         bounds = np.abs(np.random.default_rng(5).normal(1.2, 0.4, size=(B, N))).astype(np.float32)
     want_ext = model == "alpha_ns"
     g = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast,
-                        bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, bridge=bridge, **kw)
+                        bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, bridge=bridge, packed=packed, **kw)
     o = oracle.philox_simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset,
                                bounds=bounds, ext_sigma=0.1, ext_mode=0, want_ext=want_ext, want_k=True, threads=8,
-                               bridge=bridge)
+                               bridge=bridge, packed=packed)
     g = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in g.items()}
     return p, g, o
 
@@ -111,6 +111,30 @@ def test_bridge_mode_bit_parity(dt, max_steps):
     from bayesflow_nddms_amd import engine
     with pytest.raises(ValueError):
         engine.simulate(0, prior_util.basic_prior(2, 1), 10, bridge=True)
+
+
+@pytest.mark.parametrize("model", list(MODELS))
+@pytest.mark.parametrize("dt,max_steps", [(0.01, 400.0), (0.001, 4000.0), (0.01, 403.0)])
+def test_packed_layout_bit_parity(model, dt, max_steps):
+    """NDDM_GAUSS_PACKED with the exact transform (8 normals per Philox block from 16 + 16 bit pairs): trials and fused
+    summaries of every model equal the oracle's restatement of the same layout bit for bit, also when the step cap is
+    not a multiple of 8; with the fast transform nearly every (step index, choice) pair is the same."""
+    p, g, o = _run_both(model, B=96, N=300, dt=dt, max_steps=max_steps, seed=2024, packed=True)
+    assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+    p, gf, o = _run_both(model, B=96, N=300, dt=dt, max_steps=max_steps, seed=2024, packed=True, fast=True)
+    assert (gf["trials"][..., 0] == o["trials"][..., 0]).mean() > 0.995
+    # a different stream than the default layout's
+    p, g4, _ = _run_both(model, B=96, N=300, dt=dt, max_steps=max_steps, seed=2024, packed=False)
+    assert (g4["trials"][..., 0] != g["trials"][..., 0]).mean() > 0.5
+
+
+def test_packed_layout_argument_checks():
+    from bayesflow_nddms_amd import engine
+    with pytest.raises(ValueError):
+        engine.simulate(3, prior_util.alpha_ns_prior(2, 1), 10, bridge=True, packed=True)
+    with pytest.raises(ValueError, match="2\\^14"):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, dt=1e-4, max_steps=20000, packed=True)
 
 
 @pytest.mark.parametrize("max_steps", [1.0, 2.0, 3.0, 5.0, 399.0, 401.0, 400.5])

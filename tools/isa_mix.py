@@ -27,9 +27,10 @@ SO = os.path.join(ROOT, "bayesflow_nddms_amd", "libnddm_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # template arguments <MODEL, FAST, CAP4, BRIDGE, SMALL> of the instantiations the named workloads launch (max_steps a
 # multiple of 4 and below 2^14, tiles of <= 512 trials)
-KERNELS = {"basic": (0, 1, 1, 0, 1), "single": (1, 1, 1, 0, 1), "single_alt": (2, 1, 1, 0, 1), "alpha_ns": (3, 1, 1, 0, 1),
-           "alpha_ns_bridge": (3, 1, 1, 1, 0), "explicit": (4, 1, 1, 0, 1)}
-KERNELS.update({k + "_exact": (m, 0, c, b, sm) for k, (m, f, c, b, sm) in list(KERNELS.items())})
+KERNELS = {"basic": (0, 1, 1, 0, 1, 0), "single": (1, 1, 1, 0, 1, 0), "single_alt": (2, 1, 1, 0, 1, 0), "alpha_ns": (3, 1, 1, 0, 1, 0),
+           "alpha_ns_bridge": (3, 1, 1, 1, 0, 0), "explicit": (4, 1, 1, 0, 1, 0)}
+KERNELS.update({k + "_exact": (m, 0, c, b, sm, pk) for k, (m, f, c, b, sm, pk) in list(KERNELS.items())})
+KERNELS.update({k + "_packed": (m, f, c, b, sm, 1) for k, (m, f, c, b, sm, pk) in list(KERNELS.items()) if not b})  # NDDM_GAUSS_PACKED
 
 # fallback costs (profiles/r1_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
 COST = {"v_mad_u64_u32": 4.69, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
@@ -103,7 +104,7 @@ def disassemble(so_path=SO):
 
 def kernel_insts(txt, targs):
     """[(address, mnemonic, operand text, branch target or None)] of one sim_kernel instantiation."""
-    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
+    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
     lines = txt.splitlines()
     start = next(i for i, l in enumerate(lines) if l.endswith(f"<{sym}>:"))
     insts = []
@@ -167,9 +168,10 @@ def main():
     cost, sgpr_cost, src = load_ubench(ubench)
     txt, digest = disassemble()
     result = {"library_sha256_16": digest, "issue_costs_from": src or "built-in table (profiles/r1_ubench_valu.txt)",
-              "unit": "SIMD cycles per wave64 Philox block (4 E-M steps x 64 lanes), sum of isolated issue costs", "kernels": {}}
+              "unit": "SIMD cycles per wave64 Philox block (steps_per_block E-M steps x 64 lanes), sum of isolated issue costs", "kernels": {}}
     for name in names:
         r = tally(step_loop(kernel_insts(txt, KERNELS[name])), cost, sgpr_cost)
+        r["steps_per_block"] = 8 if KERNELS[name][5] else 4
         result["kernels"][name] = r
         print(f"{name}: step loop = {r['valu']} VALU / {r['salu']} SALU / {r['lds']} LDS / {r['vmem']} VMEM instructions per block")
         for m in r["mix"]:

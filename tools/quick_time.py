@@ -18,7 +18,7 @@ from bayesflow_nddms_amd import engine, _lib
 LOCK = {0: [0.0, 50.0, 0.5, 0.3, 1.0], 1: [0.0, 50.0, 0.5, 0.3, 0.01, 1.0, 1.0, 1.0], 3: [0.0, 50.0, 0.5, 0.3, 0.0, 1.0]}
 
 
-def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lockstep=False, bridge=False):
+def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lockstep=False, bridge=False, packed=False):
     p = {0: prior_util.basic_prior, 1: prior_util.single_prior, 3: prior_util.alpha_ns_prior}[model](B, 2023)
     if lockstep:   # every trial runs to the cap: all lanes busy, no refill -> pure step-loop cost
         p[:] = np.array(LOCK[model], dtype=np.float32)
@@ -28,7 +28,7 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
         _lib.check(_lib.lib().nddm_set_tuning(*tune))
     out = torch.empty((B, N, 2), dtype=torch.float32, device="cuda") if trials_out else None
     summ = torch.empty((B, 10), dtype=torch.float32, device="cuda")
-    kw = dict(dt=dt, max_steps=ms, set_offset=0, fast=fast, out_trials=out, out_summary=summ, want_trials=trials_out, bridge=bridge)
+    kw = dict(dt=dt, max_steps=ms, set_offset=0, fast=fast, out_trials=out, out_summary=summ, want_trials=trials_out, bridge=bridge, packed=packed)
     engine.simulate(model, pd, N, seed=1, **kw)
     torch.cuda.synchronize()
     dbg = torch.zeros(8, dtype=torch.int64, device='cuda')
@@ -52,10 +52,11 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
     nresp = s[:, 0] + s[:, 1]
     tau = p[:, 3] - (0.5 * dt if bridge else 0.0)
     steps = float(((s[:, 3] - tau) / dt * nresp)[nresp > 0].sum() + s[:, 2].sum() * int(ms))
-    cyc = best * 1e-3 * 2.4e9 * 1024 / (steps / 256)
+    spb = 8 if packed else 4
+    cyc = best * 1e-3 * 2.4e9 * 1024 / (steps / 256)            # per 4 steps x 64 lanes, whatever the block size
     resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / 1024.0
-    print(f"model={model} B={B} N={N} dt={dt} cap={int(ms)} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge}: "
-          f"{best:.3f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  {cyc:.0f} cyc/useful-block | lane-eff {steps/(d[0]*256):.3f} "
+    print(f"model={model} B={B} N={N} dt={dt} cap={int(ms)} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge} packed={packed}: "
+          f"{best:.3f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  {cyc:.0f} cyc/useful-block | lane-eff {steps/(d[0]*64*spb):.3f} "
           f"blocks/refill {d[0]/max(d[1],1):.1f} clock {d[2]/max(d[3],1)*0.1:.3f} GHz waves {d[4]:.0f} resident/SIMD {resident:.2f}", flush=True)
     _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
@@ -70,7 +71,7 @@ if __name__ == "__main__":
                 if fl.startswith("tune="):
                     tune = tuple(int(x) for x in fl[5:].split("/"))
             run(int(f[1]), int(f[2]), float(f[3]), float(f[4]), fast="exact" not in flags, model=int(f[0]), trials_out="notrials" not in flags,
-                lockstep="lockstep" in flags, bridge="bridge" in flags, tune=tune)
+                lockstep="lockstep" in flags, bridge="bridge" in flags, packed="packed" in flags, tune=tune)
         sys.exit(0)
     B = 1000000
     run(B, 300, 0.001, 4000)
