@@ -464,6 +464,26 @@ def simulate_bench(a, ctx):
                             "note": "from in-kernel wave lifetimes (s_memrealtime); PMC SQ_WAVE_CYCLES in profiles/ agrees"}
         if not a.no_ks:
             res["ks_vs_ref"] = ks_vs_golden(engine, a.model, a.dt, a.max_steps, fast, packed)
+        if not packed and not bridge and fast and not a.no_ks:
+            # the opt-in NDDM_GAUSS_PACKED layout on the same batch, outside the timed region: reported beside the
+            # headline, never as the headline
+            def pk(i):
+                engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023, set_offset=i * B, fast=True,
+                                out_trials=out_trials, out_summary=out_summary, want_trials=not a.summary_only, packed=True)
+            pk(0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(3):
+                pk(1 + i)
+            e1.record()
+            torch.cuda.synchronize()
+            pk_ms = e0.elapsed_time(e1) / 3
+            res["packed_gauss"] = {"value": B * N / (pk_ms * 1e-3), "unit": "trials/s", "kernel_ms": pk_ms,
+                                   "em_steps_per_s": em_steps_of(out_summary, p_dev[:, tau_i], a.dt, max_k, False) / (pk_ms * 1e-3),
+                                   "ks_vs_ref": ks_vs_golden(engine, a.model, a.dt, a.max_steps, True, True),
+                                   "what": "same workload with flags |= NDDM_GAUSS_PACKED (opt-in: 8 normals per Philox block from "
+                                           "16 + 16 bit Box-Muller pairs; include/nddm.h), 3 launches outside the timed region"}
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, p_host, a.model, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]

@@ -32,6 +32,7 @@ def test_bench_json_contract():
     rv = d["roofline_valu"]
     assert 0 < rv["frac"] < 1.05 and rv["ceiling_measured_steps_per_s"] > 0           # ceiling measured in the same run
     assert "arithmetic" in d["config"] and d["cpu_baseline"]["numpy_port"]["reference_default"]["dt"] == 0.01
+    assert d["config"]["gauss"] == "fast" and d["packed_gauss"]["ks_vs_ref"]["max"] < 0.01     # opt-in mode: beside, not as, the headline
 
 
 @pytest.mark.parametrize("model", ["single", "alpha_ns_bridge"])
