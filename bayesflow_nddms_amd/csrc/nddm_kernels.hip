@@ -6,27 +6,29 @@
 //   alpha_not_scaled.py:52-128 generator recast as an Euler-Maruyama process.
 //
 // Execution design:
-//   * one 64-lane wavefront per workgroup, PERSISTENT grid (as many waves as stay resident);
-//     a wave pulls CHUNKS of consecutive parameter sets from a device-wide atomic counter and
-//     streams through them without draining between chunks.
-//   * sets are pulled longest-expected-duration first (a counting sort by the DDM's closed-form
-//     mean first-passage time runs ahead of the simulator), so the launch has no slow-set tail and
-//     the lanes of a wave work on trials of similar length.
+//   * a pre-pass writes one 48-byte HAND-OUT RECORD per parameter set -- everything of a trial hand-out that is
+//     floating-point arithmetic on the parameter row -- in PROCESSING order: longest expected trials first (a counting
+//     sort by the DDM's closed-form mean first-passage time), so the launch has no slow-set tail and the lanes of a wave
+//     work on trials of similar length.  The simulator never reads the parameter rows.
+//   * one 64-lane wavefront per workgroup, PERSISTENT grid (as many waves as stay resident: 8 per SIMD); a wave pulls
+//     CHUNKS of consecutive records from a device-wide atomic counter and streams through them without draining
+//     between chunks; the next tile's record is loaded one tile ahead.
 //   * one lane = one trial at a time.  Trial length is heavy-tailed (median 107, p99 2243
 //     steps at dt=.001), so lanes are PERSISTENT: a lane whose trial has ended retires it and
 //     takes the next unassigned (set, trial) of the wave's stream in order (wave ballot +
 //     prefix count), instead of idling until the slowest trial of its set ends.
 //   * results are staged in an LDS ring of per-set slots as packed (step index | choice);
 //     when the last trial of a set retires the wave FLUSHES the slot: one coalesced float2
-//     store sweep to HBM plus the fused per-set summary reduction (integer sums reduced
-//     across the wave with shuffles, so summaries are bit-reproducible).
+//     store sweep to HBM (every line written whole, once; the external datum of the models that have one is recomputed
+//     there from the trial's auxiliary stream) plus the fused per-set summary reduction (integer sums reduced across
+//     the wave with DPP adds, so summaries are bit-reproducible).
 //   * the evidence is carried centred and in noise units, w = (x - a/2) / sigma: one step is
 //     w = fma(r, cos|sin, w) + mu with the unit Box-Muller radius, the range test is |w| < h.
-//     Everything of a hand-out that is constant within a set (mu, 1/sigma, h, w0, the Philox
-//     products of the set words) is computed once per tile into a 48-byte LDS record.
 //   * the Gaussian stream is counter-based (nddm_rng.h): no RNG state is loaded or stored.
 //     Philox's wave-uniform round keys are served from LDS as broadcast reads, because a VALU xor
 //     that reads an SGPR operand issues at half the rate of a VGPR-only one on gfx950.
+//   * what limits residency is the SGPR file (<= 74 SGPRs for 8 waves per SIMD): hence the kernarg reads at the point of
+//     use, the single LDS record per slot, the SMALL template split.
 //
 // The path is VALU/transcendental-bound: 8 B are written per trial for ~246 Gaussian draws.
 #include <hip/hip_runtime.h>
