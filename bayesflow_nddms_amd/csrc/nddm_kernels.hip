@@ -1112,13 +1112,14 @@ static int resident_waves(K kernel, size_t lds_bytes, int cus)
 
 template <int MODEL, bool BRIDGE>
 static int launch_model(const SimArgs &A, bool fast, bool packed, size_t lds_bytes, int n_chunks, int cus, int grid_override,
-                        hipStream_t st)
+                        bool grid_forced, hipStream_t st)
 {
     const bool cap4 = (A.max_k % (packed ? 8 : 4)) == 0;     // the step cap falls on a block boundary
     const dim3 block(WAVE);
 #define NDDM_LAUNCH(KERNEL)                                                                    \
     do {                                                                                       \
-        int waves = grid_override > 0 ? grid_override : resident_waves(KERNEL, lds_bytes, cus);\
+        int waves = resident_waves(KERNEL, lds_bytes, cus);                                    \
+        if (grid_override > 0 && (grid_override < waves || grid_forced)) waves = grid_override;\
         if (waves > n_chunks) waves = n_chunks;                                                \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
@@ -1217,8 +1218,23 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
     // wave to balance; from ~30M trials on, one tile of up to 512 trials per set is the efficient shape
     const long long total_trials = B * (long long)n_trials;
+    // Grid: as many waves as stay resident -- unless the launch is small.  Then fewer, busier waves win: a wave that gets
+    // ~300+ wave-blocks of work (64 lanes x 4 steps each) keeps its lanes balanced and amortises its start-up, and the
+    // launch's tail (its longest trial) runs on SIMDs that are less crowded.  Measured (dt=.01, 10k-30k sets x 300 trials,
+    // or 100k x 60): 1024-3072 waves are 25-45 % faster than 8192; from ~2.5M wave-blocks on the full grid is best; never
+    // below one wave per SIMD.
+    long long plan_waves = 8ll * simds;
+    if (tun.grid_waves > 0) plan_waves = tun.grid_waves;
+    else {
+        double est_steps = 0.25 / (double)dt;                            // E[steps] under the reference priors
+        if (est_steps > (double)max_steps) est_steps = (double)max_steps;
+        if (est_steps < 1.0) est_steps = 1.0;
+        const double want = (double)total_trials * est_steps / 256.0 / 300.0;
+        if (want < (double)plan_waves) plan_waves = want < (double)simds ? simds : (long long)want;
+    }
+    const long long waves_for_tiles = plan_waves < waves7 ? plan_waves : waves7;
     int tile_cap = 64;
-    while (tile_cap < 512 && (long long)tile_cap * waves7 * 8 < total_trials) tile_cap <<= 1;
+    while (tile_cap < 512 && (long long)tile_cap * waves_for_tiles * 8 < total_trials) tile_cap <<= 1;
     int tiles = tun.tile_trials > 0 ? (n_trials + tun.tile_trials - 1) / tun.tile_trials
                                     : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
     const int tile_n = (n_trials + tiles - 1) / tiles;
@@ -1235,7 +1251,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         spc = (1200 + tile_n - 1) / tile_n;
         if (spc < 1) spc = 1;
         if (spc > 64) spc = 64;
-        while (spc > 1 && vB / spc < 32 * waves7) spc >>= 1;   // keep >= ~32 chunks per resident wave: the launch's tail is one chunk
+        while (spc > 1 && vB / spc < 32 * waves_for_tiles) spc >>= 1;   // keep >= ~32 chunks per wave: the launch's tail is one chunk
         // ... but the queue is ONE atomic word: same-address atomics retire at ~85 M/s on MI355X (measured: 1M chunks
         // take 11.6 ms whatever the work; contention already costs 15 % at 55 M/s), so short-trial workloads (dt = .01,
         // few trials per set) must pull less often: at most ~40 M chunks/s over the shortest time the launch can take --
@@ -1365,16 +1381,16 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "pre-pass (hand-out records): %s", hipGetErrorString(e));
     }
     if (rc == NDDM_OK) {
-        const int gw = tun.grid_waves;   // 0 = as many waves as stay resident
+        const int gw = plan_waves < 8ll * simds || tun.grid_waves > 0 ? (int)plan_waves : 0;     // 0 = what is resident
         switch (model) {
-        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
-        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
-        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         case NDDM_ALPHA_NOT_SCALED:
-            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st)
-                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st);
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st);
             break;
-        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, st); break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         }
     }
     if (rc == NDDM_OK && A.partials) {
