@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 
 #include "../../include/nddm.h"
 #include "nddm_rng.h"
@@ -989,6 +990,7 @@ struct LaunchSlot {
 };
 static LaunchSlot *g_slots[MAX_DEVICES][MAX_SLOTS];
 static int g_nslots[MAX_DEVICES];
+static int g_slot_limit = MAX_SLOTS;       // nddm_debug_set_slot_limit: lets a test reach the "all slots in flight" path
 
 // hipMalloc with the calling thread's capture mode relaxed: another thread (or this one) may be capturing a graph, and a
 // plain hipMalloc is refused then
@@ -1001,23 +1003,37 @@ static hipError_t malloc_relaxed(void **p, size_t bytes)
     return e;
 }
 
+static LaunchSlot *acquire_slot_once(int dev, hipStream_t st, hipError_t *err);
+
+// every slot can be momentarily busy (other threads in the middle of enqueueing): wait for one of them to finish
 static LaunchSlot *acquire_slot(int dev, hipStream_t st, hipError_t *err)
+{
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        LaunchSlot *s = acquire_slot_once(dev, st, err);
+        if (s || *err != hipErrorNotReady) return s;
+        std::this_thread::yield();
+    }
+    return nullptr;
+}
+
+static LaunchSlot *acquire_slot_once(int dev, hipStream_t st, hipError_t *err)
 {
     *err = hipSuccess;
     std::lock_guard<std::mutex> lock(g_mu);
     LaunchSlot *pick = nullptr;
+    const int n_use = g_nslots[dev] < g_slot_limit ? g_nslots[dev] : g_slot_limit;      // slots in use (all, unless a test caps them)
     // (a) the slot this stream used last: stream order makes it safe without a query.  hipStreamPerThread is one handle
     //     for a different stream in every thread, so it never qualifies.
     if (st != hipStreamPerThread)
-        for (int i = 0; i < g_nslots[dev] && !pick; ++i)
+        for (int i = 0; i < n_use && !pick; ++i)
             if (!g_slots[dev][i]->busy && g_slots[dev][i]->stream == st && !g_slots[dev][i]->fresh) pick = g_slots[dev][i];
     // (b) any slot whose last launch has completed
-    for (int i = 0; i < g_nslots[dev] && !pick; ++i) {
+    for (int i = 0; i < n_use && !pick; ++i) {
         LaunchSlot *s = g_slots[dev][i];
         if (!s->busy && (s->fresh || hipEventQuery(s->done) == hipSuccess)) pick = s;
     }
     // (c) a new slot
-    if (!pick && g_nslots[dev] < MAX_SLOTS) {
+    if (!pick && g_nslots[dev] < g_slot_limit) {
         LaunchSlot *s = new LaunchSlot();
         hipError_t e = malloc_relaxed(reinterpret_cast<void **>(&s->base), SLOT_QUEUE_BYTES + SLOT_SCRATCH);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
@@ -1033,9 +1049,9 @@ static LaunchSlot *acquire_slot(int dev, hipStream_t st, hipError_t *err)
         g_slots[dev][g_nslots[dev]++] = s;
         pick = s;
     }
-    // (d) all MAX_SLOTS slots are in flight on other streams: queue behind the one used longest ago
+    // (d) every slot is in flight on other streams: queue behind the one used longest ago
     if (!pick) {
-        for (int i = 0; i < g_nslots[dev] && !pick; ++i)
+        for (int i = 0; i < n_use && !pick; ++i)
             if (!g_slots[dev][i]->busy) pick = g_slots[dev][i];
         if (!pick) { *err = hipErrorNotReady; return nullptr; }
         const hipError_t e = hipStreamWaitEvent(st, pick->done, 0);
@@ -1043,8 +1059,8 @@ static LaunchSlot *acquire_slot(int dev, hipStream_t st, hipError_t *err)
         // rotate it to the back so that the next starved launch waits on a different slot
         int at = 0;
         while (g_slots[dev][at] != pick) ++at;
-        for (int i = at; i + 1 < g_nslots[dev]; ++i) g_slots[dev][i] = g_slots[dev][i + 1];
-        g_slots[dev][g_nslots[dev] - 1] = pick;
+        for (int i = at; i + 1 < n_use; ++i) g_slots[dev][i] = g_slots[dev][i + 1];
+        g_slots[dev][n_use - 1] = pick;
     }
     pick->busy = true;
     pick->stream = st;
@@ -1466,6 +1482,14 @@ int nddm_set_debug_counters(void *dev_u64x8)
 {
     std::lock_guard<std::mutex> lock(nddm::g_mu);
     nddm::g_dbg = static_cast<unsigned long long *>(dev_u64x8);
+    return NDDM_OK;
+}
+
+/* testing aid: cap on the number of launch slots per device that are handed out (1..256) */
+int nddm_debug_set_slot_limit(int n)
+{
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
+    nddm::g_slot_limit = n < 1 ? 1 : (n > nddm::MAX_SLOTS ? nddm::MAX_SLOTS : n);
     return NDDM_OK;
 }
 

@@ -103,6 +103,9 @@ int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
 /* frees the memory held for launches captured into hipGraphs on the current device; call only when every graph that
  * captured a launch of this library has been destroyed */
 int nddm_release_graph_memory(void);
+/* testing aid (not part of the drop-in surface): cap the number of launch slots per device, so that a test can drive the
+ * library into queueing a launch behind an in-flight one */
+int nddm_debug_set_slot_limit(int n);
 
 /* ---- simulators --------------------------------------------------------------------
  * Common arguments:

@@ -60,6 +60,38 @@ def test_ks_packed_layout_vs_reference(ci):
     print(f"packed layout dt={dt}: max KS over the fixed sets {worst:.4f}")
 
 
+def test_packed_layout_large_sample_agrees_with_default_layout():
+    """3e8 trials per layout on the same 1M prior-drawn parameter sets (BASELINE configs[1]'s shape): the pooled choice
+    probabilities and the pooled mean / second moment of the step index of the opt-in NDDM_GAUSS_PACKED layout agree with
+    the default layout's within sampling error (a resolution of ~1e-4, two orders below the KS bar), and so do the per-set
+    mean RTs on average."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N, dt, ms = 1_000_000, 300, 0.001, 4000
+    p = torch.as_tensor(prior_util.basic_prior(B, 2023)).cuda()
+    stats = []
+    for packed in (False, True):
+        r = engine.simulate(engine.BASIC_DDM_DC, p, N, dt=dt, max_steps=ms, seed=77, set_offset=0, fast=True, packed=packed,
+                            want_trials=False)
+        s = r["summary"].double()
+        n_resp = s[:, 0] + s[:, 1]
+        k_mean = torch.where(n_resp > 0, (s[:, 3] - p[:, 3].double()) / dt, torch.zeros_like(n_resp))
+        k_var = torch.where(n_resp > 0, s[:, 4] / dt ** 2, torch.zeros_like(n_resp))
+        tot = float(n_resp.sum())
+        stats.append({"p_up": float(s[:, 0].sum()) / (B * N), "p_miss": float(s[:, 2].sum()) / (B * N),
+                      "mean_k": float((k_mean * n_resp).sum()) / tot,
+                      "m2_k": float(((k_var + k_mean ** 2) * n_resp).sum()) / tot, "set_mean_k": k_mean})
+    a, b = stats
+    sd_k = (a["m2_k"] - a["mean_k"] ** 2) ** 0.5
+    n = B * N
+    assert abs(a["p_up"] - b["p_up"]) < 6 * (0.25 * 2 / n) ** 0.5                       # 6 sigma of a difference of proportions
+    assert abs(a["p_miss"] - b["p_miss"]) < 6 * (a["p_miss"] * 2 / n) ** 0.5
+    assert abs(a["mean_k"] - b["mean_k"]) < 6 * sd_k * (2 / n) ** 0.5, (a["mean_k"], b["mean_k"], sd_k)
+    assert abs(a["m2_k"] / b["m2_k"] - 1) < 1e-3
+    d = (a["set_mean_k"] - b["set_mean_k"])                                              # per set: noise only, no bias
+    assert abs(float(d.mean())) < 0.2 and 200 < a["mean_k"] < 300
+
+
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("ci", [0, 1])
 def test_ks_basic_vs_reference(ci, fast):

@@ -168,3 +168,30 @@ def test_tuning_knobs_are_snapshotted_per_call():
     finally:
         stop.set()
         th.join()
+
+
+def test_more_streams_than_launch_slots():
+    """With the slot limit forced down to the slots that already exist, launches on six fresh streams must queue behind
+    in-flight launches of other streams (a stream-side wait on the slot's completion event) -- and still be right."""
+    import torch
+    from bayesflow_nddms_amd import _lib, engine
+    p_dev = torch.as_tensor(prior_util.basic_prior(4096, 15)).cuda()
+    cases = _cases()
+    ref = [_run(engine, torch, p_dev, c) for c in cases]
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    L.nddm_debug_set_slot_limit(1)
+    try:
+        streams = [torch.cuda.Stream() for _ in range(6)]
+        got = []
+        for it in range(120):
+            ci = it % len(cases)
+            with torch.cuda.stream(streams[it % 6]):
+                if it % 17 == 0:
+                    torch.cuda._sleep(int(2e7))
+                got.append((ci, _run(engine, torch, p_dev, cases[ci])))
+        torch.cuda.synchronize()
+    finally:
+        L.nddm_debug_set_slot_limit(256)
+    for ci, (t, s) in got:
+        assert _same(torch, t, ref[ci][0]) and _same(torch, s, ref[ci][1]), ci
