@@ -1,5 +1,5 @@
 """Larger-scale bit parity of the GPU exact mode against the oracle than the small unit cases (ordering pre-pass
-active, many queue chunks, ring wrap-around, split sets), every model, default tuning.  `python tools/stress_parity.py`
+active, many queue chunks, ring wrap-around, split sets), every model, both bit layouts, default tuning.  `python tools/stress_parity.py`
 runs all sizes (~80M trials, ~20 s on one MI355X + 16 host threads); tests/test_gpu_fuzz.py runs a subset."""
 import os
 import sys
@@ -37,11 +37,11 @@ def run(sizes=SIZES, models=range(5), verbose=True, threads=16):
     bad = []
     for model in models:
         for B, N in sizes:
-            for bridge in ((False, True) if model == 3 else (False,)):
+            for bridge, packed in (((False, False), (False, True), (True, False)) if model == 3 else ((False, False), (False, True))):
                 p = params_for(model, B)
                 bounds = np.abs(rng.normal(1.2, 0.5, size=(B, N))).astype(np.float32) if model == 4 else None
                 kw = dict(dt=0.001, max_steps=4000, seed=2024 + model, set_offset=123456789, bounds=bounds,
-                          ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge)
+                          ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge, packed=packed)
                 t0 = time.time()
                 g = engine.simulate(model, p, N, fast=False, **kw)
                 gt, gs = g["trials"].cpu().numpy(), g["summary"].cpu().numpy()
@@ -52,9 +52,9 @@ def run(sizes=SIZES, models=range(5), verbose=True, threads=16):
                       and np.array_equal(np.nan_to_num(gs).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
                       and (model != 3 or np.array_equal(g["ext"].cpu().numpy().view(np.uint32), o["ext"].view(np.uint32))))
                 if not ok:
-                    bad.append((model, B, N, bridge))
+                    bad.append((model, B, N, bridge, packed))
                 if verbose:
-                    print(f"model {model} B={B} N={N} bridge={bridge}: {'OK' if ok else 'MISMATCH'}  ({B * N} trials; "
+                    print(f"model {model} B={B} N={N} bridge={bridge} packed={packed}: {'OK' if ok else 'MISMATCH'}  ({B * N} trials; "
                           f"gpu {t1 - t0:.2f}s oracle {t2 - t1:.2f}s)", flush=True)
     return bad
 
