@@ -1,0 +1,50 @@
+"""CPU test (hipcc cross-compiles without a GPU): the register budget that keeps 8 waves per SIMD resident is part of
+the design (the SGPR file limits these kernels -- <= 74 SGPRs, <= 64 VGPRs, no scratch), so a
+change that silently pushes a fast kernel over it fails here instead of showing up as a 3-10 % throughput loss."""
+import os
+import shutil
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc missing")
+def test_fast_kernels_fit_eight_waves_per_simd():
+    import resource_table as rt
+    rows = {rt.pretty(r["name"]): r for r in rt.collect()}
+    sims = {k: v for k, v in rows.items() if k.startswith("sim_kernel<")}
+    assert len(sims) >= 60                                   # 5 models x {fast, exact} x {cap4} x {small, packed, ...} + bridge
+    for name, r in sims.items():
+        assert r.get("ScratchSize [bytes/lane]", 0) == 0, name               # no private scratch anywhere
+        assert r.get("VGPRs Spill", 0) == 0 and r.get("SGPRs Spill", 0) == 0, name
+    fast_small = [k for k in sims if ", fast," in k and "small=1" in k]
+    assert len(fast_small) == 20                             # 5 models x cap4 {0,1} x packed {0,1}
+    for name in fast_small:
+        v, s = sims[name]["VGPRs"], sims[name]["TotalSGPRs"]
+        assert rt.waves_by_vgpr(v) == 8 and rt.waves_by_sgpr(s) == 8, (name, v, s)
+    # the bridge kernel (alpha_not_scaled, 32-bit staging) as well
+    for name in sims:
+        if ", fast," in name and "bridge=1" in name:
+            assert rt.waves_by_sgpr(sims[name]["TotalSGPRs"]) == 8 and rt.waves_by_vgpr(sims[name]["VGPRs"]) == 8, name
+
+
+def test_issue_model_reads_the_shipped_library():
+    """tools/isa_mix.py finds the step loop in the shipped library's code object: 65 VALU instructions per 4-step block
+    for every fast non-bridge model, 16 of them the Philox multiplies; 8 steps per block with the packed layout."""
+    import isa_mix as im
+    from bayesflow_nddms_amd.build import SO_PATH, build_hip
+    build_hip()
+    assert os.path.exists(SO_PATH)
+    txt, digest = im.disassemble(SO_PATH)
+    cost, sgpr_cost, _ = im.load_ubench(None)
+    for name in ("basic", "single", "alpha_ns", "explicit"):
+        body = im.step_loop(im.kernel_insts(txt, im.KERNELS[name]))
+        t = im.tally(body, cost, sgpr_cost)
+        assert t["valu"] == 65 and t["vmem"] == 0, (name, t["valu"])
+        assert sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
+    t = im.tally(im.step_loop(im.kernel_insts(txt, im.KERNELS["basic_packed"])), cost, sgpr_cost)
+    assert 95 <= t["valu"] <= 105 and sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
