@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NDDM_HIP_LIB: developer override (A/B runs of differently built libraries); the product path is the in-tree library
 SO_PATH = os.environ.get("NDDM_HIP_LIB") or os.path.join(_HERE, "libnddm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "nddm_kernels.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "nddm_rng.h"),
-           os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
+HEADERS = [os.path.join(_HERE, "csrc", "nddm_rng.h"), os.path.join(_HERE, "csrc", "nddm_sim.h"),
+           os.path.join(_HERE, "csrc", "nddm_prepass.h"), os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
 # -ffp-contract=off: the exact Gaussian transform spells out every fma; contraction would change roundings
 HIPCC_FLAGS = ["-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"]
 

@@ -31,6 +31,9 @@
 //     use, the single LDS record per slot, the SMALL template split.
 //
 // The path is VALU/transcendental-bound: 8 B are written per trial for ~246 Gaussian draws.
+//
+// This translation unit: nddm_rng.h (random stream) -> nddm_sim.h (sim_kernel) -> nddm_prepass.h (pre-pass, combine, prior)
+// -> below: the host side (launch slots, sizing, dispatch) and the extern "C" entry points.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -41,899 +44,11 @@
 #include <thread>
 
 #include "../../include/nddm.h"
+#include "nddm_prepass.h"
 #include "nddm_rng.h"
+#include "nddm_sim.h"
 
 namespace nddm {
-
-constexpr int WAVE = 64;
-constexpr int MAX_REJECT = 64;   // cap of the per-trial latent's rejection loop (P(reject) <= 1/2 per draw)
-
-template <int MODEL> struct ModelTraits;
-template <> struct ModelTraits<NDDM_BASIC_DDM_DC>      { static constexpr int P = 5; static constexpr bool HAS_Z = false; static constexpr int TAU = 3; };
-template <> struct ModelTraits<NDDM_SINGLE_TRIAL>      { static constexpr int P = 8; static constexpr bool HAS_Z = true;  static constexpr int TAU = 3; };
-template <> struct ModelTraits<NDDM_SINGLE_TRIAL_ALT>  { static constexpr int P = 8; static constexpr bool HAS_Z = true;  static constexpr int TAU = 3; };
-template <> struct ModelTraits<NDDM_ALPHA_NOT_SCALED>  { static constexpr int P = 6; static constexpr bool HAS_Z = false; static constexpr int TAU = 3; };
-template <> struct ModelTraits<NDDM_EXPLICIT_BOUNDARY> { static constexpr int P = 4; static constexpr bool HAS_Z = true;  static constexpr int TAU = 2; };
-
-struct SimArgs {
-    const float *params;      // [B, P]
-    const float *bounds;      // [B, N] (explicit-boundary model) or null
-    float *out_trials;        // [B, N, 2] or null
-    float *out_summary;       // [B, K] or null
-    float *out_ext;           // [B] or null
-    long long B;
-    unsigned long long set_offset;
-    int n_trials;             // trials per TILE (a set is split into tiles_per_set tiles when it does not fit the LDS ring)
-    int n_total;              // trials per set (row stride of out_trials / bounds)
-    int tiles_per_set;
-    unsigned long long *partials;   // [B * tiles_per_set, partial_words()] integer partial sums of the tiles (summaries requested), else null
-    const uint32_t *recs;     // [B, REC] per-set hand-out records in PROCESSING order (longest expected trials first when
-                              // the launch is large enough to be sorted, else as given): make_record() / prep_kernel
-    int max_k;
-    float dt;
-    float sqrt_dt;
-    float tscale;             // seconds per unit of the packed time field: dt, or dt/256 with the bridge correction
-    uint32_t k0, k1;
-    int sets_per_chunk;
-    int n_chunks;
-    unsigned int *chunk_counter;   // device words [0] next chunk to hand out, [1] waves that have left; both are zero
-                                   // between launches: the last wave to leave resets them
-    int ring;                 // LDS ring slots (power of two)
-    int open_ahead;           // tiles staged ahead of the one being handed out (0 when work is scarce, else 1)
-    float ext_sigma;
-    int ext_mode;
-    unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
-    int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384;
-                              // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
-    int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
-    int max_blocks;           // (unused by the kernels: the block limit is 16, switched off by refill_thresh >= 64)
-};
-
-// The launch arguments as they sit in the kernarg segment (constant address space: scalar loads).  The rarely executed
-// parts of the kernel (opening a tile, flushing a set) read their arguments through this pointer at the point of use,
-// behind a compiler barrier, instead of keeping ~30 SGPRs live through the step loop: SGPRs, not VGPRs, limit these
-// kernels' residency.
-typedef const __attribute__((address_space(4))) SimArgs *ArgsPtr;
-__device__ __forceinline__ ArgsPtr fresh_args(ArgsPtr p)
-{
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// auxiliary normal `a` of (set, trial): stream 1.  One Philox block serves normals 4b..4b+3.  Everything lives in named
-// registers (an array indexed by `a & 3` ends up in private scratch): the common hand-out asks for normals 0 and 1 --
-// one Box-Muller pair, first_pair() -- and only a rejected draw goes on to normal(a), which evaluates the pair that
-// holds normal `a` and selects its cosine or sine half.
-template <bool FAST>
-struct AuxStream {
-    uint32_t trial, set_lo, c3, blk, kbase;
-    u32x4 x;
-    __device__ __forceinline__ AuxStream(uint32_t kbase_, uint32_t set_lo_, uint32_t set_hi28, uint32_t trial_)
-        : trial(trial_), set_lo(set_lo_), c3(set_hi28 | 0x10000000u), blk(0xffffffffu), kbase(kbase_) {}
-    __device__ __forceinline__ void block(uint32_t b)
-    {
-        if (b != blk) { x = philox4x32_10_lds(set_lo, trial, c3, b, kbase); blk = b; }
-    }
-    // normals 0 and 1
-    __device__ __forceinline__ void first_pair(float &z0, float &z1)
-    {
-        block(0u);
-        float r, cs, sn;
-        polar_pair<FAST>(x.x, x.y, r, cs, sn);
-        r *= noise_unit<FAST>(1.0f);
-        z0 = r * cs; z1 = r * sn;
-    }
-    __device__ __forceinline__ float normal(uint32_t a)
-    {
-        block(a >> 2);
-        const bool second = (a & 2u) != 0u;
-        float r, cs, sn;
-        polar_pair<FAST>(second ? x.z : x.x, second ? x.w : x.y, r, cs, sn);
-        r *= noise_unit<FAST>(1.0f);
-        return r * ((a & 1u) ? sn : cs);
-    }
-};
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
-}
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-__device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, int n_miss, unsigned long long sk,
-                                                 unsigned long long sk2, unsigned long long sk_up,
-                                                 unsigned long long sk2_up, long long sz, long long szz, int n_total,
-                                                 float tscale, float tau)
-{
-    const double dtd = (double)tscale, taud = (double)tau;
-    const double n_resp = (double)(n_up + n_lo);
-    o[0] = (float)n_up; o[1] = (float)n_lo; o[2] = (float)n_miss;
-    if (n_resp > 0) {
-        const double mk = (double)sk / n_resp;
-        const double vk = (double)sk2 / n_resp - mk * mk;
-        o[3] = (float)(taud + dtd * mk);
-        o[4] = (float)(dtd * dtd * vk);
-    } else { o[3] = __builtin_nanf(""); o[4] = __builtin_nanf(""); }
-    if (n_up > 0) {
-        const double nu = (double)n_up;
-        const double mk = (double)sk_up / nu;
-        const double vk = (double)sk2_up / nu - mk * mk;
-        o[5] = (float)(taud + dtd * mk);
-        o[6] = (float)(dtd * dtd * vk);
-    } else { o[5] = __builtin_nanf(""); o[6] = __builtin_nanf(""); }
-    const double Nd = (double)n_total;
-    const double mz = ((double)sz / 4294967296.0) / Nd;
-    const double vz = ((double)szz / 16777216.0) / Nd - mz * mz;
-    o[7] = (float)mz;
-    o[8] = (float)vz;
-    o[9] = (float)(((double)n_up + 0.5 * (double)n_miss) / Nd);
-}
-
-// Per-set constants of the trial hand-out.  Everything that is floating-point arithmetic on the parameter row is done
-// ONCE per set by a pre-pass (prep_kernel, or the scatter pass of the longest-first sort) into a REC-dword record, stored
-// in PROCESSING order so that a wave streams them sequentially; the simulator loads the record of the next tile one tile
-// ahead (one 48-byte vector load, consumed a few thousand cycles later) and never reads the parameter rows itself:
-//   r[0..3]  A   basic / alpha_ns / explicit: drift*dt/S (alpha_ns: Nu; per-trial drift), 1/S, a/(2S), (a*beta - a/2)/S
-//                (explicit: beta, 0 in the last two);  single: drift*dt/S, 1/S, std_alpha, mu_alpha;
-//                single_alt (noise scale per trial): drift, alpha, beta, std_dc
-//   r[4..7]  B   single: sigma1, gamma, beta;  single_alt: mu_dc, sigma1, gamma;  alpha_ns: Eta
-//   r[8]     the set's row index in the caller's arrays, r[9] tau
-// S = noise_unit(sqrt(dt) * dc): the state is carried in noise units (nddm_rng.h).
-enum { REC = 12, R_A = 0, R_B = 4, R_SET = 8, R_TAU = 9 };
-
-__device__ __forceinline__ void make_record(int model, bool fast, const float *row, float dt, float sqrt_dt, int set,
-                                            uint32_t *r)
-{
-    float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 1.0f, tau;
-    float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-    switch (model) {
-    case NDDM_BASIC_DDM_DC: drift = row[0]; a = row[1]; beta = row[2]; tau = row[3]; sig_c = row[4]; break;
-    case NDDM_SINGLE_TRIAL: drift = row[0]; beta = row[2]; tau = row[3]; sig_c = row[5]; b0 = row[6]; b1 = row[7]; b2 = row[2]; break;
-    case NDDM_SINGLE_TRIAL_ALT: tau = row[3]; b0 = row[5]; b1 = row[6]; b2 = row[7]; break;
-    case NDDM_ALPHA_NOT_SCALED: a = row[1]; beta = row[2]; tau = row[3]; sig_c = row[5]; b0 = row[4]; break;
-    default: drift = row[0]; beta = row[1]; tau = row[2]; sig_c = row[3]; break;
-    }
-    const float unit = sqrt_dt * sig_c;
-    const float inv_s = 1.0f / (fast ? noise_unit<true>(unit) : noise_unit<false>(unit));
-    const float hv = 0.5f * a;
-    float a0 = (drift * dt) * inv_s, a1 = inv_s, a2 = hv * inv_s, a3 = (a * beta - hv) * inv_s;
-    if (model == NDDM_SINGLE_TRIAL) { a2 = row[4]; a3 = row[1]; }
-    else if (model == NDDM_SINGLE_TRIAL_ALT) { a0 = row[0]; a1 = row[1]; a2 = row[2]; a3 = row[4]; }
-    else if (model == NDDM_ALPHA_NOT_SCALED) { a0 = row[0]; }
-    else if (model == NDDM_EXPLICIT_BOUNDARY) { a2 = beta; a3 = 0.0f; }
-    r[0] = __float_as_uint(a0); r[1] = __float_as_uint(a1); r[2] = __float_as_uint(a2); r[3] = __float_as_uint(a3);
-    r[4] = __float_as_uint(b0); r[5] = __float_as_uint(b1); r[6] = __float_as_uint(b2); r[7] = 0u;
-    r[8] = (uint32_t)set; r[9] = __float_as_uint(tau); r[10] = 0u; r[11] = 0u;
-}
-
-// The tile's record in LDS, as the hand-out reads it (ds_read_b128 each): dword index into its DV dwords.  The first REC
-// dwords are the set's record as loaded (one masked store), the rest is filled in by lane 0 when the tile opens.
-enum { D_A = 0, D_B = 4,                             // r[0..3], r[4..7]
-       D_SIC = 8, D_TAU = 9, D_TBASE = 10, D_VSET = 11, // in-call set index, tau, first trial of the tile within its set,
-                                                     // virtual set (set * tiles_per_set + tile)
-       D_CA = 12, D_CB = 13, D_HP1K = 14, D_X1 = 15, // Philox constants of the set (PathSet in nddm_rng.h)
-       D_C3 = 16, D_SETLO = 17, D_CNT = 18,          // high set word (28 bits), low set word (auxiliary stream's counter);
-                                                     // trials of the tile retired so far
-       D_ZSUM = 20,                                  // [20..23] fixed-point sums of z and z^2 (models with a z summary), or
-       D_BCA = 20, D_BCB = 21, D_BHP1K = 22, D_BX1 = 23 }; // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
-constexpr int DV = 24;                               // one layout for every model: only two LDS base addresses stay live
-static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the loaded record");
-constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,26) | kC kD kE [28,31)
-
-// The per-trial latent of the single-trial family and the external datum that goes with it: a pure function of
-// (set, trial) and the set's record, so the hand-out (which needs the latent) and the flush (which writes the datum next
-// to the choice-RT, one whole float2 per trial) each evaluate it where they need it; the part a caller does not use is
-// dead code there.  Normal 0 of the auxiliary stream is the datum's noise, normals 1, 2, ... the rejection draws.
-//   single:     latent = boundary ~ N(mu_alpha, std_alpha) > 0 (single_trial_alpha_not_scaled.py:113-116),  z1 ~ N(gamma * boundary, sigma1) (:134)
-//   single_alt: latent = dc       ~ N(mu_dc, std_dc) > 0       (:932-935),                                z1 ~ N(gamma * dc, sigma1)
-template <int MODEL, bool FAST>
-__device__ __forceinline__ void trial_latent(const uint4 dA, const uint4 dB, uint32_t set_lo, uint32_t c3, uint32_t trial,
-                                             uint32_t kbase, float &latent, float &z)
-{
-    static_assert(MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT, "models with a per-trial latent");
-    // single: A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
-    // alt:    A = drift, alpha, beta, std_dc;            B = mu_dc, sigma1, gamma
-    const float sd = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dA.z) : __uint_as_float(dA.w);
-    const float mean = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dA.w) : __uint_as_float(dB.x);
-    const float sigma1 = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dB.x) : __uint_as_float(dB.y);
-    const float gamma = MODEL == NDDM_SINGLE_TRIAL ? __uint_as_float(dB.y) : __uint_as_float(dB.z);
-    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-    float z0, z1;
-    aux.first_pair(z0, z1);
-    float v = __builtin_fmaf(sd, z1, mean);
-    for (uint32_t ai = 2; !(v > 0.0f) && ai <= MAX_REJECT; ++ai) v = __builtin_fmaf(sd, aux.normal(ai), mean);
-    if (!(v > 0.0f)) v = fabsf(v);
-    latent = v;
-    z = __builtin_fmaf(sigma1, z0, gamma * v);
-}
-
-// Fixed-point terms of the external datum's sums: trunc(z * 2^32) and trunc(z^2 * 2^24) with z clamped to +-2^18, as the
-// oracle computes them through doubles -- here by integer arithmetic on the float's bits (gfx950 has no f64 -> i64
-// conversion: the double route is ~80 instructions per hand-out, this one ~20).  |z| * 2^32 = m * 2^(e-118) with the
-// 24-bit significand m and biased exponent e <= 145: (m << 29) >> (147 - e); z^2 * 2^24 = m^2 * 2^(2e-276):
-// (m^2 << 15) >> (291 - 2e).  Shift counts are clamped to 63, where the (< 2^63) operand has become 0 as it should.
-__device__ __forceinline__ void z_fixed_point(float z, long long &fz, long long &fzz)
-{
-    z = fminf(fmaxf(z, -262144.0f), 262144.0f);
-    const uint32_t b = __float_as_uint(z);
-    const uint32_t e = (b >> 23) & 0xffu;
-    const uint32_t m = (b & 0x007fffffu) | 0x00800000u;
-    const uint32_t s1 = 147u - e, s2 = 291u - 2u * e;
-    const unsigned long long mag = ((unsigned long long)m << 29) >> (s1 < 63u ? s1 : 63u);
-    fz = (b >> 31) ? -(long long)mag : (long long)mag;
-    fzz = (long long)((((unsigned long long)m * m) << 15) >> (s2 < 63u ? s2 : 63u));
-}
-
-// Sum of a 32-bit value over the 64 lanes, in the vector ALU's data-parallel-primitive lanes (no LDS traffic, six adds):
-// row_shr 1, 2, 4, 8 leave each 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it into the next rows; lanes
-// whose DPP source lies outside the row read the `old` operand, 0.  The wave's total ends up in lane 63.  Needs all 64
-// lanes active; the caller reads the result in lane 63.  (The shuffle-based wave_sum above costs six ds_bpermute round
-// trips per value.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
-{
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
-{
-    v = dpp_add<0x111, 0xf>(v);        // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);        // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);        // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);        // row_shr:8
-    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
-    return v;                          // lane 63 holds the total (kept in a VGPR: SGPRs are what limits residency)
-}
-
-// Integer partial sums of one tile, as the simulator leaves them for combine_partials_kernel (which adds the tiles of a
-// set up and finalises the summary row in f64 with one THREAD per set instead of one lane per flush): PW 64-bit words
-//   [0] n_upper | n_lower << 21 | n_missing << 42   [1] sum k   [2] sum k^2   [3] sum k (upper)   [4] sum k^2 (upper)
-//   [5] sum z (fixed point, 2^-32)   [6] sum z^2 (2^-24)                     -- models with an external datum only
-__host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum ? 7 : 5; }
-
-// The fused epilogue of one tile (= one parameter set unless the set is split): coalesced float2 (col0, col1) stores --
-// 512 B per wave instruction, every line written whole, once -- + summary reduction.  vset = set * tiles_per_set + tile,
-// d = the tile's LDS record.  Column 1 of the models with an external datum is NOT staged in LDS (their LDS footprint,
-// and with it the occupancy, equals the basic model's): z1 is recomputed here from the trial's auxiliary stream
-// (trial_latent), the explicit boundary is re-read from the caller's array.  (Writing it when the trial is handed out
-// or retired instead made every 64-byte sector of the output a partial write, twice: WRITE_SIZE 1.93x the output.)
-// SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
-// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
-// each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
-template <int MODEL, bool FAST, bool SMALL>
-__device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, uint32_t *d, const void *res, uint32_t kbase)
-{
-    using T = ModelTraits<MODEL>;
-    constexpr bool ZSUM = MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT;
-    const float tau = __uint_as_float(d[D_TAU]);
-    [[maybe_unused]] uint4 dA = {0u, 0u, 0u, 0u}, dB = {0u, 0u, 0u, 0u};
-    [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;
-    [[maybe_unused]] long long acc_z = 0, acc_zz = 0;
-    if constexpr (ZSUM) {
-        dA = *reinterpret_cast<const uint4 *>(d + D_A); dB = *reinterpret_cast<const uint4 *>(d + D_B);
-        c3 = d[D_C3]; set_lo = d[D_SETLO];
-    }
-    const int N = Ap->n_trials;
-    const int TPS = Ap->tiles_per_set;
-    const long long set_in_call = TPS == 1 ? vset : vset / TPS;
-    const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
-    const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
-    uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
-    int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
-    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
-    float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
-    for (int j = lane; j < n_here; j += WAVE) {
-        uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
-        if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
-            const uint32_t v = static_cast<const uint16_t *>(res)[j];
-            k = v & 0x3fffu; code = v >> 14;
-        } else {
-            const uint32_t v = static_cast<const uint32_t *>(res)[j];
-            k = v & 0x3fffffffu; code = v >> 30;
-        }
-        const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
-        const float rt = __builtin_fmaf((float)k, Ap->tscale, tau);
-        float2 o;
-        if constexpr (MODEL == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
-        else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
-        else {
-            o.x = ch * rt;
-            if constexpr (ZSUM) {
-                float latent;
-                trial_latent<MODEL, FAST>(dA, dB, set_lo, c3, (uint32_t)(t0 + j), kbase, latent, o.y);
-                if (Ap->out_summary) { long long fz, fzz; z_fixed_point(o.y, fz, fzz); acc_z += fz; acc_zz += fzz; }
-            } else {
-                o.y = out ? Ap->bounds[set_in_call * Ap->n_total + t0 + j] : 0.0f;       // the boundary that was given
-            }
-        }
-        if (code == 3u) o.x = __builtin_nanf("");
-        if (out) out[j] = o;
-        if (Ap->out_summary) {
-            if constexpr (SMALL) {
-                const uint32_t kk = k * k;                                           // < 2^28
-                const bool up = code == 1u, resp = up || code == 2u;
-                cnt3 += up ? 1u : (code == 2u ? (1u << 10) : (1u << 20));
-                sk32 += resp ? k : 0u; sk2_32 += resp ? kk : 0u;
-                sk_up32 += up ? k : 0u; sk2_up32 += up ? kk : 0u;
-            } else {
-                const unsigned long long kk = (unsigned long long)k * k;
-                if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
-                else if (code == 2u) { n_lo++; sk += k; sk2 += kk; }
-                else n_miss++;
-            }
-        }
-    }
-    if (Ap->out_summary) {
-        unsigned long long *q = reinterpret_cast<unsigned long long *>(Ap->partials) + vset * partial_words(ZSUM);
-        [[maybe_unused]] unsigned long long *zsum = reinterpret_cast<unsigned long long *>(d + D_ZSUM);
-        if constexpr (ZSUM) {          // 64-bit sums: no-return LDS adds by every lane; a wave's LDS operations complete in order
-            atomicAdd(zsum, (unsigned long long)acc_z);
-            atomicAdd(zsum + 1, (unsigned long long)acc_zz);
-        }
-        if constexpr (SMALL) {
-            cnt3 = wave_sum_dpp(cnt3);
-            sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
-            const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
-            const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
-            if (lane == WAVE - 1) {                          // the DPP reductions leave the totals in the last lane
-                q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
-                       ((unsigned long long)(cnt3 >> 20) << 42);
-                q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
-                q[3] = sk_up32; q[4] = ((unsigned long long)u_hi << 16) + u_lo;
-                if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
-            }
-        } else {
-            n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
-            sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-            if (lane == 0) {
-                q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
-                q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
-                if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
-            }
-        }
-    }
-    if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-        if (Ap->out_ext && lane == 0 && t0 == 0) {
-            const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
-            AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
-            const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
-            Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
-        }
-    }
-}
-
-// The evidence is carried CENTRED: w = x - a/2, h = a/2, so that (x > 0) && (x < a) is the single compare |w| < h
-// (v_cmp_lt_f32 with the |.| source modifier; false for NaN and for h == 0).
-__device__ __forceinline__ bool in_range(float w, float h)
-{
-    return __builtin_fabsf(w) < h;
-}
-
-
-// MODEL: enum nddm_model.  FAST: Gaussian transform.  SMALL: see below.  CAP4: max_steps is a multiple of 4, so the step cap is tested
-// once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
-// points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
-// the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
-// generator is an exact first-passage sampler.
-// (Tried and dropped: Philox round keys in VGPRs.  A VOP2 xor that reads an SGPR issues at ~4.2 instead of ~2.3
-// cycles on gfx950, but the 20 extra VGPRs cut residency from 7 to 5 waves per SIMD and the net was neutral.)
-// SMALL: results staged as 16-bit words and at most 512 trials per tile -- the shape of every launch that matters for
-// throughput.  A kernel that carries BOTH flush paths (32-bit DPP sums / 64-bit shuffles) needs 79 SGPRs and 60 VGPRs; the
-// SMALL one alone 72 and 44, which is what keeps 8 waves per SIMD resident (the SGPR file limits these kernels).
-// PACKED: NDDM_GAUSS_PACKED -- 8 Euler-Maruyama steps per Philox block (polar_pair_packed in nddm_rng.h); CAP4 then means
-// "max_steps is a multiple of 8".
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED>
-__global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
-{
-    using T = ModelTraits<MODEL>;
-    constexpr int P = T::P;
-    extern __shared__ uint32_t lds_raw[];
-
-    const ArgsPtr Ak = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = threadIdx.x;
-    const int N = A.n_trials;
-    const int ring = A.ring, ring_mask = A.ring - 1;
-
-    // LDS carve-up.  Header (128 bytes): the ten Philox round-key pairs [0, 80) (philox4x32_10_path), debug stamps
-    // [80, 104), the three round keys that fold into the per-trial constants [112, 124).  Then one ring slot per
-    // in-flight parameter set ("tile"): its DV-dword record (hand-out constants, counters, z sums), then the packed results
-    if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
-    if (lane == 0) { lds_raw[28] = A.k0 + 2u * PHILOX_W0; lds_raw[29] = A.k1 + 2u * PHILOX_W1; lds_raw[30] = A.k0 + 3u * PHILOX_W0; }
-    // LDS byte address of the key table in a VGPR (the low 32 bits of a flat LDS address are the LDS offset); the asm
-    // keeps it opaque so that every ds_read in the step loop uses this one register + an immediate offset
-    uint32_t kbase;
-    {
-        const uint32_t off = (uint32_t)(size_t)lds_raw;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
-    }
-    uint32_t *dv = lds_raw + LDS_HEADER_DWORDS;                        // [ring][DV], 16-byte aligned
-    // staged results: one 32-bit word per trial, or one 16-bit word when the step cap allows (halves the LDS footprint,
-    // which is what lets the 7th and 8th wave per SIMD stay resident at 300 trials per set)
-    uint32_t *res = dv + ring * DV;
-    uint16_t *res_h = reinterpret_cast<uint16_t *>(res);
-
-    // per-lane trial state
-    // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
-    float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
-    int k = 0;
-    uint32_t jit = 0;
-    uint32_t ltrial = 0;     // index within the tile (LDS slot position)
-    int tile = 0;            // wave-local sequence number of the set this lane works on
-    bool invalid = false;
-    // which lanes hold a trial / are still stepping: wave-uniform lane masks kept in SGPRs (a per-lane bool that is
-    // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
-    unsigned long long has_m = 0ull, act_m = 0ull;
-    PathCtr pc = {0u, 0u, 0u, 0u, 0u};
-    PathCtr pcb = {0u, 0u, 0u, 0u, 0u};           // bridge-uniform stream (BRIDGE only)
-
-    // wave-uniform bookkeeping.  Tiles (sets) are opened, handed out and flushed strictly in sequence.
-    int tile_open = 0;       // tiles whose parameters are staged in LDS
-    int flushed = 0;         // tiles already flushed
-    int next_tile = 0, next_trial = 0;            // next unassigned trial of the wave's stream
-    // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
-    int to_retire = N;                            // the oldest tile cannot be complete before this many more trials retire
-    int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
-    // debug counters live in LDS (SGPRs are scarce): dbg_stamp[2] = refill phases << 32 | step-loop blocks
-    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks
-    if (lane == 0) { dbg_stamp[2] = 0; if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); } }
-
-    // The record of the NEXT tile of the current chunk, loaded when the tile before it is opened (lanes < REC hold one
-    // dword each): by the time it is consumed the load has long completed, so opening a tile never waits on memory.
-    // It is valid whenever the chunk has tiles left (the record of chunk position `chunk_set`).
-    uint32_t pre = 0u;
-
-    // open tiles (fetch chunk ids from the global queue, stage the hand-out record of each new tile) while ring slots
-    // are free -- but LAZILY: only up to `ahead` tiles beyond the one being handed out, so that a wave never hoards
-    // sets its neighbours could be working on (with an eager ring fill, 10,000 sets ended up on 2,500 of the
-    // 7,168 waves: 6x slower for mid-size batches)
-    auto open_tiles = [&]() {
-        const ArgsPtr R = fresh_args(Ak);
-        while (tile_open < flushed + ring && tile_open <= next_tile + R->open_ahead) {
-            const bool have_pre = chunk_left > 0;                        // mid-chunk: this tile's record was prefetched
-            if (chunk_left <= 0) {
-                if (chunk_left < 0) break;
-                unsigned int c = 0;
-                if (lane == 0) c = atomicAdd(R->chunk_counter, 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= (unsigned int)R->n_chunks) { chunk_left = -1; break; }
-                chunk_set = (int)c * R->sets_per_chunk;
-                const long long left = R->B - (long long)chunk_set;
-                chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
-            }
-            const int slot = tile_open & ring_mask;
-            // queue position -> queue row (position / tiles_per_set) -> its record
-            const int TPS = R->tiles_per_set;
-            const int prow = TPS == 1 ? chunk_set : chunk_set / TPS;
-            const int qt = chunk_set - prow * TPS;                       // tile within the set (0 when not tiled)
-            uint32_t rec = pre;
-            if (!have_pre) rec = lane < REC ? R->recs[(long long)prow * REC + lane] : 0u;
-            if (chunk_left > 1) {                                        // prefetch the next tile's record
-                const int nrow = TPS == 1 ? chunk_set + 1 : (chunk_set + 1) / TPS;
-                if (nrow != prow) pre = lane < REC ? R->recs[(long long)nrow * REC + lane] : 0u;
-                else pre = rec;
-            }
-            const int sic = __builtin_amdgcn_readlane((int)rec, R_SET);  // the set's row in the caller's arrays
-            const int vset = sic * TPS + qt;
-            uint32_t *d = dv + slot * DV;
-            if (lane < REC) d[lane] = rec;
-            if (lane == 0) {
-                d[D_VSET] = (uint32_t)vset; d[D_CNT] = 0u;
-                if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) { d[D_ZSUM] = 0u; d[D_ZSUM + 1] = 0u; d[D_ZSUM + 2] = 0u; d[D_ZSUM + 3] = 0u; }
-                // everything here is wave-uniform: scalar arithmetic
-                const unsigned long long gset = R->set_offset + (unsigned long long)sic;
-                const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
-                PathSet ps;
-                ps.init(s_lo, s_hi, R->k0, R->k1);              // stream 0: no tag bits in c2
-                d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
-                if constexpr (BRIDGE) {
-                    PathSet pb;
-                    pb.init(s_lo, s_hi | 0x30000000u, R->k0, R->k1);
-                    d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
-                }
-                d[D_SETLO] = s_lo;
-                d[D_C3] = s_hi;
-                d[D_TBASE] = (uint32_t)(qt * N);
-            }
-            chunk_set++; chunk_left--; tile_open++;
-        }
-    };
-    open_tiles();
-    __syncthreads();
-
-    while (true) {
-        // ------------------------------------------------------------ retire finished trials
-        const unsigned long long fin_mask0 = has_m & ~act_m;
-        if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
-            const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
-            uint32_t tfix = (uint32_t)k;
-            if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
-            const int slot = tile & ring_mask;
-            if (SMALL || fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
-            else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
-            atomicAdd(dv + slot * DV + D_CNT, 1u);
-        }
-        has_m &= ~fin_mask0;
-        to_retire -= (int)__popcll(fin_mask0);
-        // ------------------------------------------------------------ flush complete sets, in order (rare path:
-        // only entered when enough trials have retired for the oldest tile to possibly be complete)
-        if (to_retire <= 0) {
-            __syncthreads();
-            while (flushed < tile_open) {
-                const int slot = flushed & ring_mask;
-                const int c = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_CNT]);
-                if (c != N) break;
-                const int set_in_call = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_VSET]);
-                if constexpr (SMALL)
-                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV, res_h + (size_t)slot * N, kbase);
-                else
-                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV,
-                                                  fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
-                                                                        : static_cast<const void *>(res + (size_t)slot * N), kbase);
-                flushed++;
-                to_retire += N;
-            }
-            __syncthreads();
-            open_tiles();
-            __syncthreads();
-        }
-        if (flushed == tile_open && chunk_left < 0) break;
-        // ------------------------------------------------------------ hand out new trials
-        if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + ring && chunk_left >= 0) {
-            open_tiles();
-            __syncthreads();
-        }
-        {
-            const unsigned long long want_mask = ~has_m;
-            int tr = next_trial + (int)lane_rank(want_mask);
-            int tl = next_tile;
-            while (tr >= N) { tr -= N; tl++; }
-            const unsigned long long ok_mask = want_mask & __builtin_amdgcn_ballot_w64(tl < tile_open);
-            next_trial += (int)__popcll(ok_mask);
-            while (next_trial >= N) { next_trial -= N; next_tile++; }
-            has_m |= ok_mask;
-            if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
-                const ArgsPtr H = fresh_args(Ak);
-                tile = tl;
-                ltrial = (uint32_t)tr;
-                const int slot = tl & ring_mask;
-                const uint4 d0 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_A);
-                const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_CA);
-                const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_SIC);      // set index, tau, TBASE
-                const float a0 = __uint_as_float(d0.x), a1 = __uint_as_float(d0.y), a2 = __uint_as_float(d0.z),
-                            a3 = __uint_as_float(d0.w);                  // the model's A constants (make_record)
-                const uint32_t trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
-                [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;       // the auxiliary stream's set words
-                if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT || MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    const uint2 sw = *reinterpret_cast<const uint2 *>(dv + slot * DV + D_C3);
-                    c3 = sw.x; set_lo = sw.y;
-                }
-                invalid = false;
-                if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
-                    mu_dt = a0; h = a2; w = a3;
-                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
-                    // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
-                    float a, z_unused;
-                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, a, z_unused);      // per-trial boundary
-                    const float hv = 0.5f * a;
-                    mu_dt = a0;
-                    h = hv * a1;
-                    w = (a * __uint_as_float(d3.z) - hv) * a1;
-                } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
-                    // A = drift, alpha, beta, std_dc;  B = mu_dc, sigma1, gamma
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
-                    float sig_c, z_unused;
-                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, sig_c, z_unused);  // per-trial noise scale
-                    const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);
-                    const float hv = 0.5f * a1;
-                    mu_dt = (a0 * H->dt) * inv_t;
-                    h = hv * inv_t;
-                    w = (a1 * a2 - hv) * inv_t;
-                } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    // A = Nu, 1/S, a/(2S), w0;  B = Eta
-                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    const float eta = __uint_as_float(dv[slot * DV + D_B]);
-                    mu_dt = (__builtin_fmaf(eta, aux.normal(0), a0) * H->dt) * a1;
-                    h = a2; w = a3;
-                } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
-                    // A = drift*dt/S, 1/S, beta
-                    const float a = trial < (uint32_t)H->n_total ? H->bounds[(long long)d2.x * H->n_total + trial] : 1.0f;   // padded trial of a last tile
-                    invalid = !(a >= 0.0f);            // negative or NaN boundary: the reference raises ValueError
-                    const float hv = 0.5f * a;
-                    mu_dt = a0;
-                    h = invalid ? 0.0f : hv * a1;
-                    w = (a * a2 - hv) * a1;
-                }
-                const uint4 kq = *reinterpret_cast<const uint4 *>(lds_raw + 28);       // kC, kD, kE of PathCtr::init
-                pc.init(d1.x, d1.y, d1.z, d1.w, trial, kq.x, kq.y, kq.z);
-                if constexpr (BRIDGE) {
-                    const uint4 d4 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_BCA);
-                    pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
-                }
-                k = 0;
-                jit = 0;
-            }
-            // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
-            // are masked by has_m)
-            act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
-        }
-        // ------------------------------------------------------------ step phase
-        // leave the loop for a refill once refill_thresh lanes hold a finished trial, or none is stepping, or after
-        // MAX_BLOCKS blocks (so that a few finished lanes never wait long for company; a threshold >= 64 -- the lockstep
-        // measurement -- switches that exit off)
-        constexpr int MAX_BLOCKS = 16;
-        int it = 0;
-        for (;; ++it) {
-            bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
-            // counter word 0 of the path stream = index of the block's first step (a multiple of NS: a lane only starts
-            // a block after taking all NS steps of the previous one), so no shift is needed
-            constexpr int NS = PACKED ? 8 : 4;
-            const uint32_t blk = (uint32_t)k;
-            const u32x4 rb = philox4x32_10_path(blk, pc, kbase);
-            // noise of the NS steps as (radius, cos | sin) factors: the step is w = fma(r, t, w) + mu_dt, i.e. a
-            // v_fmac_f32 + v_add_f32 (2.3 issue cycles each; a three-address v_fma_f32 costs 3.8)
-            float rr[NS], tt[NS];
-            if constexpr (PACKED) {
-                polar_pair_packed<FAST>(rb.x, rr[0], tt[0], tt[1]);
-                polar_pair_packed<FAST>(rb.y, rr[2], tt[2], tt[3]);
-                polar_pair_packed<FAST>(rb.z, rr[4], tt[4], tt[5]);
-                polar_pair_packed<FAST>(rb.w, rr[6], tt[6], tt[7]);
-                rr[1] = rr[0]; rr[3] = rr[2]; rr[5] = rr[4]; rr[7] = rr[6];
-            } else {
-                polar_pair<FAST>(rb.x, rb.y, rr[0], tt[0], tt[1]);
-                polar_pair<FAST>(rb.z, rb.w, rr[2], tt[2], tt[3]);
-                rr[1] = rr[0]; rr[3] = rr[2];
-            }
-            uint32_t ub[4] = {0u, 0u, 0u, 0u};
-            if constexpr (BRIDGE) {
-                const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);          // stream 3, same constant folding as the path stream
-                ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
-            }
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (active) {
-                    // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
-                    // each on gfx950) cost more VALU issue than the predicated add / count they would replace
-                    asm volatile("" ::: "memory");
-                    float w1 = __builtin_fmaf(rr[j], tt[j], w) + mu_dt;
-                    if constexpr (BRIDGE) {
-                        if (in_range(w1, h)) {
-                            // P(crossed) = exp(-2 d0 d1 / sigma^2 dt): in noise units the coefficient is a constant
-                            // (exact: -2 with e^x; fast: -2 * 2 ln 2 * log2 e = -4 with v_exp_f32's 2^x)
-                            constexpr float cb = FAST ? -4.0f : -2.0f;
-                            const float eu = cb * ((h - w) * (h - w1));      // distances to the upper boundary
-                            const float el = cb * ((h + w) * (h + w1));      // ... and to the lower one
-                            float pu, pl;
-                            if constexpr (FAST) { pu = __builtin_amdgcn_exp2f(eu); pl = __builtin_amdgcn_exp2f(el); }
-                            else { pu = exact_expf_neg(eu); pl = exact_expf_neg(el); }
-                            const float uu = (float)(ub[j & 3] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
-                            if (uu < pu) w1 = h;
-                            else if (uu >= 1.0f - pl) w1 = -h;
-                        }
-                        jit = ub[j & 3] & 0xffu;
-                    }
-                    w = w1;
-                    k++;
-                    if (j < NS - 1) {
-                        if constexpr (CAP4) active = in_range(w, h);
-                        else active = in_range(w, h) && (k < A.max_k);
-                    }
-                }
-            }
-            // fresh compares for every lane, combined as SGPR masks: a ballot of a compare is just its SGPR result, a
-            // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
-            act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
-            if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
-            if (it >= MAX_BLOCKS - 1 && A.refill_thresh < WAVE) break;
-        }
-        // one refill phase of `it + 1` blocks: a no-return 64-bit LDS add
-        if (lane == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it + 1));
-    }
-    // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
-    // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
-    // per launch, and a captured launch is kernels only.
-    if (lane == 0) {
-        unsigned int *const q = fresh_args(Ak)->chunk_counter;
-        const unsigned int left = atomicAdd(q + 1, 1u);
-        if (left == gridDim.x - 1u) { atomicExch(q, 0u); atomicExch(q + 1, 0u); }
-    }
-    unsigned long long *const dbg = fresh_args(Ak)->dbg;
-    if (dbg && lane == 0) {
-        atomicAdd(dbg + 0, dbg_stamp[2] & 0xffffffffull);
-        atomicAdd(dbg + 1, dbg_stamp[2] >> 32);
-        atomicAdd(dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
-        atomicAdd(dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
-        atomicAdd(dbg + 4, 1ull);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Longest-first scheduling.  Expected trial length differs by two orders of magnitude across the prior (a set of
-// wide-boundary, zero-drift trials keeps a wave busy ~100x longer than a fast one), so pulling sets in the given order
-// leaves a long tail at the end of a launch and mixes fast and slow trials in one wave.  A counting sort by the
-// expected number of Euler-Maruyama steps (closed-form mean first-passage time of the DDM, half-octave buckets,
-// slowest bucket first) removes both: +8 % at 1M sets, +40 % at 100k.  Only the ORDER of processing changes; outputs
-// stay at their set's position and do not depend on it.
-constexpr int ORDER_BUCKETS = 32;
-
-__device__ __forceinline__ int duration_bucket(int model, const float *p, float dt, int max_k)
-{
-    float v, a, beta, sg;
-    switch (model) {
-    case NDDM_BASIC_DDM_DC: v = p[0]; a = p[1]; beta = p[2]; sg = p[4]; break;
-    case NDDM_SINGLE_TRIAL: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
-    case NDDM_SINGLE_TRIAL_ALT: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
-    case NDDM_ALPHA_NOT_SCALED: v = p[0]; a = p[1]; beta = p[2]; sg = p[5]; break;
-    default: v = p[0]; a = 1.0f; beta = p[1]; sg = p[3]; break;
-    }
-    const float s2 = sg * sg, av = fabsf(v);
-    const float z = v >= 0.0f ? a * beta : a - a * beta;   // mirror negative drift: same mean time, no exp overflow
-    float et;                                           // mean first-passage time, seconds
-    if (av * a < 1e-3f * s2) et = z * (a - z) / s2;
-    else et = (a * (1.0f - __expf(-2.0f * av * z / s2)) / (1.0f - __expf(-2.0f * av * a / s2)) - z) / av;
-    float steps = et / dt;
-    if (!(steps >= 1.0f)) steps = 1.0f;                 // also catches NaN
-    if (steps > (float)max_k) steps = (float)max_k;
-    int b = (int)(2.0f * __log2f(steps));               // half-octave buckets
-    b = b < 0 ? 0 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
-    return ORDER_BUCKETS - 1 - b;                       // bucket 0 = slowest
-}
-
-// ws[0..31] histogram, ws[32..63] cursors (both zeroed before the launch by zero_words_kernel)
-__global__ void order_hist_kernel(int model, const float *params, int P, int B, float dt, int max_k, int *ws)
-{
-    __shared__ int h[ORDER_BUCKETS];
-    if (threadIdx.x < ORDER_BUCKETS) h[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x)
-        atomicAdd(&h[duration_bucket(model, params + (long long)i * P, dt, max_k)], 1);
-    __syncthreads();
-    if (threadIdx.x < ORDER_BUCKETS && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ void order_scatter_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
-                                     int *ws, uint32_t *recs)
-{
-    __shared__ int start[ORDER_BUCKETS], lh[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
-    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += ws[b]; } }
-    for (int base = blockIdx.x * blockDim.x; base < B; base += gridDim.x * blockDim.x) {
-        if (threadIdx.x < ORDER_BUCKETS) lh[threadIdx.x] = 0;
-        __syncthreads();
-        const int i = base + threadIdx.x;
-        int b = -1, r = 0;
-        if (i < B) {
-            b = duration_bucket(model, params + (long long)i * P, dt, max_k);
-            r = atomicAdd(&lh[b], 1);                   // rank within this block's share of the bucket (LDS)
-        }
-        __syncthreads();
-        if (threadIdx.x < ORDER_BUCKETS && lh[threadIdx.x])     // one global cursor bump per bucket per block
-            lbase[threadIdx.x] = atomicAdd(&ws[ORDER_BUCKETS + threadIdx.x], lh[threadIdx.x]);
-        __syncthreads();
-        if (i < B) {
-            const int q = start[b] + lbase[b] + r;      // position of set i in the processing order
-            make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)q * REC);
-        }
-        __syncthreads();
-    }
-}
-
-// launches too small to be worth sorting: records in the given order
-__global__ void prep_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, uint32_t *recs)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)i * REC);
-}
-
-// ------------------------------------------------------------------------------------------------
-// sets split into several tiles: add the tiles' integer partial sums up and finalise the summary row (one thread per
-// set; exact integer arithmetic, so the result equals the single-tile path bit for bit)
-__global__ void combine_partials_kernel(const unsigned long long *partials, int pw, const float *params, int P, int tau_idx,
-                                        long long B, int tiles_per_set, int n_total, float tscale, float *out_summary)
-{
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    long long n_up = 0, n_lo = 0, n_miss = 0, sz = 0, szz = 0;
-    unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
-    for (int t = 0; t < tiles_per_set; ++t) {
-        const unsigned long long *q = partials + (b * tiles_per_set + t) * pw;       // layout: partial_words()
-        n_up += (long long)(q[0] & 0x1fffffull); n_lo += (long long)((q[0] >> 21) & 0x1fffffull); n_miss += (long long)(q[0] >> 42);
-        sk += q[1]; sk2 += q[2]; sk_up += q[3]; sk2_up += q[4];
-        if (pw > 5) { sz += (long long)q[5]; szz += (long long)q[6]; }
-    }
-    finalize_summary(out_summary + b * NDDM_SUMMARY_K, (int)n_up, (int)n_lo, (int)n_miss, sk, sk2, sk_up, sk2_up, sz, szz,
-                     n_total, tscale, params[b * P + tau_idx]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// debugging kernel for the parity tests: 4 normals per counter
-template <bool FAST>
-__global__ void debug_normals_kernel(const uint32_t *ctr, long long n, uint32_t k0, uint32_t k1, float *out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float z[4];
-    normals4<FAST>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, z);
-    out[4 * i] = z[0]; out[4 * i + 1] = z[1]; out[4 * i + 2] = z[2]; out[4 * i + 3] = z[3];
-}
-
-// ------------------------------------------------------------------------------------------------
-// on-device draw_prior(): basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 (+ _alt :889-913,
-// _scale :1205-1232 share the marginals).  Stream 2 of the row; one thread per row.
-struct PriorStream {
-    uint32_t k0, k1, row_lo, c3, draw;
-    float z[4];
-    uint32_t u[4];
-    int nz, nu;
-    __device__ PriorStream(uint32_t k0_, uint32_t k1_, uint64_t row)
-        : k0(k0_), k1(k1_), row_lo((uint32_t)row), c3(((uint32_t)(row >> 32) & 0x0fffffffu) | 0x20000000u),
-          draw(0), nz(0), nu(0) {}
-    __device__ float normal()
-    {
-        if (nz == 0) { normals4<false>(draw++, 0u, row_lo, c3, k0, k1, z); nz = 4; }
-        const int j = 4 - nz; nz--;
-        return j == 0 ? z[0] : (j == 1 ? z[1] : (j == 2 ? z[2] : z[3]));
-    }
-    __device__ float uniform()
-    {
-        if (nu == 0) { const u32x4 x = philox4x32_10(draw++, 1u, row_lo, c3, k0, k1); u[0] = x.x; u[1] = x.y; u[2] = x.z; u[3] = x.w; nu = 4; }
-        const int j = 4 - nu; nu--;
-        return uniform01(j == 0 ? u[0] : (j == 1 ? u[1] : (j == 2 ? u[2] : u[3])));
-    }
-    // N(mean, sd) truncated to [low, upp] by rejection (truncnorm_better, basic_ddm_dc.py:55-57)
-    __device__ float truncnorm(float mean, float sd, float low, float upp)
-    {
-        float v = mean;
-        for (int i = 0; i < 256; ++i) {
-            v = __builtin_fmaf(sd, normal(), mean);
-            if (v >= low && v <= upp) break;
-        }
-        return fminf(fmaxf(v, low), upp);
-    }
-    // Beta(2,2) = the median of three uniforms (order statistic U_(2:3))
-    __device__ float beta22()
-    {
-        const float a = uniform(), b = uniform(), c = uniform();
-        return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
-    }
-};
-
-__global__ void prior_kernel(int model, long long B, uint32_t k0, uint32_t k1, unsigned long long set_offset,
-                             float gamma, float *out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    PriorStream s(k0, k1, set_offset + (unsigned long long)i);
-    if (model == NDDM_BASIC_DDM_DC) {
-        float *o = out + i * 5;
-        o[0] = 2.0f * s.normal();                       // drift ~ N(0, 2)          basic_ddm_dc.py:65
-        o[1] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // alpha ~ TN(1,.5; 0,10)    :68
-        o[2] = s.beta22();                              // beta ~ Beta(2,2)          :71
-        o[3] = s.truncnorm(0.5f, 0.25f, 0.0f, 1.5f);    // ter ~ TN(.5,.25; 0,1.5)   :74
-        o[4] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // dc ~ TN(1,.5; 0,10)       :77
-    } else {   // single-trial family: same marginals for base / _alt / _scale
-        float *o = out + i * 8;
-        o[0] = 2.0f * s.normal();                       // single_trial_alpha_not_scaled.py:81
-        o[1] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // mu_alpha                  :84
-        o[2] = s.beta22();                              //                           :87
-        o[3] = s.truncnorm(0.5f, 0.25f, 0.0f, 1.5f);    //                           :90
-        o[4] = s.truncnorm(1.0f, 0.5f, 0.0f, 3.0f);     // std_alpha ~ TN(1,.5; 0,3) :93
-        o[5] = s.truncnorm(1.0f, 0.5f, 0.0f, 10.0f);    // dc                        :96
-        o[6] = 5.0f * s.uniform();                      // sigma1 ~ U(0,5)           :99
-        o[7] = gamma >= 0.0f ? gamma : 2.0f * s.uniform();   // gamma ~ U(0,2) (:1229) when gamma < 0 is passed
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // host side
