@@ -241,11 +241,11 @@ static int resident_waves(K kernel, size_t lds_bytes, int cus)
     return cus * per_cu;
 }
 
-template <int MODEL, bool BRIDGE>
-static int launch_model(const SimArgs &A, bool fast, bool packed, size_t lds_bytes, int n_chunks, int cus, int grid_override,
-                        bool grid_forced, hipStream_t st)
+// one (MODEL, BRIDGE, SMALL, PACKED, VKEYS) variant: pick the Gaussian transform and the step-cap form, size the grid
+template <int MODEL, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS>
+static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_bytes, int n_chunks, int cus, int grid_override,
+                           bool grid_forced, hipStream_t st)
 {
-    const bool cap4 = (A.max_k % (packed ? 8 : 4)) == 0;     // the step cap falls on a block boundary
     const dim3 block(WAVE);
 #define NDDM_LAUNCH(KERNEL)                                                                    \
     do {                                                                                       \
@@ -254,27 +254,36 @@ static int launch_model(const SimArgs &A, bool fast, bool packed, size_t lds_byt
         if (waves > n_chunks) waves = n_chunks;                                                \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
-    const bool small = A.res16 == 2;
-    if constexpr (!BRIDGE) {
-        if (packed) {               // NDDM_GAUSS_PACKED (the host has checked small)
-            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true, true>));
-            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true, true>));
-            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true, true>));
-            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true, true>));
-        } else if (small) {
-            if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, false, true, false>));
-            else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, false, true, false>));
-            else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, false, true, false>));
-            else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, false, true, false>));
-        }
-    }
-    if (BRIDGE || (!small && !packed)) {
-        if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, false, false>));
-        else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, false, false>));
-        else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, false, false>));
-        else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, false, false>));
-    }
+    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS>));
+    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, SMALL, PACKED, VKEYS>));
+    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, SMALL, PACKED, VKEYS>));
+    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, SMALL, PACKED, VKEYS>));
 #undef NDDM_LAUNCH
+}
+
+// vkeys: the launch is small (its grid was cut, or it has fewer chunks than resident waves) -- the variant that keeps the
+// Philox round keys in VGPRs (nddm_sim.h) is 13-29 % faster there and 1.6 % slower on a full grid; it exists for the models
+// whose kernels have the registers to spare
+template <int MODEL, bool BRIDGE>
+static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, size_t lds_bytes, int n_chunks, int cus,
+                        int grid_override, bool grid_forced, hipStream_t st)
+{
+    const bool cap4 = (A.max_k % (packed ? 8 : 4)) == 0;     // the step cap falls on a block boundary
+    const bool small = A.res16 == 2;
+    constexpr bool HAS_VKEYS = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED || MODEL == NDDM_EXPLICIT_BOUNDARY);
+#define NDDM_ARGS A, fast, cap4, lds_bytes, n_chunks, cus, grid_override, grid_forced, st
+    if constexpr (BRIDGE) launch_variant<MODEL, true, false, false, false>(NDDM_ARGS);
+    else if (!small && !packed) launch_variant<MODEL, false, false, false, false>(NDDM_ARGS);
+    else if constexpr (HAS_VKEYS) {
+        if (packed && vkeys) launch_variant<MODEL, false, true, true, true>(NDDM_ARGS);     // NDDM_GAUSS_PACKED: the host has checked small
+        else if (packed) launch_variant<MODEL, false, true, true, false>(NDDM_ARGS);
+        else if (vkeys) launch_variant<MODEL, false, true, false, true>(NDDM_ARGS);
+        else launch_variant<MODEL, false, true, false, false>(NDDM_ARGS);
+    } else {
+        if (packed) launch_variant<MODEL, false, true, true, false>(NDDM_ARGS);
+        else launch_variant<MODEL, false, true, false, false>(NDDM_ARGS);
+    }
+#undef NDDM_ARGS
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return NDDM_OK;
@@ -513,15 +522,16 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     if (rc == NDDM_OK) {
         const int gw = plan_waves < 8ll * simds || tun.grid_waves > 0 ? (int)plan_waves : 0;     // 0 = what is resident
+        const bool vkeys = plan_waves < 8ll * simds || n_chunks < 8ll * simds;                   // a small launch
         switch (model) {
-        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
-        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
-        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         case NDDM_ALPHA_NOT_SCALED:
-            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st)
-                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st);
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st);
             break;
-        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         }
     }
     if (rc == NDDM_OK && A.partials) {

@@ -118,6 +118,45 @@ __device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t draw, const PathCtr
     return {c0, c1, c2, c3};
 }
 
+// The same block with the round keys of rounds 3..9 held in VGPRs for the whole kernel (13 registers) instead of read from
+// LDS every block: identical VALU work -- the xor3 operands are VGPRs either way -- but no LDS instruction and no wait in
+// the step loop.  For the kernels that have the registers to spare (<= 64 VGPRs keeps 8 waves per SIMD); it matters most
+// when a wave has the SIMD to itself (small launches), where every LDS round trip is exposed latency.
+struct PathKeys {
+    uint32_t b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9;
+    __device__ __forceinline__ void init(uint32_t k0, uint32_t k1)
+    {
+        auto v = [](uint32_t s) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s)); return r; };   // opaque: stays a VGPR
+        b3 = v(k1 + 3u * PHILOX_W1);
+        a4 = v(k0 + 4u * PHILOX_W0); b4 = v(k1 + 4u * PHILOX_W1); a5 = v(k0 + 5u * PHILOX_W0); b5 = v(k1 + 5u * PHILOX_W1);
+        a6 = v(k0 + 6u * PHILOX_W0); b6 = v(k1 + 6u * PHILOX_W1); a7 = v(k0 + 7u * PHILOX_W0); b7 = v(k1 + 7u * PHILOX_W1);
+        a8 = v(k0 + 8u * PHILOX_W0); b8 = v(k1 + 8u * PHILOX_W1); a9 = v(k0 + 9u * PHILOX_W0); b9 = v(k1 + 9u * PHILOX_W1);
+    }
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10_path(uint32_t draw, const PathCtr &pc, const PathKeys &K)
+{
+    const uint64_t Q1 = (uint64_t)PHILOX_M1 * (pc.cA ^ draw);                        // rounds 0 + 1
+    const uint64_t S0 = (uint64_t)PHILOX_M0 * ((uint32_t)(Q1 >> 32) ^ pc.cB);        // round 2
+    const uint64_t T0 = (uint64_t)PHILOX_M0 * ((uint32_t)Q1 ^ pc.cC);                // round 3
+    const uint64_t T1 = (uint64_t)PHILOX_M1 * ((uint32_t)(S0 >> 32) ^ pc.cD);
+    uint32_t c0 = (uint32_t)(T1 >> 32) ^ pc.cE, c1 = (uint32_t)T1, c2 = xor3((uint32_t)(T0 >> 32), (uint32_t)S0, K.b3), c3 = (uint32_t)T0;
+#define NDDM_ROUND(KA, KB)                                                                                \
+    {                                                                                                     \
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;                                                     \
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;                                                     \
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, KA);                                           \
+        const uint32_t n1 = (uint32_t)p1;                                                                 \
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, KB);                                           \
+        const uint32_t n3 = (uint32_t)p0;                                                                 \
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;                                                               \
+    }
+    NDDM_ROUND(K.a4, K.b4) NDDM_ROUND(K.a5, K.b5) NDDM_ROUND(K.a6, K.b6) NDDM_ROUND(K.a7, K.b7) NDDM_ROUND(K.a8, K.b8)
+    NDDM_ROUND(K.a9, K.b9)
+#undef NDDM_ROUND
+    return {c0, c1, c2, c3};
+}
+
 // General counter, all ten key pairs from LDS (bridge-correction uniforms)
 __device__ __forceinline__ u32x4 philox4x32_10_lds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t kbase)
 {

@@ -17,12 +17,12 @@ def test_fast_kernels_fit_eight_waves_per_simd():
     import resource_table as rt
     rows = {rt.pretty(r["name"]): r for r in rt.collect()}
     sims = {k: v for k, v in rows.items() if k.startswith("sim_kernel<")}
-    assert len(sims) >= 60                                   # 5 models x {fast, exact} x {cap4} x {small, packed, ...} + bridge
+    assert len(sims) >= 80                                   # 5 models x {fast, exact} x {cap4} x {small, packed, vkeys, ...} + bridge
     for name, r in sims.items():
         assert r.get("ScratchSize [bytes/lane]", 0) == 0, name               # no private scratch anywhere
         assert r.get("VGPRs Spill", 0) == 0 and r.get("SGPRs Spill", 0) == 0, name
     fast_small = [k for k in sims if ", fast," in k and "small=1" in k]
-    assert len(fast_small) == 20                             # 5 models x cap4 {0,1} x packed {0,1}
+    assert len(fast_small) == 32                             # 5 models x cap4 {0,1} x packed {0,1} + 3 models with a VGPR-keys variant
     for name in fast_small:
         v, s = sims[name]["VGPRs"], sims[name]["TotalSGPRs"]
         assert rt.waves_by_vgpr(v) == 8 and rt.waves_by_sgpr(s) == 8, (name, v, s)

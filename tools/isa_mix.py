@@ -25,12 +25,13 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "bayesflow_nddms_amd", "libnddm_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-# template arguments <MODEL, FAST, CAP4, BRIDGE, SMALL> of the instantiations the named workloads launch (max_steps a
-# multiple of 4 and below 2^14, tiles of <= 512 trials)
-KERNELS = {"basic": (0, 1, 1, 0, 1, 0), "single": (1, 1, 1, 0, 1, 0), "single_alt": (2, 1, 1, 0, 1, 0), "alpha_ns": (3, 1, 1, 0, 1, 0),
-           "alpha_ns_bridge": (3, 1, 1, 1, 0, 0), "explicit": (4, 1, 1, 0, 1, 0)}
-KERNELS.update({k + "_exact": (m, 0, c, b, sm, pk) for k, (m, f, c, b, sm, pk) in list(KERNELS.items())})
-KERNELS.update({k + "_packed": (m, f, c, b, sm, 1) for k, (m, f, c, b, sm, pk) in list(KERNELS.items()) if not b})  # NDDM_GAUSS_PACKED
+# template arguments <MODEL, FAST, CAP4, BRIDGE, SMALL, PACKED, VKEYS> of the instantiations the named workloads launch
+# (max_steps a multiple of 4 and below 2^14, tiles of <= 512 trials, a full grid)
+KERNELS = {"basic": (0, 1, 1, 0, 1, 0, 0), "single": (1, 1, 1, 0, 1, 0, 0), "single_alt": (2, 1, 1, 0, 1, 0, 0),
+           "alpha_ns": (3, 1, 1, 0, 1, 0, 0), "alpha_ns_bridge": (3, 1, 1, 1, 0, 0, 0), "explicit": (4, 1, 1, 0, 1, 0, 0)}
+KERNELS.update({k + "_exact": (m, 0, c, b, sm, pk, vk) for k, (m, f, c, b, sm, pk, vk) in list(KERNELS.items())})
+KERNELS.update({k + "_packed": (m, f, c, b, sm, 1, vk) for k, (m, f, c, b, sm, pk, vk) in list(KERNELS.items()) if not b})  # NDDM_GAUSS_PACKED
+KERNELS["basic_vkeys"] = (0, 1, 1, 0, 1, 0, 1)               # the small-launch variant: round keys in VGPRs
 
 # fallback costs (profiles/r1_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
 COST = {"v_mad_u64_u32": 4.69, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
@@ -104,7 +105,7 @@ def disassemble(so_path=SO):
 
 def kernel_insts(txt, targs):
     """[(address, mnemonic, operand text, branch target or None)] of one sim_kernel instantiation."""
-    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
+    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
     lines = txt.splitlines()
     start = next(i for i, l in enumerate(lines) if l.endswith(f"<{sym}>:"))
     insts = []

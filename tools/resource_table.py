@@ -19,11 +19,11 @@ MODELS = {0: "basic", 1: "single", 2: "single_alt", 3: "alpha_ns", 4: "explicit"
 
 
 def pretty(name):
-    m = re.match(r"_ZN4nddm10sim_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+    m = re.match(r"_ZN4nddm10sim_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
     if m:
-        mod, fast, cap4, bridge, small, packed = (int(x) for x in m.groups())
+        mod, fast, cap4, bridge, small, packed, vkeys = (int(x) for x in m.groups())
         return (f"sim_kernel<{MODELS[mod]}, {'fast' if fast else 'exact'}, cap4={cap4}, bridge={bridge}, small={small}, "
-                f"packed={packed}>")
+                f"packed={packed}, vkeys={vkeys}>")
     m = re.match(r"_ZN4nddm(\d+)", name)
     if m:
         n = int(m.group(1))
@@ -73,7 +73,7 @@ def main():
             print("| " + " | ".join(str(x) for x in o) + " |")
     else:
         for o in out:
-            print(f"{o[0]:70s} VGPR {o[1]:3d}  SGPR {o[2]:3d}  scratch {o[3]:3d}  LDS {o[4]:5d}  waves/SIMD vgpr {o[5]} sgpr {o[6]}")
+            print(f"{o[0]:79s} VGPR {o[1]:3d}  SGPR {o[2]:3d}  scratch {o[3]:3d}  LDS {o[4]:5d}  waves/SIMD vgpr {o[5]} sgpr {o[6]}")
 
 
 if __name__ == "__main__":
