@@ -195,3 +195,40 @@ def test_more_streams_than_launch_slots():
         L.nddm_debug_set_slot_limit(256)
     for ci, (t, s) in got:
         assert _same(torch, t, ref[ci][0]) and _same(torch, s, ref[ci][1]), ci
+
+
+def test_per_thread_default_stream_handle():
+    """hipStreamPerThread is ONE handle value for a different stream in every host thread: the library must not treat two
+    such launches as ordered with each other.  Three threads call the C ABI directly with that handle, concurrently."""
+    import ctypes
+    import torch
+    from bayesflow_nddms_amd import _lib, engine
+    L = _lib.lib()
+    B, N = 600, 200
+    p_dev = torch.as_tensor(prior_util.basic_prior(B, 16)).cuda()
+    ref = engine.simulate(engine.BASIC_DDM_DC, p_dev, N, dt=0.01, max_steps=400, seed=21, set_offset=0, fast=True)
+    torch.cuda.synchronize()
+    outs = [(torch.empty((B, N, 2), device="cuda"), torch.empty((B, 10), device="cuda")) for _ in range(3)]
+    torch.cuda.synchronize()
+    per_thread = ctypes.c_void_p(2)                      # hipStreamPerThread
+    errors = []
+
+    def worker(i):
+        try:
+            t, s = outs[i]
+            for _ in range(60):
+                rc = L.nddm_basic_ddm_dc_simulate(p_dev.data_ptr(), B, N, 0.01, 400, 21, 0, 1, t.data_ptr(), s.data_ptr(), per_thread)
+                assert rc == 0, L.nddm_last_error()
+            torch.cuda.synchronize()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t, s in outs:
+        assert torch.equal(t, ref["trials"]) and torch.equal(torch.nan_to_num(s), torch.nan_to_num(ref["summary"]))
