@@ -76,6 +76,21 @@ def load_ubench(path):
     return cost, sgpr, os.path.basename(path)
 
 
+def text_section(elf):
+    """Bytes of the .text section of an ELF64 object (the kernels' machine code: independent of build paths, which the
+    rest of the file is not -- hipcc derives a compile-unit id from the source path)."""
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize)
+    stroff = sec(shstrndx)[4]
+    for i in range(shnum):
+        name_off, _, _, _, off, size = sec(i)[:6]
+        end = elf.index(b"\0", stroff + name_off)
+        if elf[stroff + name_off:end] == b".text":
+            return elf[off:off + size]
+    raise RuntimeError("no .text section")
+
+
 def code_object(so_path):
     """The gfx950 code object inside the library's clang offload bundle."""
     data = open(so_path, "rb").read()
@@ -90,7 +105,8 @@ def code_object(so_path):
         triple = data[off:off + tl].decode()
         off += tl
         if "gfx950" in triple:
-            return data[i + o:i + o + s], hashlib.sha256(data).hexdigest()[:16]
+            co = data[i + o:i + o + s]
+            return co, hashlib.sha256(text_section(co)).hexdigest()[:16]     # the machine code identifies the library
     raise RuntimeError("no gfx950 code object in " + so_path)
 
 
