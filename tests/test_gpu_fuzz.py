@@ -22,7 +22,7 @@ def _case(rng):
     return model, B, N, dt, max_steps, seed, off, tune, bridge
 
 
-@pytest.mark.parametrize("chunk", range(6))
+@pytest.mark.parametrize("chunk", range(9))
 def test_fuzz_bit_parity(chunk):
     import oracle
     from bayesflow_nddms_amd import _lib, engine
@@ -30,6 +30,8 @@ def test_fuzz_bit_parity(chunk):
     try:
         for _ in range(10):
             model, B, N, dt, max_steps, seed, off, tune, bridge = _case(rng)
+            packed = chunk >= 6                    # chunks 6..8: the NDDM_GAUSS_PACKED bit layout (never with the bridge)
+            bridge = bridge and not packed
             pseed = int(rng.integers(0, 10**6))
             if model == 0:
                 p = prior_util.basic_prior(B, pseed)
@@ -45,10 +47,10 @@ def test_fuzz_bit_parity(chunk):
             _lib.check(_lib.lib().nddm_set_tuning(*tune))
             g = engine.simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, fast=False,
                                 bounds=bounds, ext_sigma=0.2, ext_mode=0,
-                                want_ext=(model == 3), bridge=bridge)
+                                want_ext=(model == 3), bridge=bridge, packed=packed)
             o = oracle.philox_simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, bounds=bounds,
-                                       ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge, threads=8)
-            ctx = (model, B, N, dt, max_steps, seed, off, tune, bridge)
+                                       ext_sigma=0.2, ext_mode=0, want_ext=(model == 3), bridge=bridge, packed=packed, threads=8)
+            ctx = (model, B, N, dt, max_steps, seed, off, tune, bridge, packed)
             assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32)), ctx
             assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32),
                                   np.nan_to_num(o["summary"]).view(np.uint32)), ctx
