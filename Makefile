@@ -13,10 +13,12 @@ oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/ddm_oracle.c
 	gcc -O2 -ffp-contract=off -mfma -fno-math-errno -fopenmp -fPIC -shared -o $@ $< -lm
 
-ubench: tools/ubench_valu tools/ubench_residency
+ubench: tools/ubench_valu tools/ubench_residency tools/ubench_bank
 tools/ubench_valu: tools/ubench_valu.hip
 	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<
 tools/ubench_residency: tools/ubench_residency.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<
+tools/ubench_bank: tools/ubench_bank.hip
 	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<
 
 # the boundary from plain C (examples/c_abi_demo.c): no Python, no PyTorch
@@ -31,5 +33,5 @@ test-gpu:
 	python -m pytest tests -x -q -m gpu
 
 clean:
-	rm -f bayesflow_nddms_amd/libnddm_hip.so oracle/liboracle.so tools/ubench_valu tools/ubench_residency examples/c_abi_demo
+	rm -f bayesflow_nddms_amd/libnddm_hip.so oracle/liboracle.so tools/ubench_valu tools/ubench_residency tools/ubench_bank examples/c_abi_demo
 .PHONY: all lib oracle ubench demo test-cpu test-gpu clean

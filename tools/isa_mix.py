@@ -33,29 +33,32 @@ KERNELS.update({k + "_exact": (m, 0, c, b, sm, pk, vk) for k, (m, f, c, b, sm, p
 KERNELS.update({k + "_packed": (m, f, c, b, sm, 1, vk) for k, (m, f, c, b, sm, pk, vk) in list(KERNELS.items()) if not b})  # NDDM_GAUSS_PACKED
 KERNELS["basic_vkeys"] = (0, 1, 1, 0, 1, 0, 1)               # the small-launch variant: round keys in VGPRs
 
-# fallback costs (profiles/r1_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
-COST = {"v_mad_u64_u32": 4.69, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
+# fallback costs (profiles/r2_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
+COST = {"v_mad_u64_u32": 4.61, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
         "v_sqrt_f32": 8.15, "v_sin_f32": 8.11, "v_cos_f32": 8.23, "v_exp_f32": 8.21, "v_rcp_f32": 8.21,
-        "v_fma_f32": 3.82, "v_fmamk_f32": 3.82, "v_fmac_f32": 2.34, "v_fmaak_f32": 3.82, "v_add_f32": 2.27,
+        "v_fma_f32": 2.22, "v_fmamk_f32": 2.31, "v_fmac_f32": 2.34, "v_fmaak_f32": 2.31, "v_add_f32": 2.27,
         "v_sub_f32": 2.27, "v_mul_f32": 2.27, "v_add_u32": 2.35, "v_sub_u32": 2.35, "v_subrev_u32": 2.35,
         "v_lshrrev_b32": 2.34, "v_lshlrev_b32": 2.34, "v_and_b32": 2.34, "v_or_b32": 2.34, "v_mov_b32": 2.34,
         "v_cmp": 4.05, "v_mul_lo_u32": 4.47, "v_mul_hi_u32": 4.22, "v_bfe_u32": 4.19, "v_and_or_b32": 4.19,
         "v_cvt_i32_f32": 4.13, "v_lshl_add_u32": 4.19, "v_addc_co_u32": 4.22, "v_max_f32": 2.27, "v_min_f32": 2.27,
-        "v_med3_f32": 3.82, "v_add3_u32": 4.49, "v_alignbit_b32": 4.19, "v_cndmask_b32": 4.23, "v_pk_fma_f32": 4.16,
-        "v_pk_mul_f32": 4.23, "v_pk_add_f32": 4.21, "v_bitop3_b32": 3.81, "v_add_co_u32": 4.22, "v_lshl_or_b32": 4.19}
+        "v_med3_f32": 2.22, "v_add3_u32": 4.49, "v_alignbit_b32": 4.19, "v_cndmask_b32": 4.23, "v_pk_fma_f32": 4.16,
+        "v_pk_mul_f32": 4.23, "v_pk_add_f32": 4.21, "v_bitop3_b32": 2.31, "v_add_co_u32": 4.22, "v_lshl_or_b32": 4.19}
 SGPR_OPERAND_COST = 4.16           # a full-rate VOP2 op that reads an SGPR / VCC operand ("v_xor_b32 (sgpr)" row)
 FULL_RATE = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_add_f32", "v_sub_f32",
              "v_mul_f32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32", "v_fmac_f32", "v_max_f32", "v_min_f32"}
 DEFAULT = 2.4
-UBENCH_ROWS = {"v_fma_f32": ["v_fma_f32", "v_fmamk_f32", "v_fmaak_f32", "v_med3_f32"], "v_add_f32": ["v_add_f32", "v_sub_f32", "v_max_f32", "v_min_f32"],
+# (three-operand instructions are costed from the rows measured with three DIFFERENT source registers, the form the kernels
+# use: naming one register twice costs v_bitop3_b32 / v_fma_f32 ~1.5 cycles more -- the rows without a suffix)
+UBENCH_ROWS = {"v_fma_f32 (3 regs)": ["v_fma_f32", "v_med3_f32"], "v_fmamk_f32": ["v_fmamk_f32", "v_fmaak_f32"], "v_add_f32": ["v_add_f32", "v_sub_f32", "v_max_f32", "v_min_f32"],
                "v_mul_f32": ["v_mul_f32"], "v_xor_b32": ["v_xor_b32", "v_and_b32", "v_or_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32"],
                "v_add_u32": ["v_add_u32", "v_sub_u32", "v_subrev_u32"], "v_mul_lo_u32": ["v_mul_lo_u32"], "v_mul_hi_u32": ["v_mul_hi_u32"],
-               "v_mad_u64_u32": ["v_mad_u64_u32"], "v_log_f32": ["v_log_f32", "v_exp_f32"], "v_sqrt_f32": ["v_sqrt_f32"],
+               "v_log_f32": ["v_log_f32", "v_exp_f32"], "v_sqrt_f32": ["v_sqrt_f32"],
                "v_sin_f32": ["v_sin_f32"], "v_cos_f32": ["v_cos_f32"], "v_rcp_f32": ["v_rcp_f32"],
                "v_cvt_f32_u32": ["v_cvt_f32_u32", "v_cvt_f32_i32", "v_cvt_i32_f32"], "v_cmp_lt_f32": ["v_cmp"],
                "v_add3_u32": ["v_add3_u32"], "v_alignbit_b32": ["v_alignbit_b32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_lshl_or_b32"],
                "v_cndmask_e64 (s)": ["v_cndmask_b32"], "v_pk_fma_f32": ["v_pk_fma_f32"], "v_pk_mul_f32": ["v_pk_mul_f32"],
-               "v_pk_add_f32": ["v_pk_add_f32"], "v_bitop3_b32 (xor3)": ["v_bitop3_b32"], "v_fmac_f32": ["v_fmac_f32"],
+               "v_pk_add_f32": ["v_pk_add_f32"], "v_bitop3_b32 (3 regs)": ["v_bitop3_b32"], "v_fmac_f32": ["v_fmac_f32"],
+               "v_mad_u64_u32 (sgpr)": ["v_mad_u64_u32"],
                "v_add_co_u32_e64": ["v_add_co_u32", "v_addc_co_u32"]}
 
 

@@ -123,6 +123,29 @@ DEF_KERNEL(k_mix_sin_mullo, M8, OP8_MIX("v_sin_f32", "v_mul_lo_u32"), SINKM)
     asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a4) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a5) : "v"(c)); \
     asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a6) : "v"(c)); asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a7) : "v"(c));
 DEF_KERNEL(k_bitop3, U8, OP8_B3, SINKU)
+// the same three-operand instructions with THREE DIFFERENT source registers (the form the Philox rounds use): naming one
+// register twice, as the rows above do, costs the instruction an extra ~1.5 cycles
+#define OP8_3D(INS, SUF) \
+    asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a0) : "v"(c), "v"(d)); asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a1) : "v"(c), "v"(d)); \
+    asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a2) : "v"(c), "v"(d)); asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a3) : "v"(c), "v"(d)); \
+    asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a4) : "v"(c), "v"(d)); asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a5) : "v"(c), "v"(d)); \
+    asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a6) : "v"(c), "v"(d)); asm volatile(INS " %0, %0, %1, %2" SUF : "+v"(a7) : "v"(c), "v"(d));
+#define U8D U8; uint32_t d = 0xCD9E8D57u ^ threadIdx.x
+#define F8D F8; float d = 0.999f + 1e-6f * threadIdx.x
+DEF_KERNEL(k_bitop3_3r, U8D, OP8_3D("v_bitop3_b32", " bitop3:0x96"), SINKU)
+DEF_KERNEL(k_add3_3r, U8D, OP8_3D("v_add3_u32", ""), SINKU)
+DEF_KERNEL(k_fma_3r, F8D, OP8_3D("v_fma_f32", ""), SINKF)
+// v_fmamk_f32 d, a, K, b (d = a * K + b with a 32-bit literal): the form the uniform's scaling takes in the step loop
+#define OP8_FMAMK \
+    asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a0) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a1) : "v"(c)); \
+    asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a2) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a3) : "v"(c)); \
+    asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a4) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a5) : "v"(c)); \
+    asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a6) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a7) : "v"(c));
+DEF_KERNEL(k_fmamk, F8, OP8_FMAMK, SINKF)
+// v_mad_u64_u32 with the multiplier in an SGPR, as the Philox rounds have it
+#define MADS(A) { uint64_t w; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w) : "v"(A), "s"(sk) : "vcc"); asm volatile("" : "=v"(A) : "0"((uint32_t)(w >> 32))); }
+#define OP8_MADS MADS(a0) MADS(a1) MADS(a2) MADS(a3) MADS(a4) MADS(a5) MADS(a6) MADS(a7)
+DEF_KERNEL(k_mad64_s, US8, OP8_MADS, SINKU)
 DEF_KERNEL(k_fmac, F8, OP8("v_fmac_f32"), SINKF)
 DEF_KERNEL(k_add_co, U8, asm volatile("v_add_co_u32_e64 %0, s[20:21], 1, %0\n v_add_co_u32_e64 %1, s[22:23], 1, %1\n v_add_co_u32_e64 %2, s[20:21], 1, %2\n v_add_co_u32_e64 %3, s[22:23], 1, %3\n v_add_co_u32_e64 %4, s[20:21], 1, %4\n v_add_co_u32_e64 %5, s[22:23], 1, %5\n v_add_co_u32_e64 %6, s[20:21], 1, %6\n v_add_co_u32_e64 %7, s[22:23], 1, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20", "s21", "s22", "s23");, SINKU)
 
@@ -147,13 +170,15 @@ int main(int argc, char **argv)
                   {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit}, {"v_cndmask_e64 (s)", k_cndmask_s},
                   {"v_cmp_lt_u32_e64", k_cmp_e64}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
                   {"v_pk_add_f32", k_pk_add}, {"v_bitop3_b32 (xor3)", k_bitop3}, {"v_fmac_f32", k_fmac}, {"v_add_co_u32_e64", k_add_co},
+                  {"v_bitop3_b32 (3 regs)", k_bitop3_3r}, {"v_add3_u32 (3 regs)", k_add3_3r}, {"v_fma_f32 (3 regs)", k_fma_3r},
+                  {"v_fmamk_f32", k_fmamk}, {"v_mad_u64_u32 (sgpr)", k_mad64_s},
                   {"2 log + 6 xor", k_mix_log_xor},
                   {"2 sin + 6 mul_lo", k_mix_sin_mullo}};
-    printf("%-18s", "instr \\ waves/SIMD");
+    printf("%-22s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
     printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
     for (auto &e : es) {
-        printf("%-18s", e.name);
+        printf("%-22s", e.name);
         for (int wpc : wpc_list) {
             const int blocks = cus * wpc / 4;    // 256-thread blocks = 4 waves
             hipEvent_t e0, e1;
