@@ -7,6 +7,7 @@
 //           a CPU; this is what tests compare element-wise
 //   fast  : Box-Muller on the CDNA transcendental unit (v_log_f32, v_sqrt_f32, v_sin_f32,
 //           v_cos_f32; sin/cos take their argument in turns, so no 2*pi range reduction)
+// Of a pair's two words the first is the radius uniform, the second the angle: its low 23 bits, as turns.
 // This translation unit is compiled with -ffp-contract=off: every fma below is explicit.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -40,6 +41,15 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// a ? b : c bitwise, in one instruction: v_bitop3_b32 with truth table 0xCA.  With three different source registers it
+// issues at full rate (2.3 cycles; profiles/r2_ubench_valu.txt), where v_alignbit_b32 / v_and_or_b32 take 4.2.
+__device__ __forceinline__ uint32_t mux3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -276,20 +286,24 @@ __device__ __forceinline__ float noise_unit(float sigma)
     return FAST ? sigma * 1.1774100225154747f : sigma;
 }
 
-// (r, cos, sin) of one Box-Muller pair from two u32, radius in noise units
-template <bool FAST>
+// (r, cos, sin) of one Box-Muller pair from two u32, radius in noise units.  HOT: the step loop's form of the fast transform,
+// which holds two constants in VGPRs for the whole kernel; the once-per-trial uses (auxiliary normals) build the same bits
+// with a shift + v_alignbit_b32 and no registers.
+template <bool FAST, bool HOT = false>
 __device__ __forceinline__ void polar_pair(uint32_t xa, uint32_t xb, float &r, float &cs, float &sn)
 {
     const float u = __builtin_fmaf((float)xa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);   // (0, 1]
     if constexpr (FAST) {
         r = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
-        // v_sin/v_cos take turns and reduce the integer part themselves: feed [1, 2) built from the top 23 bits
-        const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, xb, 9u));   // 0x3f800000 | (xb >> 9)
+        // v_sin/v_cos take turns and reduce the integer part themselves: feed [1, 2) whose mantissa is the angle word's
+        // low 23 bits, spliced under the exponent by ONE full-rate instruction
+        const float ang = HOT ? __uint_as_float(mux3(0x007fffffu, xb, 0x3f800000u))    // 0x3f800000 | (xb & 0x7fffff)
+                              : __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, xb << 9, 9u));
         cs = __builtin_amdgcn_cosf(ang);
         sn = __builtin_amdgcn_sinf(ang);
     } else {
         r = exact_sqrtf(-2.0f * exact_logf(u));
-        exact_sincos_turn(xb, sn, cs);
+        exact_sincos_turn(xb << 9, sn, cs);      // the same 23 bits as turns
     }
 }
 
@@ -307,7 +321,7 @@ __device__ __forceinline__ void polar_pair_packed(uint32_t x, float &r, float &c
     const float u = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, x, 9u));      // (0x3f800000 | x >> 9) in [1, 2)
     if constexpr (FAST) {
         r = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
-        const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, x << 16, 9u));  // [1, 2): 16 angle bits on top
+        const float ang = __uint_as_float(mux3(0x007fff80u, x << 7, 0x3f800000u));         // [1, 2): the 16 angle bits on top of the mantissa
         cs = __builtin_amdgcn_cosf(ang);
         sn = __builtin_amdgcn_sinf(ang);
     } else {

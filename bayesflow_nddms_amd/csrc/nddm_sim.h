@@ -665,8 +665,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 polar_pair_packed<FAST>(rb.w, rr[6], tt[6], tt[7]);
                 rr[1] = rr[0]; rr[3] = rr[2]; rr[5] = rr[4]; rr[7] = rr[6];
             } else {
-                polar_pair<FAST>(rb.x, rb.y, rr[0], tt[0], tt[1]);
-                polar_pair<FAST>(rb.z, rb.w, rr[2], tt[2], tt[3]);
+                polar_pair<FAST, true>(rb.x, rb.y, rr[0], tt[0], tt[1]);
+                polar_pair<FAST, true>(rb.z, rb.w, rr[2], tt[2], tt[3]);
                 rr[1] = rr[0]; rr[3] = rr[2];
             }
             uint32_t ub[4] = {0u, 0u, 0u, 0u};

@@ -142,6 +142,23 @@ DEF_KERNEL(k_fma_3r, F8D, OP8_3D("v_fma_f32", ""), SINKF)
     asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a4) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a5) : "v"(c)); \
     asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a6) : "v"(c)); asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(a7) : "v"(c));
 DEF_KERNEL(k_fmamk, F8, OP8_FMAMK, SINKF)
+// v_alignbit_b32 with its high word in a VGPR instead of an SGPR
+#define OP8_ALIGNV \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a0) : "v"(c)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a1) : "v"(c)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a2) : "v"(c)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a3) : "v"(c)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a4) : "v"(c)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a5) : "v"(c)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a6) : "v"(c)); asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(a7) : "v"(c));
+DEF_KERNEL(k_alignbit_v, U8, OP8_ALIGNV, SINKU)
+// ... and with the shift count in a VGPR too (three different source registers)
+#define OP8_ALIGNVV \
+    asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a0) : "v"(c), "v"(d)); asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a1) : "v"(c), "v"(d)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a2) : "v"(c), "v"(d)); asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a3) : "v"(c), "v"(d)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a4) : "v"(c), "v"(d)); asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a5) : "v"(c), "v"(d)); \
+    asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a6) : "v"(c), "v"(d)); asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a7) : "v"(c), "v"(d));
+#define U8S U8; uint32_t d = 9u + (threadIdx.x & 0u)
+DEF_KERNEL(k_alignbit_vv, U8S, OP8_ALIGNVV, SINKU)
+// v_cmpx (writes EXEC as well): an always-true compare, so the lanes stay on
+DEF_KERNEL(k_cmpx, F8, asm volatile("v_cmpx_le_f32 vcc, %0, %0\n v_cmpx_le_f32 vcc, %1, %1\n v_cmpx_le_f32 vcc, %0, %0\n v_cmpx_le_f32 vcc, %1, %1\n v_cmpx_le_f32 vcc, %0, %0\n v_cmpx_le_f32 vcc, %1, %1\n v_cmpx_le_f32 vcc, %0, %0\n v_cmpx_le_f32 vcc, %1, %1" :: "v"(a0), "v"(c) : "vcc", "exec");, SINKF)
 // v_mad_u64_u32 with the multiplier in an SGPR, as the Philox rounds have it
 #define MADS(A) { uint64_t w; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w) : "v"(A), "s"(sk) : "vcc"); asm volatile("" : "=v"(A) : "0"((uint32_t)(w >> 32))); }
 #define OP8_MADS MADS(a0) MADS(a1) MADS(a2) MADS(a3) MADS(a4) MADS(a5) MADS(a6) MADS(a7)
@@ -171,14 +188,15 @@ int main(int argc, char **argv)
                   {"v_cmp_lt_u32_e64", k_cmp_e64}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
                   {"v_pk_add_f32", k_pk_add}, {"v_bitop3_b32 (xor3)", k_bitop3}, {"v_fmac_f32", k_fmac}, {"v_add_co_u32_e64", k_add_co},
                   {"v_bitop3_b32 (3 regs)", k_bitop3_3r}, {"v_add3_u32 (3 regs)", k_add3_3r}, {"v_fma_f32 (3 regs)", k_fma_3r},
-                  {"v_fmamk_f32", k_fmamk}, {"v_mad_u64_u32 (sgpr)", k_mad64_s},
+                  {"v_fmamk_f32", k_fmamk}, {"v_mad_u64_u32 (sgpr)", k_mad64_s}, {"v_cmpx_le_f32", k_cmpx},
+                  {"v_alignbit_b32 (vgpr, imm)", k_alignbit_v}, {"v_alignbit_b32 (3 vgprs)", k_alignbit_vv},
                   {"2 log + 6 xor", k_mix_log_xor},
                   {"2 sin + 6 mul_lo", k_mix_sin_mullo}};
-    printf("%-22s", "instr \\ waves/SIMD");
+    printf("%-28s", "instr \\ waves/SIMD");
     for (int w : wpc_list) printf("  %6d", w / 4);
     printf("   (SIMD cycles per wave64 instruction = wall time x in-kernel clock / instructions per SIMD)\n");
     for (auto &e : es) {
-        printf("%-22s", e.name);
+        printf("%-28s", e.name);
         for (int wpc : wpc_list) {
             const int blocks = cus * wpc / 4;    // 256-thread blocks = 4 waves
             hipEvent_t e0, e1;
