@@ -26,7 +26,7 @@ def _declare(L):
     L.nddm_summary_k.restype = c.c_int
     L.nddm_model_nparams.argtypes = [c.c_int]
     L.nddm_set_tuning.argtypes = [c.c_int] * 6
-    L.nddm_set_debug_counters.argtypes = [c.c_void_p]
+    L.nddm_set_debug_trace.argtypes = [c.c_void_p, c.c_int, c.c_int]
     L.nddm_set_ordering.argtypes = [c.c_int]
     L.nddm_debug_set_slot_limit.argtypes = [c.c_int]
     common = [c.c_int64, c.c_int32, c.c_float, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32]
@@ -47,7 +47,7 @@ EXPORTS = [
     "nddm_abi_version", "nddm_last_error", "nddm_device_count", "nddm_set_device", "nddm_summary_k",
     "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
-    "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_counters", "nddm_set_ordering",
+    "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_trace", "nddm_set_ordering",
     "nddm_release_graph_memory", "nddm_debug_set_slot_limit",
 ]
 

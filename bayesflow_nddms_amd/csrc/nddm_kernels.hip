@@ -68,7 +68,8 @@ static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order; };
 static std::mutex g_mu;
 static Tuning g_tuning = {0, 0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
-static unsigned long long *g_dbg = nullptr;       // nddm_set_debug_counters (profiling aid)
+static unsigned long long *g_dbg = nullptr;       // nddm_set_debug_trace (profiling aid)
+static int g_dbg_waves = 0, g_dbg_chunks = 0;
 
 constexpr int MAX_DEVICES = 64;
 struct DeviceInfo { int cus = 0; double clock_hz = 0.0; };
@@ -327,7 +328,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // snapshot of the developer knobs, and the device this call runs on
     Tuning tun;
     unsigned long long *dbg;
-    { std::lock_guard<std::mutex> lock(g_mu); tun = g_tuning; dbg = g_dbg; }
+    int dbg_waves, dbg_chunks;
+    { std::lock_guard<std::mutex> lock(g_mu); tun = g_tuning; dbg = g_dbg; dbg_waves = g_dbg_waves; dbg_chunks = g_dbg_chunks; }
     int dev = 0;
     {
         const hipError_t e = hipGetDevice(&dev);
@@ -346,7 +348,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.tscale = bridge ? dt * 0.00390625f : dt;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
-    A.dbg = dbg;
+    A.dbg = dbg; A.dbg_waves = dbg_waves; A.dbg_chunks = dbg_chunks;
 
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
@@ -358,18 +360,28 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // busy for milliseconds): cut the sets into tiles of as few as 64 trials so that there are ~8 tiles per resident
     // wave to balance; from ~30M trials on, one tile of up to 512 trials per set is the efficient shape
     const long long total_trials = B * (long long)n_trials;
-    // Grid: as many waves as stay resident -- unless the launch is small.  Then fewer, busier waves win: a wave that gets
-    // ~300+ wave-blocks of work (64 lanes x 4 steps each) keeps its lanes balanced and amortises its start-up, and the
-    // launch's tail (its longest trial) runs on SIMDs that are less crowded.  Measured (dt=.01, 10k-30k sets x 300 trials,
-    // or 100k x 60): 1024-3072 waves are 25-45 % faster than 8192; from ~2.5M wave-blocks on the full grid is best; never
-    // below one wave per SIMD.
+    // Grid: as many waves as stay resident -- unless the launch is small or mid-size.  Two measured effects (profiles/
+    // r2_small_launches.txt):
+    //  * amortisation: a wave that gets ~300+ wave-blocks of work (64 lanes x 4 steps each) keeps its lanes balanced and
+    //    amortises its start-up (dt=.01, 10k-30k sets x 300 trials, or 100k x 60: 1024-3072 waves are 25-45 % faster than
+    //    8192);
+    //  * critical path: a trial that runs to the cap is max_steps / 4 DEPENDENT blocks, and a block of one wave takes as
+    //    long as the SIMD's waves share it (277 cycles each when it is full).  A launch worth x = blocks / (max_steps / 4)
+    //    cap-length trials finishes when its last long trials do, and those run faster on emptier SIMDs: at dt=.001 / cap
+    //    4000, 10k / 20k / 50k sets x 300 trials are fastest on 3072 / 4096-5120 / 5120-6144 waves (29 / 45 / 12 % faster
+    //    than 8192); from x ~ 50k on the full grid is best.
+    // Never below one wave per SIMD.
+    double est_steps = 0.25 / (double)dt;                                // E[steps] under the reference priors
+    if (est_steps > (double)max_steps) est_steps = (double)max_steps;
+    if (est_steps < 1.0) est_steps = 1.0;
+    const double est_blocks = (double)total_trials * est_steps / 256.0;
     long long plan_waves = 8ll * simds;
     if (tun.grid_waves > 0) plan_waves = tun.grid_waves;
     else {
-        double est_steps = 0.25 / (double)dt;                            // E[steps] under the reference priors
-        if (est_steps > (double)max_steps) est_steps = (double)max_steps;
-        if (est_steps < 1.0) est_steps = 1.0;
-        const double want = (double)total_trials * est_steps / 256.0 / 300.0;
+        const double cap_blocks = max_steps > 4 ? (double)max_steps * 0.25 : 1.0;
+        double want = est_blocks / 300.0;
+        const double crit = 3.0 * (double)simds * pow(est_blocks / cap_blocks / (2.8 * (double)simds), 0.4);
+        if (crit < want) want = crit;
         if (want < (double)plan_waves) plan_waves = want < (double)simds ? simds : (long long)want;
     }
     const long long waves_for_tiles = plan_waves < waves7 ? plan_waves : waves7;
@@ -398,9 +410,6 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         // its stepping (E[steps] ~ min(cap, 0.25 / dt) under the reference priors, 265 SIMD cycles per 256 lane-steps)
         // plus one trial that runs to the cap on a full SIMD -- and never fewer than ~8 chunks per wave.  Mid-size
         // launches, whose tail is one chunk, stay below the limit with their fine chunks.
-        double est_steps = 0.25 / (double)dt;
-        if (est_steps > (double)max_steps) est_steps = (double)max_steps;
-        if (est_steps < 1.0) est_steps = 1.0;
         const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / ((double)simds * di.clock_hz)
                              + (double)max_steps * 0.25 * 265.0 * 7.0 / di.clock_hz;
         double max_chunks = t_est * 4.0e7;
@@ -416,7 +425,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
     // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
     const auto lds_of = [&](int r) {
-        return (size_t)LDS_HEADER_DWORDS * 4 + (size_t)r * (DV * 4) + (size_t)r * tile_n * per_trial;
+        return (size_t)LDS_HEADER_DWORDS * 4 + (size_t)r * (size_t)slot_stride_bytes(tile_n, (int)per_trial);
     };
     int ring = tun.ring;
     if (!ring) {
@@ -522,7 +531,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     if (rc == NDDM_OK) {
         const int gw = plan_waves < 8ll * simds || tun.grid_waves > 0 ? (int)plan_waves : 0;     // 0 = what is resident
-        const bool vkeys = plan_waves < 8ll * simds || n_chunks < 8ll * simds;                   // a small launch
+        // round keys in VGPRs (no LDS round trips in the step loop) whenever part of the launch runs on SIMDs that are not
+        // full: a cut grid, fewer chunks than waves, or a launch short enough that its tail matters (measured at dt=.001:
+        // 20k sets x 300 trials 32 % faster, 50k 8 %, 100k equal, 300k 2 % slower)
+        const bool vkeys = plan_waves < 8ll * simds || n_chunks < 8ll * simds || est_blocks < 2.0e4 * (double)simds;
         switch (model) {
         case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
@@ -601,12 +613,18 @@ int nddm_set_ordering(int enabled)
     return NDDM_OK;
 }
 
-/* profiling aid: device u64[8], the next launches accumulate (step-loop blocks, refill phases, sum of per-wave
- * s_memtime cycles, sum of per-wave s_memrealtime ticks (100 MHz), waves); NULL switches it off */
-int nddm_set_debug_counters(void *dev_u64x8)
+/* profiling aid: the simulator kernels of the next launches record, with plain stores, one 8-word record per workgroup
+ * (= wave) w < wave_capacity at buf[8 w ..]: {step-loop blocks, refill phases, s_memtime cycles, lifetime in
+ * s_memrealtime ticks (100 MHz), start tick, tick at which the wave found the work queue empty, end tick, 1}, and the
+ * tick at which chunk c < chunk_capacity was pulled from the queue at buf[8 wave_capacity + c].  buf = device u64
+ * [8 wave_capacity + chunk_capacity], zeroed by the caller; NULL switches the trace off.  (tools/wave_timeline.py) */
+int nddm_set_debug_trace(void *dev_u64, int wave_capacity, int chunk_capacity)
 {
+    if (dev_u64 && (wave_capacity < 0 || chunk_capacity < 0)) return nddm::fail(NDDM_ERR_PARAM, "negative trace capacity%s");
     std::lock_guard<std::mutex> lock(nddm::g_mu);
-    nddm::g_dbg = static_cast<unsigned long long *>(dev_u64x8);
+    nddm::g_dbg = static_cast<unsigned long long *>(dev_u64);
+    nddm::g_dbg_waves = dev_u64 ? wave_capacity : 0;
+    nddm::g_dbg_chunks = dev_u64 ? chunk_capacity : 0;
     return NDDM_OK;
 }
 

@@ -14,6 +14,14 @@ namespace nddm {
 constexpr int WAVE = 64;
 constexpr int MAX_REJECT = 64;   // cap of the per-trial latent's rejection loop (P(reject) <= 1/2 per draw)
 
+// LDS accessed by byte address held in a VGPR (the step loop's lanes keep addresses, not indices)
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32v2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32v4 lds_u32v4;
+typedef __attribute__((address_space(3))) u32v2 lds_u32v2;
+
 template <int MODEL> struct ModelTraits;
 template <> struct ModelTraits<NDDM_BASIC_DDM_DC>      { static constexpr int P = 5; static constexpr bool HAS_Z = false; static constexpr int TAU = 3; };
 template <> struct ModelTraits<NDDM_SINGLE_TRIAL>      { static constexpr int P = 8; static constexpr bool HAS_Z = true;  static constexpr int TAU = 3; };
@@ -48,7 +56,11 @@ struct SimArgs {
     int open_ahead;           // tiles staged ahead of the one being handed out (0 when work is scarce, else 1)
     float ext_sigma;
     int ext_mode;
-    unsigned long long *dbg;  // optional [8] counters (blocks, refills, memtime, memrealtime, waves); null in production
+    unsigned long long *dbg;  // optional trace buffer (nddm_set_debug_trace): [dbg_waves][8] per-wave records {step-loop blocks,
+                              // refill phases, s_memtime cycles, lifetime ticks, start tick, tick at which the wave found
+                              // the queue empty, end tick, 1}, indexed by workgroup, then [dbg_chunks] pull ticks of the
+                              // chunks; null in production.  Plain stores only: the trace does not perturb the launch
+    int dbg_waves, dbg_chunks;
     int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384;
                               // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
@@ -190,13 +202,18 @@ enum { D_A = 0, D_B = 4,                             // r[0..3], r[4..7]
        D_SIC = 8, D_TAU = 9, D_TBASE = 10, D_VSET = 11, // in-call set index, tau, first trial of the tile within its set,
                                                      // virtual set (set * tiles_per_set + tile)
        D_CA = 12, D_CB = 13, D_HP1K = 14, D_X1 = 15, // Philox constants of the set (PathSet in nddm_rng.h)
-       D_C3 = 16, D_SETLO = 17, D_CNT = 18,          // high set word (28 bits), low set word (auxiliary stream's counter);
-                                                     // trials of the tile retired so far
+       D_C3 = 16, D_SETLO = 17,                      // high set word (28 bits), low set word (auxiliary stream's counter)
        D_ZSUM = 20,                                  // [20..23] fixed-point sums of z and z^2 (models with a z summary), or
        D_BCA = 20, D_BCB = 21, D_BHP1K = 22, D_BX1 = 23 }; // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
 constexpr int DV = 24;                               // one layout for every model: only two LDS base addresses stay live
 static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the loaded record");
-constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,26) | kC kD kE [28,31)
+constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,28) | kC kD kE [28,31)
+// One ring slot = the tile's record followed by its staged results (2 or 4 bytes per trial), 16-byte aligned: a lane
+// addresses both from one base (slot * stride), and keeps the LDS byte address of its trial's result word while it steps.
+__host__ __device__ constexpr int slot_stride_bytes(int tile_trials, int bytes_per_result)
+{
+    return DV * 4 + ((tile_trials * bytes_per_result + 15) & ~15);
+}
 
 // The per-trial latent of the single-trial family and the external datum that goes with it: a pure function of
 // (set, trial) and the set's record, so the hand-out (which needs the latent) and the flush (which writes the datum next
@@ -205,7 +222,7 @@ constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug
 //   single:     latent = boundary ~ N(mu_alpha, std_alpha) > 0 (single_trial_alpha_not_scaled.py:113-116),  z1 ~ N(gamma * boundary, sigma1) (:134)
 //   single_alt: latent = dc       ~ N(mu_dc, std_dc) > 0       (:932-935),                                z1 ~ N(gamma * dc, sigma1)
 template <int MODEL, bool FAST>
-__device__ __forceinline__ void trial_latent(const uint4 dA, const uint4 dB, uint32_t set_lo, uint32_t c3, uint32_t trial,
+__device__ __forceinline__ void trial_latent(const u32v4 dA, const u32v4 dB, uint32_t set_lo, uint32_t c3, uint32_t trial,
                                              uint32_t kbase, float &latent, float &z)
 {
     static_assert(MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT, "models with a per-trial latent");
@@ -284,11 +301,11 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     using T = ModelTraits<MODEL>;
     constexpr bool ZSUM = MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT;
     const float tau = __uint_as_float(d[D_TAU]);
-    [[maybe_unused]] uint4 dA = {0u, 0u, 0u, 0u}, dB = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] u32v4 dA = {0u, 0u, 0u, 0u}, dB = {0u, 0u, 0u, 0u};
     [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;
     [[maybe_unused]] long long acc_z = 0, acc_zz = 0;
     if constexpr (ZSUM) {
-        dA = *reinterpret_cast<const uint4 *>(d + D_A); dB = *reinterpret_cast<const uint4 *>(d + D_B);
+        dA = *reinterpret_cast<const u32v4 *>(d + D_A); dB = *reinterpret_cast<const u32v4 *>(d + D_B);
         c3 = d[D_C3]; set_lo = d[D_SETLO];
     }
     const int N = Ap->n_trials;
@@ -427,19 +444,22 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t off = (uint32_t)(size_t)lds_raw;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
     }
-    uint32_t *dv = lds_raw + LDS_HEADER_DWORDS;                        // [ring][DV], 16-byte aligned
-    // staged results: one 32-bit word per trial, or one 16-bit word when the step cap allows (halves the LDS footprint,
-    // which is what lets the 7th and 8th wave per SIMD stay resident at 300 trials per set)
-    uint32_t *res = dv + ring * DV;
-    uint16_t *res_h = reinterpret_cast<uint16_t *>(res);
+    // ring slots: [DV-dword record | staged results], 16-byte aligned.  Staged results: one 32-bit word per trial, or one
+    // 16-bit word when the step cap allows (halves the LDS footprint, which is what lets the 7th and 8th wave per SIMD
+    // stay resident at 300 trials per set)
+    const int rshift = (SMALL || A.res16) ? 1 : 2;                     // log2 bytes per staged result
+    const int stride = DV * 4 + (((N << rshift) + 15) & ~15);          // slot_stride_bytes()
+    char *const slots = reinterpret_cast<char *>(lds_raw + LDS_HEADER_DWORDS);
+    auto slot_rec = [&](int slot) { return reinterpret_cast<uint32_t *>(slots + slot * stride); };
+    constexpr uint32_t SLOTS_OFF = LDS_HEADER_DWORDS * 4;              // byte offset of slot 0 from kbase
 
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
     float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
     int k = 0;
     uint32_t jit = 0;
-    uint32_t ltrial = 0;     // index within the tile (LDS slot position)
-    int tile = 0;            // wave-local sequence number of the set this lane works on
+    uint32_t res_addr = 0;   // LDS byte address (relative to the slots) of the trial's staged result
+    int tile = 0;            // wave-local sequence number of the tile this lane works on
     bool invalid = false;
     // which lanes hold a trial / are still stepping: wave-uniform lane masks kept in SGPRs (a per-lane bool that is
     // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
@@ -458,7 +478,11 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
     // debug counters live in LDS (SGPRs are scarce): dbg_stamp[2] = refill phases << 32 | step-loop blocks
     unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks
-    if (lane == 0) { dbg_stamp[2] = 0; if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); } }
+    if (lane == 0) {
+        dbg_stamp[2] = 0; dbg_stamp[3] = 0;
+        lds_raw[31] = blockIdx.x;             // read back at exit (kept in LDS: an SGPR held through the kernel costs residency)
+        if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+    }
 
     // The record of the NEXT tile of the current chunk, loaded when the tile before it is opened (lanes < REC hold one
     // dword each): by the time it is consumed the load has long completed, so opening a tile never waits on memory.
@@ -478,7 +502,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 unsigned int c = 0;
                 if (lane == 0) c = atomicAdd(R->chunk_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= (unsigned int)R->n_chunks) { chunk_left = -1; break; }
+                if (c >= (unsigned int)R->n_chunks) {
+                    chunk_left = -1;
+                    if (lane == 0 && R->dbg) dbg_stamp[3] = __builtin_amdgcn_s_memrealtime();      // the queue ran dry (trace)
+                    break;
+                }
+                if (lane == 0 && R->dbg && c < (unsigned int)R->dbg_chunks)                      // trace: when chunk c was pulled
+                    R->dbg[8ll * R->dbg_waves + c] = __builtin_amdgcn_s_memrealtime();
                 chunk_set = (int)c * R->sets_per_chunk;
                 const long long left = R->B - (long long)chunk_set;
                 chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
@@ -497,10 +527,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             }
             const int sic = __builtin_amdgcn_readlane((int)rec, R_SET);  // the set's row in the caller's arrays
             const int vset = sic * TPS + qt;
-            uint32_t *d = dv + slot * DV;
+            uint32_t *d = slot_rec(slot);
             if (lane < REC) d[lane] = rec;
             if (lane == 0) {
-                d[D_VSET] = (uint32_t)vset; d[D_CNT] = 0u;
+                d[D_VSET] = (uint32_t)vset;
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) { d[D_ZSUM] = 0u; d[D_ZSUM + 1] = 0u; d[D_ZSUM + 2] = 0u; d[D_ZSUM + 3] = 0u; }
                 // everything here is wave-uniform: scalar arithmetic
                 const unsigned long long gset = R->set_offset + (unsigned long long)sic;
@@ -530,10 +560,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
-            const int slot = tile & ring_mask;
-            if (SMALL || fresh_args(Ak)->res16) res_h[(size_t)slot * N + ltrial] = (uint16_t)(tfix | (code << 14));
-            else res[(size_t)slot * N + ltrial] = tfix | (code << 30);
-            atomicAdd(dv + slot * DV + D_CNT, 1u);
+            if (SMALL || rshift == 1) *reinterpret_cast<lds_u16 *>(res_addr + (SLOTS_OFF + DV * 4)) = (uint16_t)(tfix | (code << 14));
+            else *reinterpret_cast<lds_u32 *>(res_addr + (SLOTS_OFF + DV * 4)) = tfix | (code << 30);
         }
         has_m &= ~fin_mask0;
         to_retire -= (int)__popcll(fin_mask0);
@@ -542,16 +570,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         if (to_retire <= 0) {
             __syncthreads();
             while (flushed < tile_open) {
-                const int slot = flushed & ring_mask;
-                const int c = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_CNT]);
-                if (c != N) break;
-                const int set_in_call = __builtin_amdgcn_readfirstlane((int)dv[slot * DV + D_VSET]);
-                if constexpr (SMALL)
-                    flush_set<MODEL, FAST, true>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV, res_h + (size_t)slot * N, kbase);
-                else
-                    flush_set<MODEL, FAST, false>(fresh_args(Ak), lane, (long long)set_in_call, dv + slot * DV,
-                                                  fresh_args(Ak)->res16 ? static_cast<const void *>(res_h + (size_t)slot * N)
-                                                                        : static_cast<const void *>(res + (size_t)slot * N), kbase);
+                // the oldest tile is complete when all its trials have been handed out and no lane holds one of them
+                // (no per-tile counter: the hand-out is sequential, so these two wave-uniform facts say it all)
+                if (next_tile <= flushed) break;
+                if (__builtin_amdgcn_ballot_w64(tile == flushed) & has_m) break;
+                uint32_t *const d = slot_rec(flushed & ring_mask);
+                const int set_in_call = __builtin_amdgcn_readfirstlane((int)d[D_VSET]);
+                flush_set<MODEL, FAST, SMALL>(fresh_args(Ak), lane, (long long)set_in_call, d, d + DV, kbase);
                 flushed++;
                 to_retire += N;
             }
@@ -577,17 +602,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
                 const ArgsPtr H = fresh_args(Ak);
                 tile = tl;
-                ltrial = (uint32_t)tr;
-                const int slot = tl & ring_mask;
-                const uint4 d0 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_A);
-                const uint4 d1 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_CA);
-                const uint4 d2 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_SIC);      // set index, tau, TBASE
+                // LDS byte address of the slot (kbase holds the LDS base: one v_mad_u32_u24), of the trial's result word
+                const uint32_t sb = __umul24((uint32_t)(tl & ring_mask), (uint32_t)stride) + kbase;
+                res_addr = sb + ((uint32_t)tr << rshift);
+                const lds_u32v4 *const rq = reinterpret_cast<const lds_u32v4 *>(sb + SLOTS_OFF);
+                const lds_u32 *const rw = reinterpret_cast<const lds_u32 *>(sb + SLOTS_OFF);
+                const u32v4 d0 = rq[D_A / 4];
+                const u32v4 d1 = rq[D_CA / 4];
+                const u32v4 d2 = rq[D_SIC / 4];                          // set index, tau, TBASE
                 const float a0 = __uint_as_float(d0.x), a1 = __uint_as_float(d0.y), a2 = __uint_as_float(d0.z),
                             a3 = __uint_as_float(d0.w);                  // the model's A constants (make_record)
                 const uint32_t trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
                 [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;       // the auxiliary stream's set words
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT || MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    const uint2 sw = *reinterpret_cast<const uint2 *>(dv + slot * DV + D_C3);
+                    const u32v2 sw = *reinterpret_cast<const lds_u32v2 *>(sb + SLOTS_OFF + D_C3 * 4);
                     c3 = sw.x; set_lo = sw.y;
                 }
                 invalid = false;
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     mu_dt = a0; h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
+                    const u32v4 d3 = rq[D_B / 4];
                     float a, z_unused;
                     trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, a, z_unused);      // per-trial boundary
                     const float hv = 0.5f * a;
@@ -604,7 +632,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     w = (a * __uint_as_float(d3.z) - hv) * a1;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     // A = drift, alpha, beta, std_dc;  B = mu_dc, sigma1, gamma
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_B);
+                    const u32v4 d3 = rq[D_B / 4];
                     float sig_c, z_unused;
                     trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, sig_c, z_unused);  // per-trial noise scale
                     const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);
@@ -615,7 +643,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
                     // A = Nu, 1/S, a/(2S), w0;  B = Eta
                     AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    const float eta = __uint_as_float(dv[slot * DV + D_B]);
+                    const float eta = __uint_as_float(rw[D_B]);
                     mu_dt = (__builtin_fmaf(eta, aux.normal(0), a0) * H->dt) * a1;
                     h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
@@ -630,7 +658,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const uint4 kq = *reinterpret_cast<const uint4 *>(lds_raw + 28);       // kC, kD, kE of PathCtr::init
                 pc.init(d1.x, d1.y, d1.z, d1.w, trial, kq.x, kq.y, kq.z);
                 if constexpr (BRIDGE) {
-                    const uint4 d4 = *reinterpret_cast<const uint4 *>(dv + slot * DV + D_BCA);
+                    const u32v4 d4 = rq[D_BCA / 4];
                     pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
                 }
                 k = 0;
@@ -724,11 +752,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     }
     unsigned long long *const dbg = fresh_args(Ak)->dbg;
     if (dbg && lane == 0) {
-        atomicAdd(dbg + 0, dbg_stamp[2] & 0xffffffffull);
-        atomicAdd(dbg + 1, dbg_stamp[2] >> 32);
-        atomicAdd(dbg + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_stamp[0]));
-        atomicAdd(dbg + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_stamp[1]));
-        atomicAdd(dbg + 4, 1ull);
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime(), c_end = __builtin_amdgcn_s_memtime();
+        const uint32_t wg = lds_raw[31];
+        if (wg < (uint32_t)fresh_args(Ak)->dbg_waves) {
+            unsigned long long *const r = dbg + 8ull * wg;
+            r[0] = dbg_stamp[2] & 0xffffffffull; r[1] = dbg_stamp[2] >> 32;
+            r[2] = c_end - dbg_stamp[0]; r[3] = t_end - dbg_stamp[1];
+            r[4] = dbg_stamp[1]; r[5] = dbg_stamp[3]; r[6] = t_end; r[7] = 1ull;
+        }
     }
 }
 

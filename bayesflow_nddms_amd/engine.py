@@ -223,3 +223,35 @@ def debug_normals(counters, k0, k1, fast=False):
                                        torch.cuda.current_stream().cuda_stream)
     _lib.check(rc)
     return out.cpu().numpy()
+
+
+class debug_trace:
+    """Developer aid (profiling): `with debug_trace() as t: simulate(...)`, then `t.read()`.  While active, every wave of
+    the simulator kernels stores one record {step-loop blocks, refill phases, s_memtime cycles, lifetime / start / queue
+    found empty / end in 100 MHz ticks} and, with chunks > 0, the tick at which each chunk was pulled from the work queue
+    (include/nddm.h: nddm_set_debug_trace; plain stores, so the traced launch runs like any other)."""
+
+    def __init__(self, waves=16384, chunks=0, device=None):
+        torch = require_device()
+        self.waves, self.chunks = int(waves), int(chunks)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.buf = torch.zeros(8 * self.waves + self.chunks, dtype=torch.int64, device=dev)
+
+    def __enter__(self):
+        _lib.check(_lib.lib().nddm_set_debug_trace(self.buf.data_ptr(), self.waves, self.chunks))
+        return self
+
+    def __exit__(self, *exc):
+        require_device().cuda.synchronize()
+        _lib.lib().nddm_set_debug_trace(None, 0, 0)
+        return False
+
+    def read(self):
+        """dict: totals over the waves that ran (blocks, refills, cycles, ticks, waves), the per-wave records [n, 8] and
+        the chunks' pull ticks."""
+        d = self.buf.cpu().numpy()
+        rec = d[:8 * self.waves].reshape(self.waves, 8)
+        rec = rec[rec[:, 7] == 1]
+        pulls = d[8 * self.waves:]
+        return {"blocks": float(rec[:, 0].sum()), "refills": float(rec[:, 1].sum()), "cycles": float(rec[:, 2].sum()),
+                "ticks": float(rec[:, 3].sum()), "waves": int(rec.shape[0]), "records": rec, "pulls": pulls[pulls > 0]}

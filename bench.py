@@ -278,12 +278,10 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed)
         run = lambda: engine.simulate(model_id, p, N, dt=a.dt, max_steps=a.max_steps, seed=7, set_offset=0, fast=fast,
                                       out_summary=summ, want_trials=False, bridge=bridge, packed=packed)
         run()
-        dbg = torch.zeros(8, dtype=torch.int64, device=dev)
-        L.nddm_set_debug_counters(dbg.data_ptr())
-        run()
-        torch.cuda.synchronize()
-        L.nddm_set_debug_counters(None)
-        blocks = float(dbg[0].item())
+        with engine.debug_trace(device=dev) as tr:
+            run(); run()                              # back to back: the second launch's records are the ones that stay
+        t = tr.read()
+        blocks, clock = t["blocks"], 0.1 * t["cycles"] / max(t["ticks"], 1.0)      # s_memtime cycles per 100 MHz tick
         best = 1e30
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -296,7 +294,8 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed)
     lane_eff = steps / (blocks * 64.0 * (8 if packed else 4))
     sps = steps / (best * 1e-3)
     return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
-            "kernel_ms": best, "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
+            "kernel_ms": best, "clock_ghz_in_kernel": clock,
+            "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
 
 
 def worker(a):
@@ -437,6 +436,7 @@ def simulate_bench(a, ctx):
                        "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
                        "ceiling_measured_steps_per_s": c["steps_per_s"], "ceiling_lane_efficiency": c["lane_efficiency"],
                        "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"],
+                       "ceiling_clock_ghz_in_kernel": c["clock_ghz_in_kernel"],
                        "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 64.0 * spb / peak, "steps_per_block": spb})
         im = issue_model(a.model, a.gauss)
         if im:
@@ -447,26 +447,29 @@ def simulate_bench(a, ctx):
         res["roofline_valu"] = rv
         # steps the lanes actually EXECUTED (incl. lanes idling on a finished trial until the next refill): one more
         # launch of the last batch, outside the timed region, with the kernel's debug counters switched on
-        dbg = torch.zeros(8, dtype=torch.int64, device=dev)
-        _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
-        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        d0.record()
-        step(a.warmup + a.steps - 1)
-        d1.record()
-        torch.cuda.synchronize()
-        dbg_ms = d0.elapsed_time(d1)
-        _lib.lib().nddm_set_debug_counters(None)
-        d = dbg.cpu().numpy().astype(np.float64)
-        lane_steps = d[0] * 64.0 * spb
+        with engine.debug_trace(device=dev) as tr:
+            for _ in range(3):                        # back to back, like the timed steps; the last launch's records stay
+                step(a.warmup + a.steps - 1)
+        d = tr.read()
+        lane_steps = d["blocks"] * 64.0 * spb
+        clock = 0.1 * d["cycles"] / max(d["ticks"], 1.0)
         rv.update({"executed_lane_steps_per_launch": lane_steps, "lane_efficiency": em_steps / lane_steps,
-                   "philox_blocks_per_refill": d[0] / max(d[1], 1.0), "waves": int(d[4])})
+                   "philox_blocks_per_refill": d["blocks"] / max(d["refills"], 1.0), "waves": d["waves"],
+                   "clock_ghz_in_kernel": clock})
+        if "ceiling_clock_ghz_in_kernel" in rv and clock > 0:
+            # the shader clock the two launches actually ran at (s_memtime / s_memrealtime inside the kernel): short
+            # launches of the refill-heavy mix run at a lower clock than the long lockstep launch, which `frac` (a ratio of
+            # rates) counts against the kernel; this is the same ratio in SIMD cycles
+            rv["frac_in_cycles"] = rv["frac"] * rv["ceiling_clock_ghz_in_kernel"] / clock
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
-        resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / (4.0 * cus)
-        res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": int(d[4]),
+        rec = d["records"]
+        span = float(rec[:, 6].max() - rec[:, 4].min())             # first wave start -> last wave end, 100 MHz ticks
+        resident = d["ticks"] / max(span, 1.0) / (4.0 * cus)
+        res["occupancy"] = {"resident_waves_per_simd": resident, "hardware_max": 8, "grid_waves": d["waves"],
                             "limit": "SGPR file (800 per SIMD, a wave is charged its SGPRs + 22 rounded up to 16): <= 74 SGPRs -> 8 wave64 "
                                      "per SIMD; tools/resource_table.py lists every kernel",
-                            "note": "from in-kernel wave lifetimes (s_memrealtime); PMC SQ_WAVE_CYCLES in profiles/ agrees"}
+                            "note": "sum of the waves' lifetimes / (first start -> last end) / SIMDs, from per-wave s_memrealtime records (nddm_set_debug_trace)"}
         if not a.no_ks:
             res["ks_vs_ref"] = ks_vs_golden(engine, a.model, a.dt, a.max_steps, fast, packed)
         if not packed and not bridge and fast and not a.no_ks:

@@ -21,7 +21,7 @@
  *   - re-entrant and thread-safe given distinct output buffers: any number of host threads may call on any streams
  *     concurrently.  The device memory a launch needs besides the caller's buffers (work-queue words, scratch) is owned by
  *     that launch until the work it enqueued has COMPLETED (reuse is keyed on stream order or on a completion event, never
- *     on a launch count); the developer knobs (nddm_set_tuning, nddm_set_debug_counters) are read once, atomically, at entry.
+ *     on a launch count); the developer knobs (nddm_set_tuning, nddm_set_debug_trace) are read once, atomically, at entry.
  *   - hipGraph: a call made while `stream` is capturing is recorded as kernels only; the memory such a launch needs is
  *     allocated for that launch alone and lives until nddm_release_graph_memory().  Seed and set_offset are baked in.
  *

@@ -31,16 +31,12 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
     kw = dict(dt=dt, max_steps=ms, set_offset=0, fast=fast, out_trials=out, out_summary=summ, want_trials=trials_out, bridge=bridge, packed=packed)
     engine.simulate(model, pd, N, seed=1, **kw)
     torch.cuda.synchronize()
-    dbg = torch.zeros(8, dtype=torch.int64, device='cuda')
-    _lib.lib().nddm_set_debug_counters(dbg.data_ptr())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    engine.simulate(model, pd, N, seed=2, **kw)
-    e1.record()
-    torch.cuda.synchronize()
-    dbg_ms = e0.elapsed_time(e1)
-    _lib.lib().nddm_set_debug_counters(None)
-    d = dbg.cpu().numpy().astype(float)
+    with engine.debug_trace() as tr:
+        engine.simulate(model, pd, N, seed=2, **kw)
+    t = tr.read()
+    rec = t["records"]
+    d = [t["blocks"], t["refills"], t["cycles"], t["ticks"], t["waves"]]
+    span_ms = float(rec[:, 6].max() - rec[:, 4].min()) * 1e-5
     best = 1e9
     for r in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,7 +50,7 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
     steps = float(((s[:, 3] - tau) / dt * nresp)[nresp > 0].sum() + s[:, 2].sum() * int(ms))
     spb = 8 if packed else 4
     cyc = best * 1e-3 * 2.4e9 * 1024 / (steps / 256)            # per 4 steps x 64 lanes, whatever the block size
-    resident = d[3] * 1e-8 / (dbg_ms * 1e-3) / 1024.0
+    resident = d[3] * 1e-5 / span_ms / 1024.0
     print(f"model={model} B={B} N={N} dt={dt} cap={int(ms)} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge} packed={packed}: "
           f"{best:.3f} ms  {B*N/best*1e3:.3e} trials/s  {steps/best*1e3:.3e} steps/s  {cyc:.0f} cyc/useful-block | lane-eff {steps/(d[0]*64*spb):.3f} "
           f"blocks/refill {d[0]/max(d[1],1):.1f} clock {d[2]/max(d[3],1)*0.1:.3f} GHz waves {d[4]:.0f} resident/SIMD {resident:.2f}", flush=True)
