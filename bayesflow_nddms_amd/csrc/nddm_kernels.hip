@@ -425,7 +425,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // (28 single-wave workgroups per CU; LDS is allocated in 1280-byte granules, so <= 5120 B each): every wave counts
     // (+3 % from 6 to 7, -6 % at 5, -17 % at 4), which costs more than a short window.
     const auto lds_of = [&](int r) {
-        return (size_t)LDS_HEADER_DWORDS * 4 + (size_t)r * (size_t)slot_stride_bytes(tile_n, (int)per_trial);
+        return (size_t)lds_header_bytes(model) + (size_t)r * (size_t)slot_stride_bytes(tile_n, (int)per_trial);
     };
     int ring = tun.ring;
     if (!ring) {

@@ -125,6 +125,14 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// The lane index behind a compiler barrier: a predicate on it (lane == 0, lane < REC) is then recomputed where it is used
+// -- one v_cmp in a rare path -- instead of being hoisted into an SGPR pair that stays live through the step loop.
+__device__ __forceinline__ int fresh_lane(int lane)
+{
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -210,6 +218,19 @@ static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the 
 constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,28) | kC kD kE [28,31)
 // One ring slot = the tile's record followed by its staged results (2 or 4 bytes per trial), 16-byte aligned: a lane
 // addresses both from one base (slot * stride), and keeps the LDS byte address of its trial's result word while it steps.
+// Models whose trials carry a per-trial latent drawn from the auxiliary stream (single-trial family: boundary / noise
+// scale; alpha_not_scaled: drift) keep a 128-entry FIFO of latents behind the header: the latents of the next trials of
+// the wave's hand-out sequence are drawn 64 at a time, by all lanes, instead of by the ~12-16 lanes of each hand-out
+// (the draw is ~100 VALU instructions whatever the number of lanes it serves).
+__host__ __device__ constexpr bool model_has_latent(int model)
+{
+    return model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
+}
+constexpr int LATENT_FIFO = 128;                     // entries (f32); a power of two >= 2 * WAVE
+__host__ __device__ constexpr int lds_header_bytes(int model)
+{
+    return LDS_HEADER_DWORDS * 4 + (model_has_latent(model) ? LATENT_FIFO * 4 : 0);
+}
 __host__ __device__ constexpr int slot_stride_bytes(int tile_trials, int bytes_per_result)
 {
     return DV * 4 + ((tile_trials * bytes_per_result + 15) & ~15);
@@ -370,7 +391,7 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
             sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
             const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
             const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
-            if (lane == WAVE - 1) {                          // the DPP reductions leave the totals in the last lane
+            if (fresh_lane(lane) == WAVE - 1) {              // the DPP reductions leave the totals in the last lane
                 q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
                        ((unsigned long long)(cnt3 >> 20) << 42);
                 q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
@@ -380,7 +401,7 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
         } else {
             n_up = wave_sum(n_up); n_lo = wave_sum(n_lo); n_miss = wave_sum(n_miss);
             sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-            if (lane == 0) {
+            if (fresh_lane(lane) == 0) {
                 q[0] = (unsigned long long)n_up | ((unsigned long long)n_lo << 21) | ((unsigned long long)n_miss << 42);
                 q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
                 if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
@@ -388,7 +409,7 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
         }
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-        if (Ap->out_ext && lane == 0 && t0 == 0) {
+        if (Ap->out_ext && fresh_lane(lane) == 0 && t0 == 0) {
             const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
             AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
             const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     const ArgsPtr Ak = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x;
     const int N = A.n_trials;
-    const int ring = A.ring, ring_mask = A.ring - 1;
+    const int ring_mask = A.ring - 1;       // (the ring size itself is read from the kernarg segment where it is needed)
 
     // LDS carve-up.  Header (128 bytes): the ten Philox round-key pairs [0, 80) (philox4x32_10_path), debug stamps
     // [80, 104), the three round keys that fold into the per-trial constants [112, 124).  Then one ring slot per
@@ -448,10 +469,15 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // 16-bit word when the step cap allows (halves the LDS footprint, which is what lets the 7th and 8th wave per SIMD
     // stay resident at 300 trials per set)
     const int rshift = (SMALL || A.res16) ? 1 : 2;                     // log2 bytes per staged result
+    constexpr bool LATENT = model_has_latent(MODEL);
     const int stride = DV * 4 + (((N << rshift) + 15) & ~15);          // slot_stride_bytes()
-    char *const slots = reinterpret_cast<char *>(lds_raw + LDS_HEADER_DWORDS);
+    char *const slots = reinterpret_cast<char *>(lds_raw) + lds_header_bytes(MODEL);
     auto slot_rec = [&](int slot) { return reinterpret_cast<uint32_t *>(slots + slot * stride); };
-    constexpr uint32_t SLOTS_OFF = LDS_HEADER_DWORDS * 4;              // byte offset of slot 0 from kbase
+    constexpr uint32_t SLOTS_OFF = lds_header_bytes(MODEL);            // byte offset of slot 0 from kbase
+    constexpr uint32_t FIFO_OFF = LDS_HEADER_DWORDS * 4;               // ... of the latent FIFO (models with a latent)
+    // latent FIFO: fifo_pos = hand-out sequence position of the wave's next trial (entry index = position mod LATENT_FIFO),
+    // fifo_avail = latents drawn ahead of it
+    [[maybe_unused]] int fifo_pos = 0, fifo_avail = 0;
 
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
@@ -495,19 +521,19 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // 7,168 waves: 6x slower for mid-size batches)
     auto open_tiles = [&]() {
         const ArgsPtr R = fresh_args(Ak);
-        while (tile_open < flushed + ring && tile_open <= next_tile + R->open_ahead) {
+        while (tile_open < flushed + R->ring && tile_open <= next_tile + R->open_ahead) {
             const bool have_pre = chunk_left > 0;                        // mid-chunk: this tile's record was prefetched
             if (chunk_left <= 0) {
                 if (chunk_left < 0) break;
                 unsigned int c = 0;
-                if (lane == 0) c = atomicAdd(R->chunk_counter, 1u);
+                if (fresh_lane(lane) == 0) c = atomicAdd(R->chunk_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
                 if (c >= (unsigned int)R->n_chunks) {
                     chunk_left = -1;
-                    if (lane == 0 && R->dbg) dbg_stamp[3] = __builtin_amdgcn_s_memrealtime();      // the queue ran dry (trace)
+                    if (fresh_lane(lane) == 0 && R->dbg) dbg_stamp[3] = __builtin_amdgcn_s_memrealtime();      // the queue ran dry (trace)
                     break;
                 }
-                if (lane == 0 && R->dbg && c < (unsigned int)R->dbg_chunks)                      // trace: when chunk c was pulled
+                if (fresh_lane(lane) == 0 && R->dbg && c < (unsigned int)R->dbg_chunks)                      // trace: when chunk c was pulled
                     R->dbg[8ll * R->dbg_waves + c] = __builtin_amdgcn_s_memrealtime();
                 chunk_set = (int)c * R->sets_per_chunk;
                 const long long left = R->B - (long long)chunk_set;
@@ -519,22 +545,22 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             const int prow = TPS == 1 ? chunk_set : chunk_set / TPS;
             const int qt = chunk_set - prow * TPS;                       // tile within the set (0 when not tiled)
             uint32_t rec = pre;
-            if (!have_pre) rec = lane < REC ? R->recs[(long long)prow * REC + lane] : 0u;
+            if (!have_pre) rec = fresh_lane(lane) < REC ? R->recs[(long long)prow * REC + lane] : 0u;
             if (chunk_left > 1) {                                        // prefetch the next tile's record
                 const int nrow = TPS == 1 ? chunk_set + 1 : (chunk_set + 1) / TPS;
-                if (nrow != prow) pre = lane < REC ? R->recs[(long long)nrow * REC + lane] : 0u;
+                if (nrow != prow) pre = fresh_lane(lane) < REC ? R->recs[(long long)nrow * REC + lane] : 0u;
                 else pre = rec;
             }
             const int sic = __builtin_amdgcn_readlane((int)rec, R_SET);  // the set's row in the caller's arrays
             const int vset = sic * TPS + qt;
             uint32_t *d = slot_rec(slot);
             if (lane < REC) d[lane] = rec;
+            // everything about the set is wave-uniform: scalar arithmetic
+            const unsigned long long gset = R->set_offset + (unsigned long long)sic;
+            const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
             if (lane == 0) {
                 d[D_VSET] = (uint32_t)vset;
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) { d[D_ZSUM] = 0u; d[D_ZSUM + 1] = 0u; d[D_ZSUM + 2] = 0u; d[D_ZSUM + 3] = 0u; }
-                // everything here is wave-uniform: scalar arithmetic
-                const unsigned long long gset = R->set_offset + (unsigned long long)sic;
-                const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
                 PathSet ps;
                 ps.init(s_lo, s_hi, R->k0, R->k1);              // stream 0: no tag bits in c2
                 d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
@@ -550,8 +576,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             chunk_set++; chunk_left--; tile_open++;
         }
     };
-    open_tiles();
-    __syncthreads();
 
     while (true) {
         // ------------------------------------------------------------ retire finished trials
@@ -581,21 +605,53 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 to_retire += N;
             }
             __syncthreads();
+        }
+        // ------------------------------------------------------------ open tiles (the one place: also the first pass,
+        // and the pass that finds the queue empty)
+        if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + fresh_args(Ak)->ring && chunk_left >= 0) {
             open_tiles();
             __syncthreads();
         }
         if (flushed == tile_open && chunk_left < 0) break;
         // ------------------------------------------------------------ hand out new trials
-        if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + ring && chunk_left >= 0) {
-            open_tiles();
-            __syncthreads();
-        }
         {
             const unsigned long long want_mask = ~has_m;
             int tr = next_trial + (int)lane_rank(want_mask);
             int tl = next_tile;
             while (tr >= N) { tr -= N; tl++; }
             const unsigned long long ok_mask = want_mask & __builtin_amdgcn_ballot_w64(tl < tile_open);
+            if constexpr (LATENT) {
+                const int n_ok = (int)__popcll(ok_mask);
+                if (n_ok > fifo_avail) {
+                    // not enough latents drawn ahead: draw those of the next 64 positions of the hand-out sequence (all
+                    // lanes; positions whose tile is not open yet are left for the next time -- the open ones are a
+                    // prefix, and they include every position this hand-out serves)
+                    int btr = next_trial + fifo_avail + lane, btl = next_tile;
+                    while (btr >= N) { btr -= N; btl++; }
+                    const unsigned long long bmask = __builtin_amdgcn_ballot_w64(btl < tile_open);
+                    if (__builtin_amdgcn_inverse_ballot_w64(bmask)) {
+                        const uint32_t bsb = __umul24((uint32_t)(btl & ring_mask), (uint32_t)stride) + kbase;
+                        const lds_u32v4 *const bq = reinterpret_cast<const lds_u32v4 *>(bsb + SLOTS_OFF);
+                        const u32v4 dA = bq[D_A / 4];
+                        [[maybe_unused]] const u32v4 dB = bq[D_B / 4];
+                        const u32v4 dS = bq[D_SIC / 4];                                  // .z = first trial of the tile
+                        const u32v2 sw = *reinterpret_cast<const lds_u32v2 *>(bsb + SLOTS_OFF + D_C3 * 4);   // c3, set_lo
+                        const uint32_t btrial = (uint32_t)btr + dS.z;
+                        float v;
+                        if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
+                            // A = Nu, 1/S, a/(2S), w0;  B = Eta: the trial's drift N(Nu, Eta) per step, in noise units
+                            AuxStream<FAST> aux(kbase, sw.y, sw.x, btrial);
+                            v = (__builtin_fmaf(__uint_as_float(dB.x), aux.normal(0), __uint_as_float(dA.x)) * fresh_args(Ak)->dt) * __uint_as_float(dA.y);
+                        } else {
+                            float z_unused;
+                            trial_latent<MODEL, FAST>(dA, dB, sw.y, sw.x, btrial, kbase, v, z_unused);
+                        }
+                        *reinterpret_cast<__attribute__((address_space(3))) float *>(
+                            kbase + FIFO_OFF + (((uint32_t)(fifo_pos + fifo_avail + lane) & (LATENT_FIFO - 1)) << 2)) = v;
+                    }
+                    fifo_avail += (int)__popcll(bmask);
+                }
+            }
             next_trial += (int)__popcll(ok_mask);
             while (next_trial >= N) { next_trial -= N; next_tile++; }
             has_m |= ok_mask;
@@ -613,38 +669,31 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const float a0 = __uint_as_float(d0.x), a1 = __uint_as_float(d0.y), a2 = __uint_as_float(d0.z),
                             a3 = __uint_as_float(d0.w);                  // the model's A constants (make_record)
                 const uint32_t trial = (uint32_t)tr + d2.z;          // index within the set (keys the random stream)
-                [[maybe_unused]] uint32_t set_lo = 0u, c3 = 0u;       // the auxiliary stream's set words
-                if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT || MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    const u32v2 sw = *reinterpret_cast<const lds_u32v2 *>(sb + SLOTS_OFF + D_C3 * 4);
-                    c3 = sw.x; set_lo = sw.y;
-                }
+                [[maybe_unused]] float latent = 0.0f;                 // the trial's latent, drawn ahead (FIFO)
+                if constexpr (LATENT)
+                    latent = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
+                        kbase + FIFO_OFF + (((uint32_t)fifo_pos + lane_rank(want_mask)) & (LATENT_FIFO - 1)) * 4u);
                 invalid = false;
                 if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
                     mu_dt = a0; h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
-                    const u32v4 d3 = rq[D_B / 4];
-                    float a, z_unused;
-                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, a, z_unused);      // per-trial boundary
+                    const float a = latent;                                         // per-trial boundary
                     const float hv = 0.5f * a;
                     mu_dt = a0;
                     h = hv * a1;
-                    w = (a * __uint_as_float(d3.z) - hv) * a1;
+                    w = (a * __uint_as_float(rw[D_B + 2]) - hv) * a1;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL_ALT) {
                     // A = drift, alpha, beta, std_dc;  B = mu_dc, sigma1, gamma
-                    const u32v4 d3 = rq[D_B / 4];
-                    float sig_c, z_unused;
-                    trial_latent<MODEL, FAST>(d0, d3, set_lo, c3, trial, kbase, sig_c, z_unused);  // per-trial noise scale
+                    const float sig_c = latent;                                     // per-trial noise scale
                     const float inv_t = 1.0f / noise_unit<FAST>(H->sqrt_dt * sig_c);
                     const float hv = 0.5f * a1;
                     mu_dt = (a0 * H->dt) * inv_t;
                     h = hv * inv_t;
                     w = (a1 * a2 - hv) * inv_t;
                 } else if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
-                    // A = Nu, 1/S, a/(2S), w0;  B = Eta
-                    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
-                    const float eta = __uint_as_float(rw[D_B]);
-                    mu_dt = (__builtin_fmaf(eta, aux.normal(0), a0) * H->dt) * a1;
+                    // A = Nu, 1/S, a/(2S), w0: the per-trial drift N(Nu, Eta) was drawn when the tile opened
+                    mu_dt = latent;
                     h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) {
                     // A = drift*dt/S, 1/S, beta
@@ -664,6 +713,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 k = 0;
                 jit = 0;
             }
+            if constexpr (LATENT) { const int n_ok = (int)__popcll(ok_mask); fifo_pos += n_ok; fifo_avail -= n_ok; }
             // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
             // are masked by has_m)
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
@@ -740,7 +790,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (it >= MAX_BLOCKS - 1 && A.refill_thresh < WAVE) break;
         }
         // one refill phase of `it + 1` blocks: a no-return 64-bit LDS add
-        if (lane == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it + 1));
+        if (fresh_lane(lane) == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it + 1));
     }
     // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
