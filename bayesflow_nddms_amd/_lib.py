@@ -29,6 +29,7 @@ def _declare(L):
     L.nddm_set_debug_trace.argtypes = [c.c_void_p, c.c_int, c.c_int]
     L.nddm_set_ordering.argtypes = [c.c_int]
     L.nddm_debug_set_slot_limit.argtypes = [c.c_int]
+    L.nddm_debug_last_launch.argtypes = [c.POINTER(c.c_int32)]
     common = [c.c_int64, c.c_int32, c.c_float, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32]
     for name in ("nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate", "nddm_single_trial_alt_simulate"):
         getattr(L, name).argtypes = [fp] + common + [fp, fp, vp]
@@ -48,7 +49,7 @@ EXPORTS = [
     "nddm_model_nparams", "nddm_basic_ddm_dc_simulate", "nddm_single_trial_simulate",
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
     "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_trace", "nddm_set_ordering",
-    "nddm_release_graph_memory", "nddm_debug_set_slot_limit",
+    "nddm_release_graph_memory", "nddm_debug_set_slot_limit", "nddm_debug_last_launch",
 ]
 
 

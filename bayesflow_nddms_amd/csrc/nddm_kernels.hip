@@ -65,7 +65,10 @@ static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // ---- process-wide state, all of it behind one mutex -------------------------------------------------------------------
 // Entry points are re-entrant: each call takes a SNAPSHOT of the developer knobs at entry and owns the device memory it is
 // handed (a LaunchSlot) until the work it enqueued has completed.
-struct Tuning { int sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order; };
+struct Tuning { int sets_per_chunk, ring, refill_thresh, variant, grid_waves, tile_trials, no_order; };
+// geometry of the calling thread's last launch (nddm_debug_last_launch)
+struct LastLaunch { int grid_waves, vkeys, ring, tile_trials, tiles_per_set, sets_per_chunk, refill_thresh, lds_bytes; };
+static thread_local LastLaunch g_last = {0, 0, 0, 0, 0, 0, 0, 0};
 static std::mutex g_mu;
 static Tuning g_tuning = {0, 0, 0, 0, 0, 0, 0};   // 0 = automatic (nddm_set_tuning overrides; benchmarking aid)
 static unsigned long long *g_dbg = nullptr;       // nddm_set_debug_trace (profiling aid)
@@ -253,6 +256,7 @@ static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_by
         int waves = resident_waves(KERNEL, lds_bytes, cus);                                    \
         if (grid_override > 0 && (grid_override < waves || grid_forced)) waves = grid_override;\
         if (waves > n_chunks) waves = n_chunks;                                                \
+        g_last.grid_waves = waves; g_last.vkeys = VKEYS ? 1 : 0;                               \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
     if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS>));
@@ -449,7 +453,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
     if (packed && A.res16 != 2) return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs tiles of <= 512 trials (tuning override?)%s");
     A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
-    A.max_blocks = tun.max_blocks ? tun.max_blocks : 16;
+    A.max_blocks = 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
     A.open_ahead = vB >= 4 * waves7 ? 1 : 0;
@@ -534,7 +538,11 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         // round keys in VGPRs (no LDS round trips in the step loop) whenever part of the launch runs on SIMDs that are not
         // full: a cut grid, fewer chunks than waves, or a launch short enough that its tail matters (measured at dt=.001:
         // 20k sets x 300 trials 32 % faster, 50k 8 %, 100k equal, 300k 2 % slower)
-        const bool vkeys = plan_waves < 8ll * simds || n_chunks < 8ll * simds || est_blocks < 2.0e4 * (double)simds;
+        bool vkeys = plan_waves < 8ll * simds || n_chunks < 8ll * simds || est_blocks < 2.0e4 * (double)simds;
+        if (tun.variant % 3 == 1) vkeys = false;                         // developer knob: 1 LDS keys, 2 VGPR keys, else the rule
+        else if (tun.variant % 3 == 2) vkeys = true;
+        g_last.ring = ring; g_last.tile_trials = tile_n; g_last.tiles_per_set = tiles; g_last.sets_per_chunk = spc;
+        g_last.refill_thresh = A.refill_thresh; g_last.lds_bytes = (int)lds;
         switch (model) {
         case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
@@ -596,12 +604,12 @@ int nddm_set_device(int device)
 }
 
 /* benchmarking aid (not part of the drop-in surface): 0 = automatic */
-int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int max_blocks, int grid_waves, int tile_trials)
+int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int variant, int grid_waves, int tile_trials)
 {
     if (ring && (ring & (ring - 1))) return nddm::fail(NDDM_ERR_PARAM, "ring must be a power of two%s");
     std::lock_guard<std::mutex> lock(nddm::g_mu);
     const int no_order = nddm::g_tuning.no_order;
-    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, max_blocks, grid_waves, tile_trials, no_order};
+    nddm::g_tuning = {sets_per_chunk, ring, refill_thresh, variant < 0 ? 0 : variant, grid_waves, tile_trials, no_order};
     return NDDM_OK;
 }
 
@@ -625,6 +633,17 @@ int nddm_set_debug_trace(void *dev_u64, int wave_capacity, int chunk_capacity)
     nddm::g_dbg = static_cast<unsigned long long *>(dev_u64);
     nddm::g_dbg_waves = dev_u64 ? wave_capacity : 0;
     nddm::g_dbg_chunks = dev_u64 ? chunk_capacity : 0;
+    return NDDM_OK;
+}
+
+/* developer aid: geometry of the calling thread's last simulator launch: out[8] = {grid waves, 1 if the VGPR-keys kernel
+ * variant ran, ring slots, trials per tile, tiles per set, sets per chunk, refill threshold, dynamic LDS bytes} */
+int nddm_debug_last_launch(int32_t *out8)
+{
+    if (!out8) return nddm::fail(NDDM_ERR_NULL, "out8 is NULL%s");
+    const nddm::LastLaunch &l = nddm::g_last;
+    out8[0] = l.grid_waves; out8[1] = l.vkeys; out8[2] = l.ring; out8[3] = l.tile_trials; out8[4] = l.tiles_per_set;
+    out8[5] = l.sets_per_chunk; out8[6] = l.refill_thresh; out8[7] = l.lds_bytes;
     return NDDM_OK;
 }
 

@@ -255,3 +255,12 @@ class debug_trace:
         pulls = d[8 * self.waves:]
         return {"blocks": float(rec[:, 0].sum()), "refills": float(rec[:, 1].sum()), "cycles": float(rec[:, 2].sum()),
                 "ticks": float(rec[:, 3].sum()), "waves": int(rec.shape[0]), "records": rec, "pulls": pulls[pulls > 0]}
+
+
+def last_launch():
+    """Developer aid: geometry of this thread's last simulator launch (include/nddm.h: nddm_debug_last_launch)."""
+    import ctypes
+    out = (ctypes.c_int32 * 8)()
+    _lib.check(_lib.lib().nddm_debug_last_launch(out))
+    keys = ("grid_waves", "vgpr_keys", "ring", "tile_trials", "tiles_per_set", "sets_per_chunk", "refill_thresh", "lds_bytes")
+    return dict(zip(keys, (int(v) for v in out)))

@@ -263,17 +263,19 @@ def em_steps_of(summary, tau, dt, max_k, bridge):
     return float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
 
 
-def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed):
-    """The step loop with every lane useful: the SAME kernel on a workload whose trials all run to the step cap
-    (no refill, no idle lanes, same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane
-    efficiency it was measured at (executed-block counter of the kernel)."""
+def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry):
+    """The step loop with every lane useful: the SAME kernel (variant and grid of the timed launch: `geometry` =
+    engine.last_launch() after a timed step) on a workload whose trials all run to the step cap (no refill, no idle lanes,
+    same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane efficiency it was measured at
+    (executed-block counter of the kernel)."""
     max_k = engine.max_k_of(a.max_steps)
     N = a.trials
     B = int(max(2048, min(400_000, 4.8e10 / (N * max_k))))
     p = torch.tensor([LOCKSTEP_ROW[a.model]] * B, dtype=torch.float32, device=dev)
     summ = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
     L = _lib.lib()
-    _lib.check(L.nddm_set_tuning(1, 0, 64, 64, 0, 0))          # never leave the loop early: refill only when all lanes are done
+    # never leave the loop early (refill only when all lanes are done); the timed launch's kernel variant and grid
+    _lib.check(L.nddm_set_tuning(1, 0, 64, 2 if geometry["vgpr_keys"] else 1, geometry["grid_waves"], 0))
     try:
         run = lambda: engine.simulate(model_id, p, N, dt=a.dt, max_steps=a.max_steps, seed=7, set_offset=0, fast=fast,
                                       out_summary=summ, want_trials=False, bridge=bridge, packed=packed)
@@ -294,7 +296,7 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed)
     lane_eff = steps / (blocks * 64.0 * (8 if packed else 4))
     sps = steps / (best * 1e-3)
     return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
-            "kernel_ms": best, "clock_ghz_in_kernel": clock,
+            "kernel_ms": best, "clock_ghz_in_kernel": clock, "launch": engine.last_launch(),
             "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
 
 
@@ -384,6 +386,7 @@ def simulate_bench(a, ctx):
         ev[i][1].record()
     barrier(a, ctx)
     elapsed = time.perf_counter() - t0
+    geometry = engine.last_launch()          # the timed launches' kernel variant, grid, ring, tiles (outside the timed region)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,6 +420,7 @@ def simulate_bench(a, ctx):
                      "kernel": KERNEL_NAME[a.model] % a.gauss,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "path is VALU-bound, not HBM- or MFMA-bound: see roofline_valu"},
+        "launch": geometry,
         "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
         "p_missing": p_missing,
     }
@@ -430,13 +434,13 @@ def simulate_bench(a, ctx):
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
         spb = 8 if packed else 4                     # Euler-Maruyama steps per Philox block
         if not a.no_ceiling:
-            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed)
+            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry)
             peak = c["steps_per_s_all_lanes_useful"]
             rv.update({"peak": peak / 1e9, "frac": achieved_steps / peak,
                        "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
                        "ceiling_measured_steps_per_s": c["steps_per_s"], "ceiling_lane_efficiency": c["lane_efficiency"],
                        "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"],
-                       "ceiling_clock_ghz_in_kernel": c["clock_ghz_in_kernel"],
+                       "ceiling_clock_ghz_in_kernel": c["clock_ghz_in_kernel"], "ceiling_launch": c["launch"],
                        "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 64.0 * spb / peak, "steps_per_block": spb})
         im = issue_model(a.model, a.gauss)
         if im:

@@ -106,6 +106,10 @@ int nddm_release_graph_memory(void);
 /* testing aid (not part of the drop-in surface): cap the number of launch slots per device, so that a test can drive the
  * library into queueing a launch behind an in-flight one */
 int nddm_debug_set_slot_limit(int n);
+/* developer aid: geometry of the calling thread's last simulator launch, out[8] = {grid waves, 1 if the kernel variant with
+ * the Philox round keys in VGPRs ran, ring slots, trials per tile, tiles per set, sets per chunk, refill threshold, dynamic
+ * LDS bytes}.  bench.py uses it to run its lockstep ceiling on the same kernel variant and grid as the timed workload. */
+int nddm_debug_last_launch(int32_t *out8);
 
 /* ---- simulators --------------------------------------------------------------------
  * Common arguments:

@@ -399,3 +399,31 @@ def test_wide_step_cap_uses_32bit_staging(model):
     assert np.array_equal(g["trials"].view(np.uint32), o["trials"].view(np.uint32))
     assert np.array_equal(np.nan_to_num(g["summary"]).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
     assert o["k"].max() > 16383            # the case does exercise step indices beyond 14 bits
+
+
+@pytest.mark.parametrize("model", [0, 1, 3])
+def test_debug_trace_records_and_leaves_results_alone(model):
+    """nddm_set_debug_trace (engine.debug_trace): every wave of the launch leaves one record, the pull stamps cover the
+    queue, the counters are consistent with the work -- and the traced launch returns the same bits as an untraced one."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N = 3000, 100
+    p = {0: prior_util.basic_prior, 1: prior_util.single_prior, 3: prior_util.alpha_ns_prior}[model](B, 5)
+    p_dev = torch.as_tensor(p).cuda()
+    kw = dict(dt=0.01, max_steps=400, seed=11, set_offset=7, fast=True)
+    ref = engine.simulate(model, p_dev, N, **kw)
+    with engine.debug_trace(waves=16384, chunks=1 << 16) as tr:
+        got = engine.simulate(model, p_dev, N, **kw)
+    t = tr.read()
+    assert torch.equal(torch.nan_to_num(got["trials"]), torch.nan_to_num(ref["trials"]))
+    assert torch.equal(torch.nan_to_num(got["summary"]), torch.nan_to_num(ref["summary"]))
+    rec = t["records"]
+    assert t["waves"] >= 1 and rec.shape == (t["waves"], 8)
+    assert (rec[:, 6] > rec[:, 4]).all() and (rec[:, 5] >= rec[:, 4]).all() and (rec[:, 5] <= rec[:, 6]).all()   # start < dry <= end
+    s = got["summary"].cpu().numpy()
+    steps_lower_bound = float(s[:, 2].sum()) * 400.0                   # the trials that ran to the cap alone
+    assert t["blocks"] * 64 * 4 >= B * N + steps_lower_bound           # every trial takes at least one step
+    assert t["refills"] >= t["waves"]
+    assert len(t["pulls"]) >= 1 and t["pulls"].min() >= rec[:, 4].min() and t["pulls"].max() <= rec[:, 6].max()
+    after = engine.simulate(model, p_dev, N, **kw)                     # the trace is off again
+    assert torch.equal(torch.nan_to_num(after["trials"]), torch.nan_to_num(ref["trials"]))

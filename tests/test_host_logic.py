@@ -46,6 +46,8 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.nddm_basic_ddm_dc_simulate(dummy, 2**30, 100000, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
     assert b"< 2^31" in L.nddm_last_error()
     assert L.nddm_basic_ddm_dc_simulate(dummy, 0, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_OK  # empty batch
+    assert L.nddm_set_debug_trace(dummy, -1, 0) == _lib.NDDM_ERR_PARAM                                         # developer aids
+    assert L.nddm_set_debug_trace(None, 0, 0) == _lib.NDDM_OK
     with pytest.raises(ValueError):
         _lib.check(_lib.NDDM_ERR_SHAPE)
     with pytest.raises(RuntimeError):

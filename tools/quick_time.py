@@ -22,7 +22,7 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
     p = {0: prior_util.basic_prior, 1: prior_util.single_prior, 3: prior_util.alpha_ns_prior}[model](B, 2023)
     if lockstep:   # every trial runs to the cap: all lanes busy, no refill -> pure step-loop cost
         p[:] = np.array(LOCK[model], dtype=np.float32)
-        tune = tune or (1, 0, 64, 64, 0, 0)
+        tune = tune or (1, 0, 64, 1, 32 * torch.cuda.get_device_properties(0).multi_processor_count, 0)   # LDS-keys variant, full grid
     pd = torch.as_tensor(p).cuda()
     if tune:
         _lib.check(_lib.lib().nddm_set_tuning(*tune))

@@ -1,5 +1,5 @@
 """Developer aid: when do the simulator's waves start and end?  Runs one launch with the per-wave (start, end) trace of
-nddm_set_debug_counters switched on and prints how many waves are alive over the kernel's duration (twentieths), the
+nddm_set_debug_trace switched on and prints how many waves are alive over the kernel's duration (twentieths), the
 spread of start and end times, and the share of wave-slot time that is empty at the head and at the tail.
 
 usage: python tools/wave_timeline.py [model:B:N:dt:max_steps[:packed] ...]   (default: the headline shape at both step sizes)"""
