@@ -502,10 +502,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
     int to_retire = N;                            // the oldest tile cannot be complete before this many more trials retire
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
-    // debug counters live in LDS (SGPRs are scarce): dbg_stamp[2] = refill phases << 32 | step-loop blocks
-    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks
+    // trace counters: two wave-uniform integers (scalar adds; as an LDS counter bumped by lane 0 they were 7 of the ~36
+    // VALU instructions of every refill), and the start / queue-dry stamps in LDS
+    uint32_t dbg_blocks = 0, dbg_refills = 0;
+    unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks, [3]: dry
     if (lane == 0) {
-        dbg_stamp[2] = 0; dbg_stamp[3] = 0;
+        dbg_stamp[3] = 0;
         lds_raw[31] = blockIdx.x;             // read back at exit (kept in LDS: an SGPR held through the kernel costs residency)
         if (Ak->dbg) { dbg_stamp[0] = __builtin_amdgcn_s_memtime(); dbg_stamp[1] = __builtin_amdgcn_s_memrealtime(); }
     }
@@ -789,8 +791,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
             if (it >= MAX_BLOCKS - 1 && A.refill_thresh < WAVE) break;
         }
-        // one refill phase of `it + 1` blocks: a no-return 64-bit LDS add
-        if (fresh_lane(lane) == 0) atomicAdd(dbg_stamp + 2, (1ull << 32) | (unsigned long long)(it + 1));
+        // one refill phase of `it + 1` blocks
+        dbg_blocks += (uint32_t)(it + 1); dbg_refills++;
     }
     // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t wg = lds_raw[31];
         if (wg < (uint32_t)fresh_args(Ak)->dbg_waves) {
             unsigned long long *const r = dbg + 8ull * wg;
-            r[0] = dbg_stamp[2] & 0xffffffffull; r[1] = dbg_stamp[2] >> 32;
+            r[0] = dbg_blocks; r[1] = dbg_refills;
             r[2] = c_end - dbg_stamp[0]; r[3] = t_end - dbg_stamp[1];
             r[4] = dbg_stamp[1]; r[5] = dbg_stamp[3]; r[6] = t_end; r[7] = 1ull;
         }

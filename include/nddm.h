@@ -110,6 +110,18 @@ int nddm_debug_set_slot_limit(int n);
  * the Philox round keys in VGPRs ran, ring slots, trials per tile, tiles per set, sets per chunk, refill threshold, dynamic
  * LDS bytes}.  bench.py uses it to run its lockstep ceiling on the same kernel variant and grid as the timed workload. */
 int nddm_debug_last_launch(int32_t *out8);
+/* developer knobs of the launch geometry (0 = the library's rule): sets per queue chunk, ring slots (a power of two),
+ * refill threshold (lanes holding a finished trial; >= 64 = refill only when no lane is stepping), kernel variant (1 =
+ * Philox round keys from LDS, 2 = in VGPRs, taken modulo 3), grid in waves, trials per tile.  Results never depend on
+ * them (tests/test_gpu_fuzz.py randomises all six). */
+int nddm_set_tuning(int sets_per_chunk, int ring, int refill_thresh, int variant, int grid_waves, int tile_trials);
+/* 0 switches the longest-first ordering pre-pass off (sets are processed in the given order) */
+int nddm_set_ordering(int enabled);
+/* profiling aid: while set, every wave of the simulator kernels stores -- plain stores, no atomics -- one 8-word record
+ * at buf[8 w ..], w = workgroup < wave_capacity: {step-loop blocks, refill phases, s_memtime cycles, lifetime, start, "found
+ * the queue empty", end in s_memrealtime ticks (100 MHz), 1}; and the tick at which chunk c < chunk_capacity was pulled
+ * at buf[8 wave_capacity + c].  buf: device u64 [8 wave_capacity + chunk_capacity], zeroed by the caller; NULL = off. */
+int nddm_set_debug_trace(void *dev_u64, int wave_capacity, int chunk_capacity);
 
 /* ---- simulators --------------------------------------------------------------------
  * Common arguments:

@@ -79,8 +79,12 @@ if __name__ == "__main__":
     run(B, 300, 0.001, 4000, model=3)
     run(B, 300, 0.001, 4000, model=3, bridge=True)
     run(B, 60, 0.001, 4000)
-    for b in (3000000, 300000, 100000, 30000, 10000, 1000):
+    for b in (3000000, 300000, 100000, 50000, 30000, 20000, 10000, 5000, 3000, 1000):
         run(b, 300, 0.001, 4000)
+    for b in (300000, 100000, 30000, 10000, 3000, 1000):
+        run(b, 300, 0.01, 400)
+    run(100000, 60, 0.01, 400)
+    run(32, 180, 0.01, 400); run(32, 180, 0.001, 4000); run(256, 180, 0.01, 400)
     run(40000, 300, 0.001, 4000, lockstep=True)     # every lane busy: pure step-loop cost
     run(400000, 300, 0.01, 400, lockstep=True)
     run(40000, 300, 0.001, 4000, lockstep=True, model=1)
