@@ -334,11 +334,11 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     const long long set_in_call = TPS == 1 ? vset : vset / TPS;
     const int t0 = TPS == 1 ? 0 : (int)(vset - set_in_call * TPS) * N;      // first trial of this tile
     const int n_here = (Ap->n_total - t0) < N ? (Ap->n_total - t0) : N;           // the last tile may be padded
-    uint32_t cnt3 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL
+    uint32_t cnt2 = 0, sk32 = 0, sk2_32 = 0, sk_up32 = 0, sk2_up32 = 0;           // SMALL (cnt2: upper | responded << 10)
     int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
     float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
-    for (int j = lane; j < n_here; j += WAVE) {
+    for (uint32_t j = (uint32_t)lane; j < (uint32_t)n_here; j += WAVE) {   // (unsigned: scalar base + 32-bit lane offset)
         uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
         if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
             const uint32_t v = static_cast<const uint16_t *>(res)[j];
@@ -362,15 +362,17 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
                 o.y = out ? Ap->bounds[set_in_call * Ap->n_total + t0 + j] : 0.0f;       // the boundary that was given
             }
         }
-        if (code == 3u) o.x = __builtin_nanf("");
+        if constexpr (MODEL == NDDM_EXPLICIT_BOUNDARY) { if (code == 3u) o.x = __builtin_nanf(""); }   // only this model has invalid trials
         if (out) out[j] = o;
         if (Ap->out_summary) {
             if constexpr (SMALL) {
-                const uint32_t kk = k * k;                                           // < 2^28
-                const bool up = code == 1u, resp = up || code == 2u;
-                cnt3 += up ? 1u : (code == 2u ? (1u << 10) : (1u << 20));
-                sk32 += resp ? k : 0u; sk2_32 += resp ? kk : 0u;
-                sk_up32 += up ? k : 0u; sk2_up32 += up ? kk : 0u;
+                // 0 / 1 flags as bit `code` of a constant (v_bfe_u32), sums by 24-bit multiply-adds (k < 2^14): 10
+                // instructions where compares and selects took 14.  A code-3 (invalid) trial counts as missing.
+                const uint32_t up01 = __builtin_amdgcn_ubfe(0x2u, code, 1u), resp01 = __builtin_amdgcn_ubfe(0x6u, code, 1u);
+                const uint32_t kr = __umul24(k, resp01), ku = __umul24(k, up01);
+                cnt2 += up01 | (resp01 << 10);
+                sk32 += kr; sk_up32 += ku;
+                sk2_32 = __umul24(kr, k) + sk2_32; sk2_up32 = __umul24(ku, k) + sk2_up32;
             } else {
                 const unsigned long long kk = (unsigned long long)k * k;
                 if (code == 1u) { n_up++; sk += k; sk2 += kk; sk_up += k; sk2_up += kk; }
@@ -387,13 +389,14 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
             atomicAdd(zsum + 1, (unsigned long long)acc_zz);
         }
         if constexpr (SMALL) {
-            cnt3 = wave_sum_dpp(cnt3);
+            cnt2 = wave_sum_dpp(cnt2);
             sk32 = wave_sum_dpp(sk32); sk_up32 = wave_sum_dpp(sk_up32);
             const uint32_t a_hi = wave_sum_dpp(sk2_32 >> 16), a_lo = wave_sum_dpp(sk2_32 & 0xffffu);
             const uint32_t u_hi = wave_sum_dpp(sk2_up32 >> 16), u_lo = wave_sum_dpp(sk2_up32 & 0xffffu);
             if (fresh_lane(lane) == WAVE - 1) {              // the DPP reductions leave the totals in the last lane
-                q[0] = (unsigned long long)(cnt3 & 1023u) | ((unsigned long long)((cnt3 >> 10) & 1023u) << 21) |
-                       ((unsigned long long)(cnt3 >> 20) << 42);
+                const uint32_t n_up = cnt2 & 1023u, n_resp = cnt2 >> 10;              // <= 512 each
+                q[0] = (unsigned long long)n_up | ((unsigned long long)(n_resp - n_up) << 21) |
+                       ((unsigned long long)((uint32_t)n_here - n_resp) << 42);
                 q[1] = sk32; q[2] = ((unsigned long long)a_hi << 16) + a_lo;
                 q[3] = sk_up32; q[4] = ((unsigned long long)u_hi << 16) + u_lo;
                 if constexpr (ZSUM) { q[5] = zsum[0]; q[6] = zsum[1]; }
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
     // trace counters: two wave-uniform integers (scalar adds; as an LDS counter bumped by lane 0 they were 7 of the ~36
     // VALU instructions of every refill), and the start / queue-dry stamps in LDS
-    uint32_t dbg_blocks = 0, dbg_refills = 0;
+    unsigned long long dbg_cnt = 0;              // refill phases << 32 | step-loop blocks
     unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks, [3]: dry
     if (lane == 0) {
         dbg_stamp[3] = 0;
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         // MAX_BLOCKS blocks (so that a few finished lanes never wait long for company; a threshold >= 64 -- the lockstep
         // measurement -- switches that exit off)
         constexpr int MAX_BLOCKS = 16;
+        const int it_limit = A.refill_thresh < WAVE ? MAX_BLOCKS - 1 : 0x7fffffff;      // (one integer, not a lane-mask pair)
         int it = 0;
         for (;; ++it) {
             bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
@@ -789,10 +793,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
-            if (it >= MAX_BLOCKS - 1 && A.refill_thresh < WAVE) break;
+            if (it >= it_limit) break;
         }
         // one refill phase of `it + 1` blocks
-        dbg_blocks += (uint32_t)(it + 1); dbg_refills++;
+        dbg_cnt += (1ull << 32) | (unsigned long long)(uint32_t)(it + 1);
     }
     // the queue resets itself: every wave has finished pulling chunks before it counts itself out (its pulls returned
     // values it waited for), so when the last one arrives nobody will touch the words again in this launch.  No memset
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const uint32_t wg = lds_raw[31];
         if (wg < (uint32_t)fresh_args(Ak)->dbg_waves) {
             unsigned long long *const r = dbg + 8ull * wg;
-            r[0] = dbg_blocks; r[1] = dbg_refills;
+            r[0] = dbg_cnt & 0xffffffffull; r[1] = dbg_cnt >> 32;
             r[2] = c_end - dbg_stamp[0]; r[3] = t_end - dbg_stamp[1];
             r[4] = dbg_stamp[1]; r[5] = dbg_stamp[3]; r[6] = t_end; r[7] = 1ull;
         }
