@@ -427,3 +427,32 @@ def test_debug_trace_records_and_leaves_results_alone(model):
     assert len(t["pulls"]) >= 1 and t["pulls"].min() >= rec[:, 4].min() and t["pulls"].max() <= rec[:, 6].max()
     after = engine.simulate(model, p_dev, N, **kw)                     # the trace is off again
     assert torch.equal(torch.nan_to_num(after["trials"]), torch.nan_to_num(ref["trials"]))
+
+
+def test_kernel_variants_and_geometry_do_not_change_results():
+    """The two Philox-key variants of the kernel (round keys from LDS / in VGPRs), forced through the variant knob, and a
+    forced grid return the same bits as the library's own choice; nddm_debug_last_launch reports what ran."""
+    import torch
+    from bayesflow_nddms_amd import _lib, engine
+    B, N = 5000, 150
+    p_dev = torch.as_tensor(prior_util.basic_prior(B, 21)).cuda()
+    kw = dict(dt=0.001, max_steps=4000, seed=5, set_offset=99, fast=True)
+    ref = engine.simulate(engine.BASIC_DDM_DC, p_dev, N, **kw)
+    auto = engine.last_launch()
+    assert auto["grid_waves"] >= 1 and auto["ring"] in (2, 4, 8, 16, 32, 64) and auto["tile_trials"] * auto["tiles_per_set"] >= N
+    assert auto["vgpr_keys"] == 1                                       # a launch this small runs the VGPR-keys variant
+    seen = set()
+    try:
+        for variant, grid in ((1, 0), (2, 0), (1, 777), (2, 8192)):
+            _lib.check(_lib.lib().nddm_set_tuning(0, 0, 0, variant, grid, 0))
+            got = engine.simulate(engine.BASIC_DDM_DC, p_dev, N, **kw)
+            ll = engine.last_launch()
+            seen.add(ll["vgpr_keys"])
+            assert ll["vgpr_keys"] == variant - 1
+            if grid:
+                assert ll["grid_waves"] == min(grid, (B * ll["tiles_per_set"] + ll["sets_per_chunk"] - 1) // ll["sets_per_chunk"])
+            assert torch.equal(got["trials"], ref["trials"])
+            assert torch.equal(torch.nan_to_num(got["summary"]), torch.nan_to_num(ref["summary"]))
+    finally:
+        _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
+    assert seen == {0, 1}
