@@ -443,16 +443,15 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (lds_of(ring) > 60 * 1024)
         return fail(NDDM_ERR_SHAPE, "tile too large for the LDS ring (tuning override?)%s");
     A.sets_per_chunk = spc; A.ring = ring;
-    // refill threshold: a refill costs ~170 issue cycles whatever the number of lanes it serves, a waiting lane wastes
-    // its share of every block; with lambda completions per block the optimum is ~sqrt(61 lambda) finished lanes:
-    // 8 when trials last ~64 blocks (dt=.001, cap 4000), ~16-24 when they last ~7 (the reference default dt=.01, cap
-    // 400).  The cap is the only hint the host has about trial length.
-    // refill when this many lanes hold a finished trial: 8, or 16 where a refill is dearer relative to the stepping
-    // between two refills (short trials; models whose hand-out draws per-trial auxiliary normals) -- measured +2..5 %
-    const bool aux_handout = model == NDDM_SINGLE_TRIAL || model == NDDM_SINGLE_TRIAL_ALT || model == NDDM_ALPHA_NOT_SCALED;
+    // refill threshold: a refill costs ~27 VALU instructions whatever the number of lanes it serves, a waiting lane
+    // wastes its share of every block; with lambda completions per block the optimum is ~sqrt(c lambda) finished lanes:
+    // 8 when trials last ~64 blocks (dt=.001, cap 4000), 16 when they last ~7 (the reference default dt=.01, cap 400).
+    // The cap is the only hint the host has about trial length.  (The models that draw per-trial latents used to take 16
+    // at every cap; since their latents are drawn 64 at a time their refill costs what the basic model's does, and 8 is
+    // measured 0.4 / 2 / 3.3 % faster for single_trial / alpha_not_scaled / + bridge at dt=.001.)
     A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
     if (packed && A.res16 != 2) return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs tiles of <= 512 trials (tuning override?)%s");
-    A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : ((max_steps <= 1000 || aux_handout) ? 16 : 8);
+    A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : (max_steps <= 1000 ? 16 : 8);
     A.max_blocks = 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
