@@ -488,7 +488,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     int k = 0;
     uint32_t jit = 0;
     uint32_t res_addr = 0;   // LDS byte address (relative to the slots) of the trial's staged result
-    int tile = 0;            // wave-local sequence number of the tile this lane works on
+    [[maybe_unused]] int tile = 0;   // !SMALL only: wave-local sequence number of the tile this lane works on
     bool invalid = false;
     // which lanes hold a trial / are still stepping: wave-uniform lane masks kept in SGPRs (a per-lane bool that is
     // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
@@ -602,7 +602,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 // the oldest tile is complete when all its trials have been handed out and no lane holds one of them
                 // (no per-tile counter: the hand-out is sequential, so these two wave-uniform facts say it all)
                 if (next_tile <= flushed) break;
-                if (__builtin_amdgcn_ballot_w64(tile == flushed) & has_m) break;
+                // (a lane holds a trial of this tile iff its result address lies in the tile's slot: slots are not reused
+                // before their tile is flushed)
+                if constexpr (SMALL) {
+                    const uint32_t fsb = __umul24((uint32_t)(flushed & ring_mask), (uint32_t)stride) + kbase;
+                    if (__builtin_amdgcn_ballot_w64(res_addr - fsb < (uint32_t)stride) & has_m) break;
+                } else {                     // (the general kernels keep the tile number per lane: fewer SGPRs there)
+                    if (__builtin_amdgcn_ballot_w64(tile == flushed) & has_m) break;
+                }
                 uint32_t *const d = slot_rec(flushed & ring_mask);
                 const int set_in_call = __builtin_amdgcn_readfirstlane((int)d[D_VSET]);
                 flush_set<MODEL, FAST, SMALL>(fresh_args(Ak), lane, (long long)set_in_call, d, d + DV, kbase);
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             has_m |= ok_mask;
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
                 const ArgsPtr H = fresh_args(Ak);
-                tile = tl;
+                if constexpr (!SMALL) tile = tl;
                 // LDS byte address of the slot (kbase holds the LDS base: one v_mad_u32_u24), of the trial's result word
                 const uint32_t sb = __umul24((uint32_t)(tl & ring_mask), (uint32_t)stride) + kbase;
                 res_addr = sb + ((uint32_t)tr << rshift);
