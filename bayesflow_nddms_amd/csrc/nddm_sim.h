@@ -314,7 +314,7 @@ __host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum
 // (trial_latent), the explicit boundary is re-read from the caller's array.  (Writing it when the trial is handed out
 // or retired instead made every 64-byte sector of the output a partial write, twice: WRITE_SIZE 1.93x the output.)
 // SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
-// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the three counters share one word (10 bits
+// Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the two counters share one word (10 bits
 // each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
 template <int MODEL, bool FAST, bool SMALL>
 __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, uint32_t *d, const void *res, uint32_t kbase)
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 
     // LDS carve-up.  Header (128 bytes): the ten Philox round-key pairs [0, 80) (philox4x32_10_path), debug stamps
     // [80, 104), the three round keys that fold into the per-trial constants [112, 124).  Then one ring slot per
-    // in-flight parameter set ("tile"): its DV-dword record (hand-out constants, counters, z sums), then the packed results
+    // in-flight parameter set ("tile"): its DV-dword record (hand-out constants, z sums), then the packed results
     if (lane < 10) { lds_raw[2 * lane] = A.k0 + (uint32_t)lane * 0x9E3779B9u; lds_raw[2 * lane + 1] = A.k1 + (uint32_t)lane * 0xBB67AE85u; }
     if (lane == 0) { lds_raw[28] = A.k0 + 2u * PHILOX_W0; lds_raw[29] = A.k1 + 2u * PHILOX_W1; lds_raw[30] = A.k0 + 3u * PHILOX_W0; }
     // LDS byte address of the key table in a VGPR (the low 32 bits of a flat LDS address are the LDS offset); the asm
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
     int to_retire = N;                            // the oldest tile cannot be complete before this many more trials retire
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
-    // trace counters: two wave-uniform integers (scalar adds; as an LDS counter bumped by lane 0 they were 7 of the ~36
+    // trace counters: one wave-uniform 64-bit integer (scalar adds; as an LDS counter bumped by lane 0 they were 7 of the ~36
     // VALU instructions of every refill), and the start / queue-dry stamps in LDS
     unsigned long long dbg_cnt = 0;              // refill phases << 32 | step-loop blocks
     unsigned long long *dbg_stamp = reinterpret_cast<unsigned long long *>(lds_raw + 20);   // [0], [1]: start clocks, [3]: dry
