@@ -738,7 +738,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const int it_limit = A.refill_thresh < WAVE ? MAX_BLOCKS - 1 : 0x7fffffff;      // (one integer, not a lane-mask pair)
         int it = 0;
         for (;; ++it) {
-            bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
+            [[maybe_unused]] bool active = (!BRIDGE && CAP4 && !PACKED) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
             // counter word 0 of the path stream = index of the block's first step (a multiple of NS: a lane only starts
             // a block after taking all NS steps of the previous one), so no shift is needed
             constexpr int NS = PACKED ? 8 : 4;
@@ -764,6 +764,31 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if constexpr (BRIDGE) {
                 const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);          // stream 3, same constant folding as the path stream
                 ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
+            }
+            if constexpr (!BRIDGE && CAP4 && !PACKED) {
+                // The four steps with the execution mask narrowed by the range compare itself (v_cmpx writes EXEC): fmac, add,
+                // k + 1, compare per step and not one scalar instruction in between.  As the compiler writes `if (active)` a
+                // step carries four (s_and_saveexec, s_cbranch_execz, s_and, s_or), and a SIMD issues one scalar instruction
+                // per ~4.2 cycles, only partly in the shadow of the vector ones (tools/ubench_salu).  Measured A/B on one box:
+                // +0.5 % at the headline, +1.4 % single_trial, +1.9 % alpha_not_scaled, +3 % at 60 trials per set, 0 at
+                // dt=.01 -- and -1.8 % in lockstep, where no lane ever leaves (the compare-to-EXEC dependency costs there
+                // what the scalar instructions cost elsewhere), -2 % with the 8-step packed layout, which keeps the C form.
+                // The lanes still in range afterwards are EXEC itself.  (EXEC is all ones here -- the step loop is
+                // wave-uniform code -- and is left so.)
+                unsigned long long still;
+#define NDDM_STEP(R, T) "v_fmac_f32 %[w], %[" R "], %[" T "]\n\tv_add_f32 %[w], %[mu], %[w]\n\tv_add_u32 %[k], 1, %[k]\n\tv_cmpx_lt_f32_e64 vcc, |%[w]|, %[h]\n\t"
+                asm volatile("s_mov_b64 exec, %[am]\n\t"
+                             NDDM_STEP("r0", "t0") NDDM_STEP("r0", "t1") NDDM_STEP("r1", "t2") NDDM_STEP("r1", "t3")
+                             "s_nop 1\n\ts_mov_b64 %[st], exec\n\ts_mov_b64 exec, -1"
+                             : [w] "+v"(w), [k] "+v"(k), [st] "=s"(still)
+                             : [am] "s"(act_m), [mu] "v"(mu_dt), [h] "v"(h), [r0] "v"(rr[0]), [r1] "v"(rr[2]),
+                               [t0] "v"(tt[0]), [t1] "v"(tt[1]), [t2] "v"(tt[2]), [t3] "v"(tt[3])
+                             : "vcc");
+#undef NDDM_STEP
+                act_m = still & __builtin_amdgcn_ballot_w64(k < A.max_k);      // (still is a subset of the lanes that stepped)
+                if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
+                if (it >= it_limit) break;
+                continue;
             }
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
