@@ -48,6 +48,11 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.nddm_basic_ddm_dc_simulate(dummy, 0, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_OK  # empty batch
     assert L.nddm_set_debug_trace(dummy, -1, 0) == _lib.NDDM_ERR_PARAM                                         # developer aids
     assert L.nddm_set_debug_trace(None, 0, 0) == _lib.NDDM_OK
+    assert L.nddm_debug_last_launch(None) == _lib.NDDM_ERR_NULL
+    geo = (ctypes.c_int32 * 8)()
+    assert L.nddm_debug_last_launch(geo) == _lib.NDDM_OK and list(geo) == [0] * 8      # nothing launched on this thread
+    assert L.nddm_set_tuning(0, 3, 0, 0, 0, 0) == _lib.NDDM_ERR_PARAM                   # ring must be a power of two
+    assert L.nddm_set_tuning(0, 0, 0, 0, 0, 0) == _lib.NDDM_OK
     with pytest.raises(ValueError):
         _lib.check(_lib.NDDM_ERR_SHAPE)
     with pytest.raises(RuntimeError):
