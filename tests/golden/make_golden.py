@@ -27,7 +27,10 @@ Outputs (all under tests/golden/):
                 explicit per-trial boundary): step-index histograms by choice + quantile tables of the external
                 datum, >= 4e5 reference trials per parameter set, both dt configurations
 
-Usage:  python tests/golden/make_golden.py [--kat] [--ks] [--variants] [--ratcliff] [--priors] [--procs 8]
+  ezdiff.npz    known answers of the EZ-diffusion estimator (simulations/Basic_DDM_simulations.py:131-158) on reference
+                choice-RT data
+
+Usage:  python tests/golden/make_golden.py [--kat] [--ks] [--variants] [--ratcliff] [--priors] [--ezdiff] [--procs 8]
 This only runs in the build container (it needs /root/reference); the GPU box
 only ever sees the .npz files.
 """
@@ -67,6 +70,8 @@ SLICES = {
     # alpha_not_scaled.py participant-level draws: seed + uniform draws (:63-72) and the fixed participant (:82-88)
     "alpha_ns_draws": ("alpha_not_scaled.py", 63, 72),
     "alpha_ns_fixed": ("alpha_not_scaled.py", 82, 88),
+    # EZ-diffusion estimator fed by the per-simulation summaries
+    "ezdiff": ("simulations/Basic_DDM_simulations.py", 131, 158),
 }
 
 
@@ -493,6 +498,30 @@ def make_ratcliff(procs, n_total=200_000, chunk=5000):
     print("ratcliff.npz written", time.time() - t0, "s")
 
 
+def make_ezdiff():
+    """Known answers of the reference's ezdiff() (simulations/Basic_DDM_simulations.py:131-158) on choice-RT data made by the
+    reference simulator: inputs (rt, correct with NaN for missing trials) and the three estimates, per case."""
+    import contextlib
+    import io
+    b = load_slice("basic_sim")
+    ez = load_slice("ezdiff")["ezdiff"]
+    out = {}
+    cases = [(BASIC_SETS[0], 0.01, 400.0, 400, 2023), (BASIC_SETS[1], 0.01, 400.0, 400, 7), (BASIC_SETS[3], 0.001, 4000.0, 150, 11),
+             (BASIC_SETS[6], 0.01, 400.0, 300, 5), (np.array([6.0, 1.0, 0.5, 0.3, 0.5]), 0.01, 400.0, 60, 3)]   # last: pc == 1
+    for ci, (p, dt, ms, n, seed) in enumerate(cases):
+        np.random.seed(seed)
+        rows = np.array([_basic_trial(b, p, dt, ms) for _ in range(n)])
+        rt, choice = rows[:, 0].copy(), rows[:, 1]
+        correct = np.where(choice == 1, 1.0, np.where(choice == -1, 0.0, np.nan))
+        rt[np.isnan(correct)] = np.nan
+        with contextlib.redirect_stdout(io.StringIO()):
+            est = np.array(ez(rt, correct), dtype=np.float64)
+        out[f"rt_{ci}"] = rt; out[f"correct_{ci}"] = correct; out[f"est_{ci}"] = est
+        print(f"ezdiff case {ci}: n={n} pc={np.nanmean(correct):.3f} -> {est}")
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "ezdiff.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--kat", action="store_true")
@@ -501,13 +530,16 @@ if __name__ == "__main__":
     ap.add_argument("--variants", action="store_true")
     ap.add_argument("--ratcliff", action="store_true")
     ap.add_argument("--mixture", action="store_true")
+    ap.add_argument("--ezdiff", action="store_true")
     ap.add_argument("--procs", type=int, default=8)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}; fixtures can only be regenerated in the build container")
-    everything = not (a.kat or a.priors or a.ks or a.variants or a.ratcliff or a.mixture)
+    everything = not (a.kat or a.priors or a.ks or a.variants or a.ratcliff or a.mixture or a.ezdiff)
     if a.kat or everything:
         make_kat()
+    if a.ezdiff or everything:
+        make_ezdiff()
     if a.priors or everything:
         make_priors()
     if a.ratcliff or everything:

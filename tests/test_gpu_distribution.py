@@ -431,3 +431,33 @@ def test_drop_in_api_on_device(kat):
     assert c.shape == (4, 50) and np.all(np.abs(c[c != 0]) > 0.3)
     with pytest.raises(ValueError):
         imputation.diffusion_trial(1.0, -0.5, .5, .3, 1.1)
+
+
+def test_ez_diffusion_from_fused_summaries_recovers_the_parameters():
+    """The fused summaries feed the EZ-diffusion estimator (simulations/Basic_DDM_simulations.py:131-158) without the
+    trials ever leaving the kernel: for unbiased starting points the closed form recovers (drift/dc, boundary/dc, tau).
+    Summary-only launch, 20000 trials per set; the estimates also agree with ezdiff() on the trials of the same launch."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    from bayesflow_nddms_amd import ezdiff as ez
+    p = np.array([[1.5, 1.2, 0.5, 0.35, 1.0], [3.0, 2.4, 0.5, 0.35, 2.0], [3.0, 1.2, 0.5, 0.35, 2.0], [1.5, 1.2, 0.5, 0.35, 0.5],
+                  [0.8, 1.6, 0.5, 0.20, 1.0]], dtype=np.float32)       # the sets of Basic_DDM_simulations.py:164-207 + one
+    N = 20000
+    r = engine.simulate(engine.BASIC_DDM_DC, p, N, dt=0.001, max_steps=4000, seed=31, set_offset=0, fast=True, want_trials=True)
+    est = ez.ez_from_summary(r["summary"])                              # on the device
+    assert isinstance(est, torch.Tensor) and est.shape == (5, 3)
+    est = est.cpu().numpy()
+    # in units of the diffusion coefficient (s = 1).  The estimator sees the DISCRETISED process: Euler-Maruyama detects a
+    # crossing late, which acts like a boundary wider by 0.5826 sqrt(dt) on either side (Siegmund's correction)
+    truth = np.stack([p[:, 0] / p[:, 4], p[:, 1] / p[:, 4] + 2 * 0.5826 * np.sqrt(0.001), p[:, 3]], axis=1)
+    assert np.allclose(est[:, 0], truth[:, 0], rtol=0.015), (est, truth)
+    assert np.allclose(est[:, 1], truth[:, 1], rtol=0.015), (est, truth)
+    assert np.allclose(est[:, 2], truth[:, 2], atol=0.01), (est, truth)
+    tr = r["trials"].cpu().numpy()
+    for b in range(5):
+        rt, ch = tr[b, :, 0].astype(np.float64), tr[b, :, 1]
+        correct = np.where(ch == 1, 1.0, np.where(ch == -1, 0.0, np.nan))
+        want = np.array(ez.ezdiff(np.where(np.isnan(correct), np.nan, rt), correct))
+        assert np.allclose(est[b], want, rtol=2e-4, atol=2e-5), (b, est[b], want)      # f32 summaries vs f64 from the trials
+    only = engine.simulate(engine.BASIC_DDM_DC, p, N, dt=0.001, max_steps=4000, seed=31, set_offset=0, fast=True, want_trials=False)
+    assert torch.equal(torch.nan_to_num(only["summary"]), torch.nan_to_num(r["summary"]))

@@ -228,3 +228,26 @@ def test_bench_launcher_without_gpu_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--sets", "10", "--steps", "1"],
                        capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
+
+
+def test_ezdiff_matches_reference_known_answers():
+    """bayesflow_nddms_amd.ezdiff.ezdiff against the reference's ezdiff() run on reference choice-RT data
+    (tests/golden/ezdiff.npz, made by make_golden.py --ezdiff), and the batched summary form against it."""
+    from bayesflow_nddms_amd import ezdiff as ez
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ezdiff.npz"))
+    for ci in range(int(g["n_cases"])):
+        rt, correct, want = g[f"rt_{ci}"], g[f"correct_{ci}"], g[f"est_{ci}"]
+        got = np.array(ez.ezdiff(rt, correct))
+        assert np.allclose(got, want, rtol=1e-12, atol=0), (ci, got, want)
+        # the same data as a fused summary row (upper = correct): counts, mean / variance of the correct RTs
+        hits = rt[correct == 1]
+        row = np.full(10, np.nan)
+        row[0], row[1], row[2] = (correct == 1).sum(), (correct == 0).sum(), np.isnan(correct).sum()
+        row[5], row[6] = hits.mean(), hits.var()
+        assert np.allclose(ez.ez_from_summary(row[None])[0], want, rtol=1e-9), ci
+    with pytest.raises(ValueError):
+        ez.ezdiff(np.array([0.5, 0.6]), np.array([0.0, 0.0]))              # no correct response
+    with pytest.raises(ValueError):
+        ez.ezdiff(np.array([0.5]), np.array([1.0, 1.0]))                   # length mismatch
+    bad = np.zeros((2, 10)); bad[1, 0] = 5; bad[1, 5] = 0.4                 # row 0: nothing; row 1: zero variance
+    assert np.isnan(ez.ez_from_summary(bad)).all()
