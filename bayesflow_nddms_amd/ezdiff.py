@@ -84,3 +84,11 @@ def ez_from_summary(summary, s=1.0):
         with np.errstate(all="ignore"):                  # undefined rows are NaN by design
             drift, boundary, ndt = _ez_core(pc, n_resp + n_miss, sm[..., _COL["mean_rt_upper"]], vrt, float(s), xp)
     return stack([drift, boundary, ndt])
+
+
+def accuracy_rt_moments(summary):
+    """``(mean_accuracy, mean_rt, var_rt)`` per parameter set from the fused ``summary_stats [B, 10]`` -- the three numbers
+    the reference's parameter sweeps plot (simulations/mean_RT_accuracy_effects.py:88-90: ``np.nanmean(correct)``,
+    ``np.nanmean(rts)``, ``np.nanvar(rts)``; missing trials are NaN there, i.e. excluded).  NumPy array or torch tensor."""
+    n_up, n_lo = summary[..., _COL["n_upper"]], summary[..., _COL["n_lower"]]
+    return n_up / (n_up + n_lo), summary[..., _COL["mean_rt"]], summary[..., _COL["var_rt"]]

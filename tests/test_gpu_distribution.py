@@ -459,5 +459,10 @@ def test_ez_diffusion_from_fused_summaries_recovers_the_parameters():
         correct = np.where(ch == 1, 1.0, np.where(ch == -1, 0.0, np.nan))
         want = np.array(ez.ezdiff(np.where(np.isnan(correct), np.nan, rt), correct))
         assert np.allclose(est[b], want, rtol=2e-4, atol=2e-5), (b, est[b], want)      # f32 summaries vs f64 from the trials
+    acc, mrt, vrt = (x.cpu().numpy() for x in ez.accuracy_rt_moments(r["summary"]))        # mean_RT_accuracy_effects.py:88-90
+    for b in range(5):
+        rt, ch = tr[b, :, 0].astype(np.float64), tr[b, :, 1]
+        resp = ch != 0
+        assert abs(acc[b] - (ch[resp] == 1).mean()) < 1e-6 and abs(mrt[b] - rt[resp].mean()) < 1e-5 and abs(vrt[b] - rt[resp].var()) < 1e-5
     only = engine.simulate(engine.BASIC_DDM_DC, p, N, dt=0.001, max_steps=4000, seed=31, set_offset=0, fast=True, want_trials=False)
     assert torch.equal(torch.nan_to_num(only["summary"]), torch.nan_to_num(r["summary"]))
