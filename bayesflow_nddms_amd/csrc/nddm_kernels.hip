@@ -393,8 +393,17 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     while (tile_cap < 512 && (long long)tile_cap * waves_for_tiles * 8 < total_trials) tile_cap <<= 1;
     int tiles = tun.tile_trials > 0 ? (n_trials + tun.tile_trials - 1) / tun.tile_trials
                                     : (n_trials <= tile_cap ? 1 : (n_trials + tile_cap - 1) / tile_cap);
-    const int tile_n = (n_trials + tiles - 1) / tiles;
+    int tile_n = (n_trials + tiles - 1) / tiles;
     tiles = (n_trials + tile_n - 1) / tile_n;
+    // Four ring slots must fit the LDS budget (4 granules of 1280 B, below): with two, a straggler in the older tile stalls
+    // the hand-out (sets are flushed in order).  Only the kernels that stage 32-bit results get here at 300 trials per set
+    // (the bridge: 2 x 300 gave lane efficiency 0.905, 4 x 150 gives 0.93 and +2.4 %): split their sets further.
+    if (!tun.ring && !tun.tile_trials)
+        while (tile_n > 96 && (size_t)lds_header_bytes(model) + 4u * (size_t)slot_stride_bytes(tile_n, (int)per_trial) > 5120u) {
+            tiles++;
+            tile_n = (n_trials + tiles - 1) / tiles;
+            tiles = (n_trials + tile_n - 1) / tile_n;
+        }
     const long long vB = B * (long long)tiles;
     if (vB >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
     if ((long long)tile_n * tiles >= (1ll << 30) || n_trials >= (1 << 30))
