@@ -52,7 +52,7 @@ struct SimArgs {
     int n_chunks;
     unsigned int *chunk_counter;   // device words [0] next chunk to hand out, [1] waves that have left; both are zero
                                    // between launches: the last wave to leave resets them
-    int ring;                 // LDS ring slots (power of two)
+    int ring;                 // LDS ring slots (any number >= 2: the slot of tile t is t mod ring)
     int open_ahead;           // tiles staged ahead of the one being handed out (0 when work is scarce, else 1)
     float ext_sigma;
     int ext_mode;
@@ -64,6 +64,7 @@ struct SimArgs {
     int res16;                // results are staged as 16-bit words (step index < 2^14 | code << 14): no bridge, cap < 16384;
                               // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
+    uint32_t ring_magic;      // floor(2^32 / ring): t mod ring by a multiply (ring_slot())
     int max_blocks;           // (unused by the kernels: the block limit is 16, switched off by refill_thresh >= 64)
 };
 
@@ -421,6 +422,15 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     }
 }
 
+// t mod ring for a wave-uniform tile number (t < 2^31): quotient estimate by the high product with floor(2^32 / ring), one
+// correction.  The ring need not be a power of two (six slots of 300 trials fit where eight do not).
+__device__ __forceinline__ int ring_slot(int t, int ring, uint32_t magic)
+{
+    const uint32_t q = (uint32_t)(((unsigned long long)(uint32_t)t * magic) >> 32);
+    int r = t - (int)(q * (uint32_t)ring);
+    return r >= ring ? r - ring : r;
+}
+
 // The evidence is carried CENTRED: w = x - a/2, h = a/2, so that (x > 0) && (x < a) is the single compare |w| < h
 // (v_cmp_lt_f32 with the |.| source modifier; false for NaN and for h == 0).
 __device__ __forceinline__ bool in_range(float w, float h)
@@ -454,7 +464,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     const ArgsPtr Ak = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x;
     const int N = A.n_trials;
-    const int ring_mask = A.ring - 1;       // (the ring size itself is read from the kernarg segment where it is needed)
 
     // LDS carve-up.  Header (128 bytes): the ten Philox round-key pairs [0, 80) (philox4x32_10_path), debug stamps
     // [80, 104), the three round keys that fold into the per-trial constants [112, 124).  Then one ring slot per
@@ -476,6 +485,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     const int stride = DV * 4 + (((N << rshift) + 15) & ~15);          // slot_stride_bytes()
     char *const slots = reinterpret_cast<char *>(lds_raw) + lds_header_bytes(MODEL);
     auto slot_rec = [&](int slot) { return reinterpret_cast<uint32_t *>(slots + slot * stride); };
+    auto pack_slots = [&](int t) {                                     // (rare path: kernarg reads, a multiply-high)
+        const ArgsPtr R = fresh_args(Ak);
+        const int s0 = ring_slot(t, R->ring, R->ring_magic);
+        const int o0 = s0 * stride, o01 = (s0 + 1 == R->ring ? 0 : s0 + 1) * stride - o0;
+        return (o0 & 0xffff) | (o01 << 16);                            // (slot offsets < 64 KB: the whole LDS footprint is)
+    };
     constexpr uint32_t SLOTS_OFF = lds_header_bytes(MODEL);            // byte offset of slot 0 from kbase
     constexpr uint32_t FIFO_OFF = LDS_HEADER_DWORDS * 4;               // ... of the latent FIFO (models with a latent)
     // latent FIFO: fifo_pos = hand-out sequence position of the wave's next trial (entry index = position mod LATENT_FIFO),
@@ -505,6 +520,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // (32-bit, compared modulo 2^32: SGPRs are what limits these kernels' residency)
     int to_retire = N;                            // the oldest tile cannot be complete before this many more trials retire
     int chunk_set = 0, chunk_left = 0;            // current chunk: next set index (in-call), sets left; -1: queue exhausted
+    // byte offset of the slot of the tile being handed out (next_tile) in the low half, and -- signed, in the high half -- the
+    // step from it to the next tile's slot: recomputed when next_tile moves, unpacked (two scalar ops) at every hand-out
+    int slot_pack = pack_slots(0);
+    int dirty = 1;                                // the tile counters changed since "open more tiles?" / "all done?" were evaluated
     // trace counters: one wave-uniform 64-bit integer (scalar adds; as an LDS counter bumped by lane 0 they were 7 of the ~36
     // VALU instructions of every refill), and the start / queue-dry stamps in LDS
     unsigned long long dbg_cnt = 0;              // refill phases << 32 | step-loop blocks
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 const long long left = R->B - (long long)chunk_set;
                 chunk_left = (int)(left < R->sets_per_chunk ? left : R->sets_per_chunk);
             }
-            const int slot = tile_open & ring_mask;
+            const int slot = ring_slot(tile_open, R->ring, R->ring_magic);
             // queue position -> queue row (position / tiles_per_set) -> its record
             const int TPS = R->tiles_per_set;
             const int prow = TPS == 1 ? chunk_set : chunk_set / TPS;
@@ -604,27 +623,34 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 if (next_tile <= flushed) break;
                 // (a lane holds a trial of this tile iff its result address lies in the tile's slot: slots are not reused
                 // before their tile is flushed)
+                const int fslot = ring_slot(flushed, fresh_args(Ak)->ring, fresh_args(Ak)->ring_magic);
                 if constexpr (SMALL) {
-                    const uint32_t fsb = __umul24((uint32_t)(flushed & ring_mask), (uint32_t)stride) + kbase;
+                    const uint32_t fsb = (uint32_t)(fslot * stride) + kbase;
                     if (__builtin_amdgcn_ballot_w64(res_addr - fsb < (uint32_t)stride) & has_m) break;
                 } else {                     // (the general kernels keep the tile number per lane: fewer SGPRs there)
                     if (__builtin_amdgcn_ballot_w64(tile == flushed) & has_m) break;
                 }
-                uint32_t *const d = slot_rec(flushed & ring_mask);
+                uint32_t *const d = slot_rec(fslot);
                 const int set_in_call = __builtin_amdgcn_readfirstlane((int)d[D_VSET]);
                 flush_set<MODEL, FAST, SMALL>(fresh_args(Ak), lane, (long long)set_in_call, d, d + DV, kbase);
                 flushed++;
                 to_retire += N;
+                dirty = 1;
             }
             __syncthreads();
         }
         // ------------------------------------------------------------ open tiles (the one place: also the first pass,
         // and the pass that finds the queue empty)
-        if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + fresh_args(Ak)->ring && chunk_left >= 0) {
-            open_tiles();
-            __syncthreads();
+        // (both questions depend only on the tile counters, which change when a tile is flushed, opened or handed out
+        // completely: they are asked then, not at every refill -- scalar instructions are not free, tools/ubench_salu)
+        if (dirty) {
+            dirty = 0;
+            if (tile_open <= next_tile + fresh_args(Ak)->open_ahead && tile_open < flushed + fresh_args(Ak)->ring && chunk_left >= 0) {
+                open_tiles();
+                __syncthreads();
+            }
+            if (flushed == tile_open && chunk_left < 0) break;
         }
-        if (flushed == tile_open && chunk_left < 0) break;
         // ------------------------------------------------------------ hand out new trials
         {
             const unsigned long long want_mask = ~has_m;
@@ -632,6 +658,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             int tl = next_tile;
             while (tr >= N) { tr -= N; tl++; }
             const unsigned long long ok_mask = want_mask & __builtin_amdgcn_ballot_w64(tl < tile_open);
+            // byte offsets of the slots of the (at most two) tiles open for hand-out: next_tile and the one after it
+            const int off0 = slot_pack & 0xffff, off01 = slot_pack >> 16;
+            const int tile0 = next_tile;
             if constexpr (LATENT) {
                 const int n_ok = (int)__popcll(ok_mask);
                 if (n_ok > fifo_avail) {
@@ -642,7 +671,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     while (btr >= N) { btr -= N; btl++; }
                     const unsigned long long bmask = __builtin_amdgcn_ballot_w64(btl < tile_open);
                     if (__builtin_amdgcn_inverse_ballot_w64(bmask)) {
-                        const uint32_t bsb = __umul24((uint32_t)(btl & ring_mask), (uint32_t)stride) + kbase;
+                        const uint32_t bsb = (uint32_t)(__mul24(btl - tile0, off01) + off0) + kbase;
                         const lds_u32v4 *const bq = reinterpret_cast<const lds_u32v4 *>(bsb + SLOTS_OFF);
                         const u32v4 dA = bq[D_A / 4];
                         [[maybe_unused]] const u32v4 dB = bq[D_B / 4];
@@ -665,13 +694,25 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 }
             }
             next_trial += (int)__popcll(ok_mask);
-            while (next_trial >= N) { next_trial -= N; next_tile++; }
+            if (next_trial >= N) {
+                // the cursor moves on by one tile (more only when tiles are smaller than a wave): the next tile's slot becomes
+                // the current one, the one after it follows -- or wraps to slot 0 at the end of the ring
+                const int ring_bytes = fresh_args(Ak)->ring * stride;
+                int o0 = slot_pack & 0xffff, o01 = slot_pack >> 16;
+                while (next_trial >= N) {
+                    next_trial -= N; next_tile++;
+                    o0 += o01;
+                    o01 = o0 + stride == ring_bytes ? -o0 : stride;
+                }
+                slot_pack = (o0 & 0xffff) | (o01 << 16);
+                dirty = 1;
+            }
             has_m |= ok_mask;
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
                 const ArgsPtr H = fresh_args(Ak);
                 if constexpr (!SMALL) tile = tl;
                 // LDS byte address of the slot (kbase holds the LDS base: one v_mad_u32_u24), of the trial's result word
-                const uint32_t sb = __umul24((uint32_t)(tl & ring_mask), (uint32_t)stride) + kbase;
+                const uint32_t sb = (uint32_t)(__mul24(tl - tile0, off01) + off0) + kbase;
                 res_addr = sb + ((uint32_t)tr << rshift);
                 const lds_u32v4 *const rq = reinterpret_cast<const lds_u32v4 *>(sb + SLOTS_OFF);
                 const lds_u32 *const rw = reinterpret_cast<const lds_u32 *>(sb + SLOTS_OFF);

@@ -110,7 +110,7 @@ int nddm_debug_set_slot_limit(int n);
  * the Philox round keys in VGPRs ran, ring slots, trials per tile, tiles per set, sets per chunk, refill threshold, dynamic
  * LDS bytes}.  bench.py uses it to run its lockstep ceiling on the same kernel variant and grid as the timed workload. */
 int nddm_debug_last_launch(int32_t *out8);
-/* developer knobs of the launch geometry (0 = the library's rule): sets per queue chunk, ring slots (a power of two),
+/* developer knobs of the launch geometry (0 = the library's rule): sets per queue chunk, ring slots (>= 2),
  * refill threshold (lanes holding a finished trial; >= 64 = refill only when no lane is stepping), kernel variant (1 =
  * Philox round keys from LDS, 2 = in VGPRs, taken modulo 3), grid in waves, trials per tile.  Results never depend on
  * them (tests/test_gpu_fuzz.py randomises all six). */

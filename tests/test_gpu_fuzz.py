@@ -16,7 +16,7 @@ def _case(rng):
     max_steps = float(rng.choice([0, 1, 3, 10, 400, 401, 1000, 4000]))
     seed = int(rng.integers(0, 2**63))
     off = int(rng.choice([0, 1, 2**31 - 5, 2**32 - 3, 2**40 + 17]))
-    tune = (int(rng.integers(0, 9)), int(rng.choice([0, 2, 4, 8, 16])), int(rng.integers(0, 70)), int(rng.integers(0, 20)),
+    tune = (int(rng.integers(0, 9)), int(rng.choice([0, 2, 3, 4, 6, 8, 13, 16])), int(rng.integers(0, 70)), int(rng.integers(0, 20)),
             int(rng.choice([0, 1, 3, 64, 5000])), int(rng.choice([0, 0, 0, 5, 33, 64, 200])))
     bridge = bool(model == 3 and rng.random() < 0.5 and max_steps < 2**22)
     return model, B, N, dt, max_steps, seed, off, tune, bridge

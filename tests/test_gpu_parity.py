@@ -439,7 +439,7 @@ def test_kernel_variants_and_geometry_do_not_change_results():
     kw = dict(dt=0.001, max_steps=4000, seed=5, set_offset=99, fast=True)
     ref = engine.simulate(engine.BASIC_DDM_DC, p_dev, N, **kw)
     auto = engine.last_launch()
-    assert auto["grid_waves"] >= 1 and auto["ring"] in (2, 4, 8, 16, 32, 64) and auto["tile_trials"] * auto["tiles_per_set"] >= N
+    assert auto["grid_waves"] >= 1 and 2 <= auto["ring"] <= 32 and auto["tile_trials"] * auto["tiles_per_set"] >= N
     assert auto["vgpr_keys"] == 1                                       # a launch this small runs the VGPR-keys variant
     seen = set()
     try:

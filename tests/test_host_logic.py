@@ -51,7 +51,7 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.nddm_debug_last_launch(None) == _lib.NDDM_ERR_NULL
     geo = (ctypes.c_int32 * 8)()
     assert L.nddm_debug_last_launch(geo) == _lib.NDDM_OK and list(geo) == [0] * 8      # nothing launched on this thread
-    assert L.nddm_set_tuning(0, 3, 0, 0, 0, 0) == _lib.NDDM_ERR_PARAM                   # ring must be a power of two
+    assert L.nddm_set_tuning(0, 1, 0, 0, 0, 0) == _lib.NDDM_ERR_PARAM                   # a ring has at least two slots
     assert L.nddm_set_tuning(0, 0, 0, 0, 0, 0) == _lib.NDDM_OK
     with pytest.raises(ValueError):
         _lib.check(_lib.NDDM_ERR_SHAPE)
