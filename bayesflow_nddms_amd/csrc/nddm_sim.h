@@ -777,6 +777,10 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         // measurement -- switches that exit off)
         constexpr int MAX_BLOCKS = 16;
         const int it_limit = A.refill_thresh < WAVE ? MAX_BLOCKS - 1 : 0x7fffffff;      // (one integer, not a lane-mask pair)
+        // leave when this many lanes hold a finished trial: the threshold, or all the lanes that hold one at all ("none is
+        // stepping" is the same test: the occupied lanes do not change inside the step loop)
+        const int occupied = (int)__popcll(has_m);
+        const int leave_at = occupied < A.refill_thresh ? occupied : A.refill_thresh;
         int it = 0;
         for (;; ++it) {
             [[maybe_unused]] bool active = (!BRIDGE && CAP4 && !PACKED) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                              : "vcc");
 #undef NDDM_STEP
                 act_m = still & __builtin_amdgcn_ballot_w64(k < A.max_k);      // (still is a subset of the lanes that stepped)
-                if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
+                if ((int)__popcll(has_m & ~act_m) >= leave_at) break;
                 if (it >= it_limit) break;
                 continue;
             }
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             // fresh compares for every lane, combined as SGPR masks: a ballot of a compare is just its SGPR result, a
             // ballot of the loop-carried flag (or of an && of two compares) is rebuilt through v_cndmask + v_cmp
             act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
-            if (act_m == 0ull || __popcll(has_m & ~act_m) >= A.refill_thresh) break;
+            if ((int)__popcll(has_m & ~act_m) >= leave_at) break;
             if (it >= it_limit) break;
         }
         // one refill phase of `it + 1` blocks
