@@ -152,7 +152,19 @@ def step_loop(insts):
                 best = body
     if best is None:
         raise RuntimeError("step loop not found")
-    return best
+    # a loop may have several latches (the compiler rotates / splits the exit tests): the body runs from the header to the
+    # LAST backward branch that targets it
+    # ... and what the compiler makes of `continue` / several exit tests is a nest of latches whose headers lie a few
+    # instructions before one another: grow the region over every backward branch that starts at most 64 bytes before the
+    # current header and ends after the current end (never into the enclosing refill loop, whose header is far away)
+    header, last = best[0][0], best[-1][0]
+    grown = True
+    while grown:
+        grown = False
+        for a, op, args, t in insts:
+            if op.startswith(("s_cbranch", "s_branch")) and t is not None and header - 64 <= t <= header and a >= last and (t, a) != (header, last):
+                header, last, grown = t, a, True
+    return [x for x in insts if header <= x[0] <= last]
 
 
 def tally(body, cost, sgpr_cost):
