@@ -6,7 +6,7 @@ all: lib oracle ubench demo
 
 lib: bayesflow_nddms_amd/libnddm_hip.so
 bayesflow_nddms_amd/libnddm_hip.so: bayesflow_nddms_amd/csrc/nddm_kernels.hip bayesflow_nddms_amd/csrc/nddm_sim.h bayesflow_nddms_amd/csrc/nddm_prepass.h bayesflow_nddms_amd/csrc/nddm_rng.h include/nddm.h
-	$(HIPCC) $(HIPFLAGS) -o $@ $<
+	python -m bayesflow_nddms_amd.build    # (hipcc $(HIPFLAGS) + the content hash of the sources, -DNDDM_SOURCE_HASH)
 
 # test infrastructure only (CPU oracle); never linked into the product
 oracle: oracle/liboracle.so

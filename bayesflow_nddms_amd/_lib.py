@@ -7,7 +7,7 @@ from .build import SO_PATH
 
 NDDM_OK, NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM, NDDM_ERR_HIP, NDDM_ERR_NO_DEVICE = range(6)
 GAUSS_EXACT, GAUSS_FAST, BRIDGE, GAUSS_PACKED = 0, 1, 2, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -36,10 +36,13 @@ def _declare(L):
     L.nddm_alpha_not_scaled_simulate.argtypes = [fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_explicit_boundary_simulate.argtypes = [fp, fp] + common + [fp, fp, vp]
     L.nddm_simulate.argtypes = [c.c_int32, fp, fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
+    L.nddm_simulate_indirect.argtypes = [c.c_int32, fp, fp] + common[:-1] + [fp, c.c_uint32, c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_draw_prior.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, c.c_float, fp, vp]
+    L.nddm_draw_prior_indirect.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, fp, c.c_float, fp, vp]
+    L.nddm_source_hash.restype = c.c_char_p
     L.nddm_debug_normals.argtypes = [fp, c.c_int64, c.c_uint32, c.c_uint32, c.c_uint32, fp, vp]
     for name in EXPORTS:
-        if name != "nddm_last_error":
+        if name not in ("nddm_last_error", "nddm_source_hash"):
             getattr(L, name).restype = c.c_int
 
 
@@ -50,29 +53,30 @@ EXPORTS = [
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
     "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_trace", "nddm_set_ordering",
     "nddm_release_graph_memory", "nddm_debug_set_slot_limit", "nddm_debug_last_launch",
+    "nddm_simulate_indirect", "nddm_draw_prior_indirect", "nddm_source_hash",
 ]
 
 
 def lib():
-    """The loaded library; raises NddmLibraryError (an ImportError) when it is absent."""
+    """The loaded library; raises NddmLibraryError (an ImportError) when it is absent, was built from other sources than
+    the tree holds and cannot be rebuilt, or does not export the ABI this binding declares.  Staleness is decided by a
+    content hash compiled into the library (build.source_hash), never by file times."""
     global _lib
     if _lib is None:
-        from .build import build_hip, is_stale
-        build_error = None
-        if is_stale():                 # a fresh checkout or an edited kernel: compile in-tree (hipcc, gfx950)
+        from .build import build_hip, embedded_hash, is_stale, source_hash
+        override = bool(os.environ.get("NDDM_HIP_LIB"))
+        if is_stale():                 # no library, or one built from other sources: compile in-tree (hipcc, gfx950)
             try:
                 build_hip()
-            except Exception as e:     # noqa: BLE001 -- reported just below
-                build_error = e
+            except Exception as e:     # noqa: BLE001 -- reported below
+                why = "is missing" if not os.path.exists(SO_PATH) else \
+                    f"was built from other sources (library {embedded_hash()}, tree {source_hash()})"
+                raise NddmLibraryError(
+                    f"{SO_PATH} {why} and could not be rebuilt ({e!r}): build it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                    "There is no CPU fallback.") from e
         if not os.path.exists(SO_PATH):
-            raise NddmLibraryError(
-                f"{SO_PATH} is missing and could not be built ({build_error!r}): build it with "
-                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
-                "There is no CPU fallback.")
-        if build_error is not None:    # an older library exists but its sources changed and the rebuild failed
-            import warnings
-            warnings.warn(f"{SO_PATH} is older than its sources and rebuilding it failed ({build_error!r}); "
-                          "using the existing library", RuntimeWarning)
+            raise NddmLibraryError(f"{SO_PATH} does not exist (NDDM_HIP_LIB points to a missing file?).  There is no CPU fallback.")
         # PyTorch (the plumbing for device memory / streams) bundles its own ROCm runtime: it must be the first HIP
         # runtime loaded into the process, otherwise torch and this library end up on different libamdhip64 copies
         import torch  # noqa: F401
@@ -80,9 +84,17 @@ def lib():
             L = ctypes.CDLL(SO_PATH)
         except OSError as e:   # e.g. libamdhip64 not found
             raise NddmLibraryError(f"cannot load {SO_PATH}: {e}") from e
+        missing = [name for name in EXPORTS if not hasattr(L, name)]
+        if missing:
+            raise NddmLibraryError(f"{SO_PATH} does not export {missing}: it is older than this binding -- rebuild it "
+                                   "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _declare(L)
         if L.nddm_abi_version() != ABI_VERSION:
-            raise NddmLibraryError(f"ABI mismatch: library {L.nddm_abi_version()} != binding {ABI_VERSION}")
+            raise NddmLibraryError(f"ABI mismatch: library {L.nddm_abi_version()} != binding {ABI_VERSION} "
+                                   "(the random stream differs between ABI versions): rebuild the library")
+        if not override and L.nddm_source_hash().decode() != source_hash():
+            raise NddmLibraryError(f"{SO_PATH} reports source hash {L.nddm_source_hash().decode()} but the tree hashes to "
+                                   f"{source_hash()}: rebuild the library")
         _lib = L
     return _lib
 

@@ -23,12 +23,24 @@ import torch
 from torch import nn
 
 
-def _mlp(d_in, d_hidden, d_out, n_hidden=2, act=nn.ReLU):
+def _mlp(d_in, d_hidden, d_out, n_hidden=2, act=nn.ReLU, keras_init=True):
     layers, d = [], d_in
     for _ in range(n_hidden):
         layers += [nn.Linear(d, d_hidden), act()]
         d = d_hidden
     layers.append(nn.Linear(d, d_out))
+    # Keras-style initialisation (the reference's networks are BayesFlow/Keras Dense layers: Glorot weights, zero biases),
+    # with He scaling on the hidden layers: PyTorch's Linear default shrinks the signal by ~0.58 per layer, and through the ~15
+    # stacked layers of the summary network the data-dependent part of its output was 1e-5 of the bias-driven part at
+    # initialisation -- the amortizer then learns the prior long before it starts looking at the data
+    # (the coupling layers' internal networks keep PyTorch's small default: a flow should start near the identity)
+    if keras_init:
+        for m in layers[:-1]:
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_uniform_(m.weight, nonlinearity="relu")
+                nn.init.zeros_(m.bias)
+        nn.init.xavier_uniform_(layers[-1].weight)
+        nn.init.zeros_(layers[-1].bias)
     return nn.Sequential(*layers)
 
 
@@ -40,9 +52,10 @@ class _Equivariant(nn.Module):
         self.inv = _mlp(d_in, d_hidden, d_hidden)
         self.eq = _mlp(d_in + d_hidden, d_hidden, d_hidden)
 
-    def forward(self, x):
-        pooled = self.inv(x).mean(dim=1, keepdim=True).expand(-1, x.shape[1], -1)
-        return self.eq(torch.cat([x, pooled], dim=-1))
+    def forward(self, x, mask=None, inv_n=None):
+        g = self.inv(x)
+        pooled = g.mean(dim=1, keepdim=True) if mask is None else (g * mask).sum(dim=1, keepdim=True) * inv_n
+        return self.eq(torch.cat([x, pooled.expand(-1, x.shape[1], -1)], dim=-1))
 
 
 class InvariantNetwork(nn.Module):
@@ -59,8 +72,15 @@ class InvariantNetwork(nn.Module):
         self.post_pool = _mlp(hidden, hidden, summary_dim)
         self.summary_dim = summary_dim
 
-    def forward(self, x):
-        return self.post_pool(self.pre_pool(self.equiv(x)).mean(dim=1))
+    def forward(self, x, mask=None, inv_n=None):
+        """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors:
+        the pooled means then run over the real trials only, so a batch padded to a fixed length (one hipGraph per length
+        bucket, GraphTrainer) gives what the unpadded batch gives."""
+        for block in self.equiv:
+            x = block(x, mask, inv_n)
+        h = self.pre_pool(x)
+        pooled = h.mean(dim=1) if mask is None else (h * mask).sum(dim=1) * inv_n
+        return self.post_pool(pooled)
 
 
 class _AffineCoupling(nn.Module):
@@ -69,8 +89,8 @@ class _AffineCoupling(nn.Module):
         self.d1 = dim // 2
         self.d2 = dim - self.d1
         self.clamp = clamp
-        self.net1 = _mlp(self.d1 + cond_dim, hidden, 2 * self.d2, act=nn.ELU)
-        self.net2 = _mlp(self.d2 + cond_dim, hidden, 2 * self.d1, act=nn.ELU)
+        self.net1 = _mlp(self.d1 + cond_dim, hidden, 2 * self.d2, act=nn.ELU, keras_init=False)
+        self.net2 = _mlp(self.d2 + cond_dim, hidden, 2 * self.d1, act=nn.ELU, keras_init=False)
 
     def _st(self, net, h, cond):
         s, t = net(torch.cat([h, cond], dim=-1)).chunk(2, dim=-1)
@@ -139,7 +159,9 @@ class AmortizedPosterior(nn.Module):
         return v.to(dev, torch.float32) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev)
 
     def _conditions(self, input_dict):
-        summ = self.summary_net(self._t(input_dict["summary_conditions"]))
+        pad = input_dict.get("summary_mask", None)        # (mask, inv_n) of a batch padded to a bucket length (additive key)
+        x = self._t(input_dict["summary_conditions"])
+        summ = self.summary_net(x) if pad is None else self.summary_net(x, pad[0], pad[1])
         direct = input_dict.get("direct_conditions", None)
         return summ if direct is None else torch.cat([summ, self._t(direct)], dim=-1)
 

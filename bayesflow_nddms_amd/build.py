@@ -3,7 +3,9 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the built .so
 travels to the GPU box with the repository snapshot.
 """
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -24,13 +26,39 @@ def _hipcc():
     return exe
 
 
+def source_hash():
+    """sha256 over the CONTENT of every source and header (in a fixed order) and the compiler flags: what the library is
+    a function of.  It is compiled into the library (-DNDDM_SOURCE_HASH, exported as nddm_source_hash() and findable in the
+    file as `NDDM_SRC_HASH=<hex>`), so staleness does not depend on file times -- a snapshot copied to the GPU box has
+    arbitrary ones."""
+    h = hashlib.sha256()
+    for p in SOURCES + HEADERS:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def embedded_hash(path=None):
+    """The source hash compiled into a built library, read from the file (no dlopen); None if there is none."""
+    path = path or SO_PATH
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"NDDM_SRC_HASH=([0-9a-f]{64})", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def is_stale():
+    """True when there is no library or it was built from other sources than the ones in the tree (by content hash)."""
     if os.environ.get("NDDM_HIP_LIB"):
         return False
     if not os.path.exists(SO_PATH):
         return True
-    t = os.path.getmtime(SO_PATH)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    return embedded_hash() != source_hash()
 
 
 def build_hip(force=False, verbose=False):
@@ -43,7 +71,7 @@ def build_hip(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or is_stale():
             tmp = f"{SO_PATH}.{os.getpid()}.tmp"
-            cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + SOURCES
+            cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DNDDM_SOURCE_HASH="{source_hash()}"', "-o", tmp] + SOURCES
             if verbose:
                 print(" ".join(cmd))
             try:

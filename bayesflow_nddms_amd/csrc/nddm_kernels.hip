@@ -38,6 +38,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -141,11 +142,17 @@ static LaunchSlot *acquire_slot_once(int dev, hipStream_t st, hipError_t *err)
     std::lock_guard<std::mutex> lock(g_mu);
     LaunchSlot *pick = nullptr;
     const int n_use = g_nslots[dev] < g_slot_limit ? g_nslots[dev] : g_slot_limit;      // slots in use (all, unless a test caps them)
-    // (a) the slot this stream used last: stream order makes it safe without a query.  hipStreamPerThread is one handle
-    //     for a different stream in every thread, so it never qualifies.
+    // (a) the slot this stream used last: stream order makes it safe -- PROVIDED `st` still is the stream that used it.  A
+    //     handle value is recycled once its stream has been destroyed (possibly with the slot's launch still in flight), so
+    //     the new launch is also made to wait for the slot's completion event: no wait at all on a genuinely identical
+    //     stream (the event is behind it in stream order), the needed one on a recycled handle.  hipStreamPerThread is one
+    //     handle for a different stream in every thread, so it never qualifies.
     if (st != hipStreamPerThread)
         for (int i = 0; i < n_use && !pick; ++i)
-            if (!g_slots[dev][i]->busy && g_slots[dev][i]->stream == st && !g_slots[dev][i]->fresh) pick = g_slots[dev][i];
+            if (!g_slots[dev][i]->busy && g_slots[dev][i]->stream == st && !g_slots[dev][i]->fresh) {
+                if (hipStreamWaitEvent(st, g_slots[dev][i]->done, 0) != hipSuccess) { (void)hipGetLastError(); continue; }
+                pick = g_slots[dev][i];
+            }
     // (b) any slot whose last launch has completed
     for (int i = 0; i < n_use && !pick; ++i) {
         LaunchSlot *s = g_slots[dev][i];
@@ -295,8 +302,8 @@ static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, si
 }
 
 static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
-                    int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma,
-                    int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream)
+                    int32_t max_steps, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags,
+                    float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream)
 {
     g_err[0] = 0;
     int P;
@@ -342,13 +349,18 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     DeviceInfo di;
     if (!device_info(dev, &di)) return fail(NDDM_ERR_HIP, "hipGetDeviceProperties failed%s");
     const int simds = 4 * di.cus;
-    const long long waves7 = 7ll * simds;      // a persistent grid at 7 waves per SIMD (7168 on MI355X): the sizing rules'
-    const long long waves6 = 6ll * simds;      // "resident waves"; the launch itself asks resident_waves() per kernel
+    // The sizing rules' yardsticks.  They are NOT the grid (the launch asks resident_waves() per kernel: 8 per SIMD for every
+    // fast kernel): `waves_sizing` = 7 per SIMD is what tiles, chunks and the open-ahead switch were tuned against, and an
+    // A/B of the same rules at 8 per SIMD moved no shape by more than the run-to-run noise (profiles/r3_sizing_ab.txt), so the
+    // measured constants stay; `waves_min_chunks` = 6 per SIMD is the floor of the chunk count.
+    static const int sizing_per_simd = [] { const char *e = getenv("NDDM_SIZING_WAVES_PER_SIMD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 7; }();
+    const long long waves_sizing = (long long)sizing_per_simd * simds;                 // (the environment variable is the A/B's switch)
+    const long long waves_min_chunks = (long long)(sizing_per_simd - 1) * simds;
 
     SimArgs A;
     memset(&A, 0, sizeof A);
     A.params = params; A.bounds = bounds; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_ext;
-    A.B = B; A.set_offset = set_offset; A.n_trials = n_trials; A.max_k = max_steps; A.dt = dt; A.sqrt_dt = sqrtf(dt);
+    A.B = B; A.n_trials = n_trials; A.max_k = max_steps; A.dt = dt; A.sqrt_dt = sqrtf(dt);
     A.tscale = bridge ? dt * 0.00390625f : dt;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
@@ -388,7 +400,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         if (crit < want) want = crit;
         if (want < (double)plan_waves) plan_waves = want < (double)simds ? simds : (long long)want;
     }
-    const long long waves_for_tiles = plan_waves < waves7 ? plan_waves : waves7;
+    const long long waves_for_tiles = plan_waves < waves_sizing ? plan_waves : waves_sizing;
     int tile_cap = 64;
     while (tile_cap < 512 && (long long)tile_cap * waves_for_tiles * 8 < total_trials) tile_cap <<= 1;
     int tiles = tun.tile_trials > 0 ? (n_trials + tun.tile_trials - 1) / tun.tile_trials
@@ -426,7 +438,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         const double t_est = (double)vB * ((double)tile_n * est_steps / 256.0) * 265.0 / ((double)simds * di.clock_hz)
                              + (double)max_steps * 0.25 * 265.0 * 7.0 / di.clock_hz;
         double max_chunks = t_est * 4.0e7;
-        if (max_chunks < 8.0 * (double)waves6) max_chunks = 8.0 * (double)waves6;
+        if (max_chunks < 8.0 * (double)waves_min_chunks) max_chunks = 8.0 * (double)waves_min_chunks;
         if ((double)vB / spc > max_chunks) {
             spc = (int)((double)vB / max_chunks) + 1;
             if (spc > 64) spc = 64;
@@ -456,8 +468,11 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     }
     if (ring < 2) ring = 2;
     if (ring > 64) ring = 64;
-    if (lds_of(ring) > 60 * 1024)
-        return fail(NDDM_ERR_SHAPE, "tile too large for the LDS ring (tuning override?)%s");
+    // the hand-out carries the byte offset of the current slot and the SIGNED step to the next one as two 16-bit halves of one
+    // register (nddm_sim.h: slot_pack): the ring's slots must span < 32 KB.  The library's own geometry stays below 5 KB; only
+    // a tuning override gets here.
+    if ((size_t)ring * (size_t)slot_stride_bytes(tile_n, (int)per_trial) >= 32768u)
+        return fail(NDDM_ERR_SHAPE, "ring x tile too large: the LDS ring's slots must span < 32 KB (tuning override?)%s");
     A.sets_per_chunk = spc; A.ring = ring; A.ring_magic = (uint32_t)(0x100000000ull / (unsigned long long)ring);
     // refill threshold: a refill costs ~27 VALU instructions whatever the number of lanes it serves, a waiting lane
     // wastes its share of every block; with lambda completions per block the optimum is ~sqrt(c lambda) finished lanes:
@@ -468,10 +483,9 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
     if (packed && A.res16 != 2) return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs tiles of <= 512 trials (tuning override?)%s");
     A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : (max_steps <= 1000 ? 16 : 8);
-    A.max_blocks = 16;
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
-    A.open_ahead = vB >= 4 * waves7 ? 1 : 0;
+    A.open_ahead = vB >= 4 * waves_sizing ? 1 : 0;
     const size_t lds = lds_of(ring);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool fast = (flags & NDDM_GAUSS_FAST) != 0;
@@ -537,12 +551,13 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
             hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
                                (int)max_steps, order_ws);
             hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P,
-                               (int)B, dt, A.sqrt_dt, (int)max_steps, order_ws, recs);
+                               (int)B, dt, A.sqrt_dt, (int)max_steps, (unsigned long long)set_offset,
+                               reinterpret_cast<const unsigned long long *>(set_offset_dev), order_ws, recs);
             A.recs = recs;
         } else {
             uint32_t *recs = reinterpret_cast<uint32_t *>(scratch);
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P, (int)B, dt,
-                               A.sqrt_dt, recs);
+                               A.sqrt_dt, (unsigned long long)set_offset, reinterpret_cast<const unsigned long long *>(set_offset_dev), recs);
             A.recs = recs;
         }
         e = hipGetLastError();
@@ -687,7 +702,7 @@ int nddm_basic_ddm_dc_simulate(const float *params, int64_t B, int32_t n_trials,
                                uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
                                float *out_summary, void *stream)
 {
-    return nddm::simulate(NDDM_BASIC_DDM_DC, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, flags,
+    return nddm::simulate(NDDM_BASIC_DDM_DC, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, nullptr, flags,
                           0.0f, 0, out_trials, out_summary, nullptr, stream);
 }
 
@@ -695,7 +710,7 @@ int nddm_single_trial_simulate(const float *params, int64_t B, int32_t n_trials,
                                uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
                                float *out_summary, void *stream)
 {
-    return nddm::simulate(NDDM_SINGLE_TRIAL, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, flags,
+    return nddm::simulate(NDDM_SINGLE_TRIAL, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, nullptr, flags,
                           0.0f, 0, out_trials, out_summary, nullptr, stream);
 }
 
@@ -703,7 +718,7 @@ int nddm_single_trial_alt_simulate(const float *params, int64_t B, int32_t n_tri
                                    uint64_t seed, uint64_t set_offset, uint32_t flags, float *out_trials,
                                    float *out_summary, void *stream)
 {
-    return nddm::simulate(NDDM_SINGLE_TRIAL_ALT, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset,
+    return nddm::simulate(NDDM_SINGLE_TRIAL_ALT, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, nullptr,
                           flags, 0.0f, 0, out_trials, out_summary, nullptr, stream);
 }
 
@@ -712,7 +727,7 @@ int nddm_alpha_not_scaled_simulate(const float *params, int64_t B, int32_t n_tri
                                    int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
                                    void *stream)
 {
-    return nddm::simulate(NDDM_ALPHA_NOT_SCALED, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset,
+    return nddm::simulate(NDDM_ALPHA_NOT_SCALED, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, nullptr,
                           flags, ext_sigma, ext_mode, out_trials, out_summary, out_extdata, stream);
 }
 
@@ -720,7 +735,7 @@ int nddm_explicit_boundary_simulate(const float *params, const float *bounds, in
                                     float dt, int32_t max_steps, uint64_t seed, uint64_t set_offset,
                                     uint32_t flags, float *out_trials, float *out_summary, void *stream)
 {
-    return nddm::simulate(NDDM_EXPLICIT_BOUNDARY, params, bounds, B, n_trials, dt, max_steps, seed, set_offset,
+    return nddm::simulate(NDDM_EXPLICIT_BOUNDARY, params, bounds, B, n_trials, dt, max_steps, seed, set_offset, nullptr,
                           flags, 0.0f, 0, out_trials, out_summary, nullptr, stream);
 }
 
@@ -729,12 +744,22 @@ int nddm_simulate(int32_t model, const float *params, const float *bounds, int64
                   float *out_trials, float *out_summary, float *out_extdata, void *stream)
 {
     return nddm::simulate(model, params, model == NDDM_EXPLICIT_BOUNDARY ? bounds : nullptr, B, n_trials, dt, max_steps,
-                          seed, set_offset, flags, ext_sigma, ext_mode, out_trials, out_summary,
+                          seed, set_offset, nullptr, flags, ext_sigma, ext_mode, out_trials, out_summary,
                           model == NDDM_ALPHA_NOT_SCALED ? out_extdata : nullptr, stream);
 }
 
-int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
-                    void *stream)
+int nddm_simulate_indirect(int32_t model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
+                           int32_t max_steps, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags,
+                           float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
+                           void *stream)
+{
+    return nddm::simulate(model, params, model == NDDM_EXPLICIT_BOUNDARY ? bounds : nullptr, B, n_trials, dt, max_steps,
+                          seed, set_offset, set_offset_dev, flags, ext_sigma, ext_mode, out_trials, out_summary,
+                          model == NDDM_ALPHA_NOT_SCALED ? out_extdata : nullptr, stream);
+}
+
+static int draw_prior_impl(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev,
+                           float gamma, float *out_params, void *stream)
 {
     nddm::g_err[0] = 0;
     if (model != NDDM_BASIC_DDM_DC && model != NDDM_SINGLE_TRIAL && model != NDDM_SINGLE_TRIAL_ALT)
@@ -746,10 +771,33 @@ int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset
     const long long blocks = (B + threads - 1) / threads;
     hipLaunchKernelGGL(nddm::prior_kernel, dim3((unsigned)blocks), dim3(threads), 0,
                        reinterpret_cast<hipStream_t>(stream), (int)model, (long long)B, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), (unsigned long long)set_offset, gamma, out_params);
+                       (uint32_t)(seed >> 32), (unsigned long long)set_offset,
+                       reinterpret_cast<const unsigned long long *>(set_offset_dev), gamma, out_params);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nddm::fail(NDDM_ERR_HIP, "prior kernel launch failed: %s", hipGetErrorString(e));
     return NDDM_OK;
+}
+
+int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
+                    void *stream)
+{
+    return draw_prior_impl(model, B, seed, set_offset, nullptr, gamma, out_params, stream);
+}
+
+int nddm_draw_prior_indirect(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev,
+                             float gamma, float *out_params, void *stream)
+{
+    return draw_prior_impl(model, B, seed, set_offset, set_offset_dev, gamma, out_params, stream);
+}
+
+/* sha256 (hex) of the sources this library was compiled from (build.py passes it; "unknown" for a hand-made build) */
+#ifndef NDDM_SOURCE_HASH
+#define NDDM_SOURCE_HASH "unknown"
+#endif
+const char *nddm_source_hash(void)
+{
+    static const char tag[] = "NDDM_SRC_HASH=" NDDM_SOURCE_HASH;      // the tag makes the hash findable in the file without loading it
+    return tag + 14;
 }
 
 int nddm_debug_normals(const uint32_t *counters, int64_t n, uint32_t k0, uint32_t k1, uint32_t flags, float *out,

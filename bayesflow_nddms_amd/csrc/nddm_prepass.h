@@ -50,9 +50,16 @@ __global__ void order_hist_kernel(int model, const float *params, int P, int B, 
     if (threadIdx.x < ORDER_BUCKETS && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ void order_scatter_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
-                                     int *ws, uint32_t *recs)
+// set_offset + (off_dev ? *off_dev : 0) = global index of row 0 (nddm.h: nddm_simulate_indirect)
+__device__ __forceinline__ unsigned long long global_offset(unsigned long long set_offset, const unsigned long long *off_dev)
 {
+    return set_offset + (off_dev ? *off_dev : 0ull);
+}
+
+__global__ void order_scatter_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
+                                     unsigned long long set_offset, const unsigned long long *off_dev, int *ws, uint32_t *recs)
+{
+    const unsigned long long g0 = global_offset(set_offset, off_dev);
     __shared__ int start[ORDER_BUCKETS], lh[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
     if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += ws[b]; } }
     for (int base = blockIdx.x * blockDim.x; base < B; base += gridDim.x * blockDim.x) {
@@ -70,17 +77,20 @@ __global__ void order_scatter_kernel(int model, int fast, const float *params, i
         __syncthreads();
         if (i < B) {
             const int q = start[b] + lbase[b] + r;      // position of set i in the processing order
-            make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)q * REC);
+            make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, g0 + (unsigned long long)i, recs + (long long)q * REC);
         }
         __syncthreads();
     }
 }
 
 // launches too small to be worth sorting: records in the given order
-__global__ void prep_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, uint32_t *recs)
+__global__ void prep_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt,
+                            unsigned long long set_offset, const unsigned long long *off_dev, uint32_t *recs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, recs + (long long)i * REC);
+    if (i < B)
+        make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i,
+                    global_offset(set_offset, off_dev) + (unsigned long long)i, recs + (long long)i * REC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,11 +167,11 @@ struct PriorStream {
 };
 
 __global__ void prior_kernel(int model, long long B, uint32_t k0, uint32_t k1, unsigned long long set_offset,
-                             float gamma, float *out)
+                             const unsigned long long *off_dev, float gamma, float *out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    PriorStream s(k0, k1, set_offset + (unsigned long long)i);
+    PriorStream s(k0, k1, set_offset + (off_dev ? *off_dev : 0ull) + (unsigned long long)i);
     if (model == NDDM_BASIC_DDM_DC) {
         float *o = out + i * 5;
         o[0] = 2.0f * s.normal();                       // drift ~ N(0, 2)          basic_ddm_dc.py:65

@@ -36,7 +36,6 @@ struct SimArgs {
     float *out_summary;       // [B, K] or null
     float *out_ext;           // [B] or null
     long long B;
-    unsigned long long set_offset;
     int n_trials;             // trials per TILE (a set is split into tiles_per_set tiles when it does not fit the LDS ring)
     int n_total;              // trials per set (row stride of out_trials / bounds)
     int tiles_per_set;
@@ -65,7 +64,6 @@ struct SimArgs {
                               // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
     uint32_t ring_magic;      // floor(2^32 / ring): t mod ring by a multiply (ring_slot())
-    int max_blocks;           // (unused by the kernels: the block limit is 16, switched off by refill_thresh >= 64)
 };
 
 // The launch arguments as they sit in the kernarg segment (constant address space: scalar loads).  The rarely executed
@@ -177,11 +175,14 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
 //                single_alt (noise scale per trial): drift, alpha, beta, std_dc
 //   r[4..7]  B   single: sigma1, gamma, beta;  single_alt: mu_dc, sigma1, gamma;  alpha_ns: Eta
 //   r[8]     the set's row index in the caller's arrays, r[9] tau
+//   r[10,11] the set's GLOBAL index (low word, high 28 bits): set_offset + *set_offset_dev + row.  It keys the random
+//            stream; the pre-pass adds the optional device-resident part of the offset (nddm_simulate_indirect: a
+//            replayed hipGraph moves along the stream without new kernel arguments), the simulator only reads it here
 // S = noise_unit(sqrt(dt) * dc): the state is carried in noise units (nddm_rng.h).
-enum { REC = 12, R_A = 0, R_B = 4, R_SET = 8, R_TAU = 9 };
+enum { REC = 12, R_A = 0, R_B = 4, R_SET = 8, R_TAU = 9, R_GLO = 10, R_GHI = 11 };
 
 __device__ __forceinline__ void make_record(int model, bool fast, const float *row, float dt, float sqrt_dt, int set,
-                                            uint32_t *r)
+                                            unsigned long long gset, uint32_t *r)
 {
     float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 1.0f, tau;
     float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -202,7 +203,8 @@ __device__ __forceinline__ void make_record(int model, bool fast, const float *r
     else if (model == NDDM_EXPLICIT_BOUNDARY) { a2 = beta; a3 = 0.0f; }
     r[0] = __float_as_uint(a0); r[1] = __float_as_uint(a1); r[2] = __float_as_uint(a2); r[3] = __float_as_uint(a3);
     r[4] = __float_as_uint(b0); r[5] = __float_as_uint(b1); r[6] = __float_as_uint(b2); r[7] = 0u;
-    r[8] = (uint32_t)set; r[9] = __float_as_uint(tau); r[10] = 0u; r[11] = 0u;
+    r[8] = (uint32_t)set; r[9] = __float_as_uint(tau);
+    r[R_GLO] = (uint32_t)gset; r[R_GHI] = (uint32_t)(gset >> 32) & 0x0fffffffu;
 }
 
 // The tile's record in LDS, as the hand-out reads it (ds_read_b128 each): dword index into its DV dwords.  The first REC
@@ -414,8 +416,7 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     }
     if constexpr (MODEL == NDDM_ALPHA_NOT_SCALED) {
         if (Ap->out_ext && fresh_lane(lane) == 0 && t0 == 0) {
-            const unsigned long long gset = Ap->set_offset + (unsigned long long)set_in_call;
-            AuxStream<FAST> aux(kbase, (uint32_t)gset, (uint32_t)(gset >> 32) & 0x0fffffffu, 0xffffffffu);
+            AuxStream<FAST> aux(kbase, d[D_SETLO], d[D_C3], 0xffffffffu);                           // the set's global index
             const float loc = (Ap->ext_mode == 0) ? Ap->params[set_in_call * T::P + 1] : 1.0f;     // Alpha of the set
             Ap->out_ext[set_in_call] = __builtin_fmaf(Ap->ext_sigma, aux.normal(0), loc);
         }
@@ -579,9 +580,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             const int vset = sic * TPS + qt;
             uint32_t *d = slot_rec(slot);
             if (lane < REC) d[lane] = rec;
-            // everything about the set is wave-uniform: scalar arithmetic
-            const unsigned long long gset = R->set_offset + (unsigned long long)sic;
-            const uint32_t s_lo = (uint32_t)gset, s_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
+            // everything about the set is wave-uniform: scalar arithmetic.  Its global index comes with the record
+            const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)rec, R_GLO);
+            const uint32_t s_hi = (uint32_t)__builtin_amdgcn_readlane((int)rec, R_GHI);
             if (lane == 0) {
                 d[D_VSET] = (uint32_t)vset;
                 if constexpr (MODEL == NDDM_SINGLE_TRIAL || MODEL == NDDM_SINGLE_TRIAL_ALT) { d[D_ZSUM] = 0u; d[D_ZSUM + 1] = 0u; d[D_ZSUM + 2] = 0u; d[D_ZSUM + 3] = 0u; }

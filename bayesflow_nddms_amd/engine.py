@@ -92,12 +92,16 @@ def validate_params_host(model, params):
 
 def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
              bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, packed=False, want_trials=True, want_summary=True, want_ext=False,
-             out_trials=None, out_summary=None, stream_state=None, device=None):
+             out_trials=None, out_summary=None, stream_state=None, device=None, set_offset_dev=None):
     """Run one batched simulation on the current ROCm device.
 
     params: array-like or torch tensor [B, P] (or [P]) in the reference's parameter order.
     packed=True selects NDDM_GAUSS_PACKED (include/nddm.h): 8 normals per Philox block from 16 + 16 bit pairs, ~25 % faster,
     a different random stream; not with the bridge, max_steps < 2^14.
+
+    set_offset_dev: optional device int64 tensor [1]; the global index of row 0 is then set_offset + its value WHEN THE
+    LAUNCH RUNS (nddm_simulate_indirect) -- a launch captured into a hipGraph moves along the random stream by a captured
+    `set_offset_dev += B` instead of new kernel arguments.
 
     Returns a dict of torch tensors on the device: 'trials' f32 [B, n_trials, 2], 'summary' f32 [B, 10],
     'ext' f32 [B] (alpha_not_scaled only), plus 'seed' / 'set_offset' actually used.
@@ -170,7 +174,13 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
         pt = lambda t: None if t is None else t.data_ptr()
         if B > 0:
             common = (B, n_trials, float(dt), max_k, seed, set_offset, flags)
-            if model == BASIC_DDM_DC:
+            if set_offset_dev is not None:
+                if not (isinstance(set_offset_dev, torch.Tensor) and set_offset_dev.is_cuda and set_offset_dev.dtype == torch.int64
+                        and set_offset_dev.numel() >= 1):
+                    raise ValueError("set_offset_dev must be a device int64 tensor")
+                rc = L.nddm_simulate_indirect(model, pt(p_dev), pt(b_dev), *common[:-1], set_offset_dev.data_ptr(), flags,
+                                              float(ext_sigma), int(ext_mode), pt(out_trials), pt(out_summary), pt(out_ext), st)
+            elif model == BASIC_DDM_DC:
                 rc = L.nddm_basic_ddm_dc_simulate(pt(p_dev), *common, pt(out_trials), pt(out_summary), st)
             elif model == SINGLE_TRIAL:
                 rc = L.nddm_single_trial_simulate(pt(p_dev), *common, pt(out_trials), pt(out_summary), st)
@@ -199,16 +209,23 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     return res
 
 
-def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device=None):
-    """On-device batched draw_prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102): f32 [B, P]."""
+def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device=None, set_offset_dev=None, out=None):
+    """On-device batched draw_prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102): f32 [B, P].
+    set_offset_dev: as in simulate() (nddm_draw_prior_indirect)."""
     torch = require_device()
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     P = NPARAMS[model]
     with torch.cuda.device(dev):
-        out = torch.empty((int(batch_size), P), dtype=torch.float32, device=dev)
-        rc = _lib.lib().nddm_draw_prior(model, int(batch_size), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                        int(set_offset) & 0xFFFFFFFFFFFFFFFF, float(gamma), out.data_ptr(),
-                                        torch.cuda.current_stream(dev).cuda_stream)
+        if out is None:
+            out = torch.empty((int(batch_size), P), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if set_offset_dev is not None:
+            rc = _lib.lib().nddm_draw_prior_indirect(model, int(batch_size), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                     int(set_offset) & 0xFFFFFFFFFFFFFFFF, set_offset_dev.data_ptr(),
+                                                     float(gamma), out.data_ptr(), st)
+        else:
+            rc = _lib.lib().nddm_draw_prior(model, int(batch_size), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                            int(set_offset) & 0xFFFFFFFFFFFFFFFF, float(gamma), out.data_ptr(), st)
         _lib.check(rc)
     return out
 
@@ -255,6 +272,27 @@ class debug_trace:
         pulls = d[8 * self.waves:]
         return {"blocks": float(rec[:, 0].sum()), "refills": float(rec[:, 1].sum()), "cycles": float(rec[:, 2].sum()),
                 "ticks": float(rec[:, 3].sum()), "waves": int(rec.shape[0]), "records": rec, "pulls": pulls[pulls > 0]}
+
+
+def release_graph_memory():
+    """Free the device memory the library holds for launches that were captured into hipGraphs on the current device
+    (include/nddm.h: nddm_release_graph_memory).  Call only after every such graph has been destroyed."""
+    _lib.check(_lib.lib().nddm_release_graph_memory())
+
+
+class graph_memory:
+    """Owner of the library memory behind captured launches: `with engine.graph_memory(): ...capture, replay, delete the
+    graphs...` releases it on exit.  Every captured launch pins an allocation of its own (queue words + scratch) until
+    then, so a loop that re-captures -- one graph per n_trials bucket, say -- grows without an owner (amortizer.GraphTrainer
+    is one)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        require_device().cuda.synchronize()
+        release_graph_memory()
+        return False
 
 
 def last_launch():

@@ -1,0 +1,274 @@
+"""BASELINE config 5 GPU-bound: the online training loop of the reference (basic_ddm_dc.py:163-176, 199-202 -- a
+generative model feeding `trainer.train_*(batch_size=32)`) with every iteration ONE hipGraph replay:
+
+    device prior -> simulate (HIP kernels, C ABI) -> configurator -> DeepSet + coupling flow forward -> backward
+    -> gradient clipping -> Adam (+ cosine learning-rate schedule, + the loss stored into a device buffer)
+
+The eager loop (amortizer.Trainer) spends ~10 ms of host time per iteration launching ~1000 small kernels and reads the
+loss back every step; the MI355X is busy for a few per cent of it.  Here the host's share of an iteration is: draw the
+batch-shared N (a pure function of (seed, iteration), distributed.shared_prior_N), write it to the device, replay a graph.
+
+What makes the iteration capturable:
+  * the random stream moves WITHOUT new kernel arguments: the simulator and the prior sampler add a 64-bit offset they
+    read from device memory when they run (include/nddm.h: nddm_simulate_indirect / nddm_draw_prior_indirect), and the
+    graph itself advances that word;
+  * N varies per batch (basic_ddm_dc.py:50-52, 131): it is BUCKETED -- 16 buckets over 60..300, one graph per bucket,
+    captured lazily -- the batch is simulated with the bucket's top number of trials and the summary network pools over
+    the first N only (mask + 1/N from a device scalar), which equals pooling the unpadded batch: trial i of a set is the
+    same function of (seed, set, i) whatever the launch's n_trials;
+  * the loss is written to a device buffer indexed by the device-side step counter and read back when training ends (or on
+    request), not every step; the learning rate is a device tensor computed in the graph from the same counter.
+
+More than one rank (`world` > 1, one process per GPU): `parallel='gather'` keeps north_star's shape -- every rank simulates
+its shard, ONE all-gather reassembles the minibatch, every rank runs the same training step (replicated); `parallel='ddp'`
+shards the training too -- every rank trains on its own shard and the flat gradient buffer is all-reduced.  The collective
+sits BETWEEN two graphs (simulate [+ forward/backward] | collective | [forward/backward +] clip + Adam): RCCL calls are not
+captured.
+
+PyTorch is plumbing here (autograd, GEMMs, graphs); the simulator is the library's.  Parity with BayesFlow's networks is
+unpinned as for amortizer.py.
+"""
+import math
+
+import torch
+
+from . import engine
+from .distributed import shared_prior_N
+
+_PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5)}
+
+
+class _Bucket:
+    __slots__ = ("n_top", "params", "trials", "g_params", "g_trials", "graphs")
+
+
+class GraphTrainer:
+    def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=16, dt=0.01,
+                 max_steps=400.0, seed=2023, learning_rate=5e-4, clip=5.0, device=None, use_graph=True,
+                 world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic"):
+        """total_steps: length of the cosine schedule and capacity of the loss buffer.  use_graph=False runs the SAME
+        iteration eagerly (the comparator of the parity test).  split: force the two-graph form (the one used with a
+        collective in the middle) at world 1."""
+        if parallel not in ("gather", "ddp"):
+            raise ValueError("parallel must be 'gather' or 'ddp'")
+        torch_ = engine.require_device()
+        assert torch_ is torch
+        self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.amortizer = amortizer.to(self.dev)
+        self.model_id, self.P = _PRIOR_MODEL[model]
+        self.B, self.T = int(batch_size), int(total_steps)
+        self.n_min, self.n_max, self.n_buckets = int(n_min), int(n_max), int(n_buckets)
+        self.width = -(-(self.n_max - self.n_min + 1) // self.n_buckets)
+        self.dt, self.max_steps, self.seed = float(dt), float(max_steps), int(seed)
+        self.lr0, self.clip = float(learning_rate), float(clip)
+        self.use_graph = bool(use_graph)
+        self.world, self.rank, self.parallel, self.backend = int(world), int(rank), parallel, backend
+        self.split = (self.world > 1) if split is None else bool(split)
+        self.iteration = 0
+        with torch.cuda.device(self.dev):
+            # parameters' gradients are views of ONE flat buffer (+ 1 slot that carries the loss through the all-reduce)
+            self.params = [p for p in self.amortizer.parameters() if p.requires_grad]
+            n_el = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(n_el + 1, dtype=torch.float32, device=self.dev)
+            self.n_el, o = n_el, 0
+            for p in self.params:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.lr_t = torch.tensor(self.lr0, dtype=torch.float32, device=self.dev)
+            self.optimizer = torch.optim.Adam(self.params, lr=self.lr_t, capturable=True, foreach=True)
+            # device-side counters and scalars
+            self.offset = torch.tensor([self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
+            self.step_i = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.step_f = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            self.n_f = torch.full((1,), float(self.n_max), dtype=torch.float32, device=self.dev)
+            self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
+            self.arange = torch.arange(self.n_max, dtype=torch.float32, device=self.dev)
+            # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
+            self.optimizer.step()
+            for st in self.optimizer.state.values():
+                st["step"].zero_()
+        self._buckets = {}
+        # everything the trainer enqueues -- warm-up passes, captures, replays -- goes to ONE stream of its own: autograd's
+        # gradient-accumulation nodes remember the stream they were first used on, and capture needs a non-default one
+        self._stream = torch.cuda.Stream(device=self.dev)
+        self._comm = torch.cuda.Stream(device=self.dev)
+        self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
+        self._closed = False
+
+    # ------------------------------------------------------------------------------------------------ the iteration
+    def bucket_top(self, n):
+        return min(self.n_max, self.n_min + self.width * ((n - self.n_min) // self.width + 1) - 1)
+
+    def _simulate(self, bk):
+        """This rank's shard of the batch: prior draws and trials, both keyed by the global row index (offset word)."""
+        engine.draw_prior_device(self.model_id, self.B, seed=self.seed, set_offset=0, set_offset_dev=self.offset,
+                                 out=bk.params, device=self.dev)
+        engine.simulate(self.model_id, bk.params, bk.n_top, dt=self.dt, max_steps=self.max_steps, seed=self.seed,
+                        set_offset=0, set_offset_dev=self.offset, fast=True, want_summary=False, out_trials=bk.trials,
+                        device=self.dev)
+        self.offset += self.B * self.world
+
+    def _forward_backward(self, params, trials):
+        """configurator (basic_ddm_dc.py:139-160) on device scalars + maximum-likelihood loss + backward into the flat buffer."""
+        n_top = trials.shape[1]
+        mask = (self.arange[:n_top] < self.n_f).to(torch.float32).view(1, n_top, 1)
+        conf = {"summary_conditions": trials, "summary_mask": (mask, 1.0 / self.n_f),
+                "direct_conditions": torch.log(self.n_f).view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
+                "parameters": params}
+        loss = self.amortizer.compute_loss(conf)
+        self.flat.zero_()
+        loss.backward()
+        self.flat[self.n_el:].copy_(loss.detach().view(1))
+
+    def _update(self, scale):
+        """cosine schedule, clip_grad_norm_(5.0) on the flat gradient, Adam, loss into the history buffer."""
+        g = self.flat[:self.n_el]
+        if scale != 1.0:
+            self.flat.mul_(scale)                                     # mean over ranks (gradients and the loss slot)
+        self.lr_t.copy_((0.5 * self.lr0 * (1.0 + torch.cos(self.step_f * (math.pi / max(1, self.T))))).view(()))
+        coef = torch.clamp(self.clip / (g.norm() + 1e-6), max=1.0)
+        g.mul_(coef)
+        self.optimizer.step()
+        self.loss_buf.index_copy_(0, torch.clamp(self.step_i, max=self.loss_buf.numel() - 1), self.flat[self.n_el:])
+        self.step_i += 1
+        self.step_f += 1.0
+
+    def _collective(self, bk):
+        """The exchange step between the two graphs -- on a communication stream of its own, never on the stream that
+        captures: the process group's watchdog thread polls the events of its collectives (recorded on the stream they were
+        issued on), and HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent aborts the process)."""
+        self._comm.wait_stream(self._stream)
+        with torch.cuda.stream(self._comm):
+            self._collective_on_current_stream(bk)
+        self._stream.wait_stream(self._comm)
+
+    def _collective_on_current_stream(self, bk):
+        import torch.distributed as dist
+        if self.parallel == "gather":
+            for dst, src in ((bk.g_trials, bk.trials), (bk.g_params, bk.params)):
+                if self.backend == "nccl":
+                    dist.all_gather_into_tensor(dst, src)
+                else:
+                    dist.all_gather(list(dst.unbind(0)), src)
+        else:
+            dist.all_reduce(self.flat)
+
+    def _part_a(self, bk):
+        self._simulate(bk)
+        if self.parallel == "ddp" or not self._has_collective():
+            self._forward_backward(bk.params, bk.trials)
+
+    def _part_b(self, bk):
+        if self.parallel == "gather" and self._has_collective():
+            self._forward_backward(bk.g_params.view(-1, self.P), bk.g_trials.view(-1, bk.n_top, 2))
+        self._update(1.0 / self.world if (self.parallel == "ddp" and self._has_collective()) else 1.0)
+
+    def _has_collective(self):
+        import torch.distributed as dist
+        return self.world > 1 or (self.split and dist.is_available() and dist.is_initialized())
+
+    def _eager_iteration(self, bk):
+        self._part_a(bk)
+        if self._has_collective():
+            self._collective(bk)
+        self._part_b(bk)
+
+    # ------------------------------------------------------------------------------------------------ graphs
+    def _mutable(self):
+        ts = list(self.params) + [self.offset, self.step_i, self.step_f, self.lr_t, self.n_f]
+        for st in self.optimizer.state.values():
+            ts += [st["step"], st["exp_avg"], st["exp_avg_sq"]]
+        return ts
+
+    def _bucket(self, n_top):
+        bk = self._buckets.get(n_top)
+        if bk is not None:
+            return bk
+        bk = _Bucket()
+        bk.n_top = n_top
+        with torch.cuda.device(self.dev):
+            bk.params = torch.empty((self.B, self.P), dtype=torch.float32, device=self.dev)
+            bk.trials = torch.empty((self.B, n_top, 2), dtype=torch.float32, device=self.dev)
+            bk.g_params = bk.g_trials = None
+            if self.parallel == "gather" and self._has_collective():
+                bk.g_params = torch.empty((self.world, self.B, self.P), dtype=torch.float32, device=self.dev)
+                bk.g_trials = torch.empty((self.world, self.B, n_top, 2), dtype=torch.float32, device=self.dev)
+            bk.graphs = None
+            if self.use_graph:
+                # one eager pass at this shape first (GEMM heuristics, workspaces, autograd buffers), on a side stream, with
+                # every piece of state it touches put back afterwards: capturing must not cost an iteration
+                with torch.no_grad():
+                    snap = [t.clone() for t in self._mutable()]
+                self._eager_iteration(bk)
+                with torch.no_grad():
+                    for t, s0 in zip(self._mutable(), snap):
+                        t.copy_(s0)
+                torch.cuda.synchronize(self.dev)
+                parts = [lambda: self._part_a(bk), lambda: self._part_b(bk)] if (self.split or self._has_collective()) \
+                    else [lambda: (self._part_a(bk), self._part_b(bk))]
+                bk.graphs = []
+                for fn in parts:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
+                    # default (global) capture mode turns into an error that kills the process
+                    with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
+                        fn()
+                    bk.graphs.append(g)
+        self._buckets[n_top] = bk
+        return bk
+
+    def train_online(self, iterations):
+        """`iterations` training steps; returns nothing -- losses stay on the device until loss_history()."""
+        self._stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
+            for _ in range(int(iterations)):
+                n = shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max)     # batch-shared N (basic_ddm_dc.py:50-52, 131)
+                self.n_f.fill_(float(n))
+                bk = self._bucket(self.bucket_top(n))
+                if bk.graphs is None:
+                    self._eager_iteration(bk)
+                elif len(bk.graphs) == 1:
+                    bk.graphs[0].replay()
+                else:
+                    bk.graphs[0].replay()
+                    if self._has_collective():
+                        self._collective(bk)
+                    bk.graphs[1].replay()
+                self.iteration += 1
+        torch.cuda.current_stream(self.dev).wait_stream(self._stream)
+
+    def loss_history(self):
+        """The losses of the iterations run so far (one device synchronisation)."""
+        self._stream.synchronize()
+        return self.loss_buf[:min(self.iteration, self.loss_buf.numel())].cpu().numpy().tolist()
+
+    @property
+    def n_graphs(self):
+        return sum(len(b.graphs) for b in self._buckets.values() if b.graphs)
+
+    # ------------------------------------------------------------------------------------------------ ownership
+    def close(self):
+        """Destroy the graphs, then hand the library's memory behind their captured launches back (the trainer owns it:
+        include/nddm.h, nddm_release_graph_memory)."""
+        if self._closed:
+            return
+        self._closed = True
+        torch.cuda.synchronize(self.dev)
+        had = any(b.graphs for b in self._buckets.values())
+        self._buckets.clear()
+        if had:
+            with torch.cuda.device(self.dev):
+                engine.release_graph_memory()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass

@@ -71,14 +71,28 @@ def parse():
     ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle baseline sample")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="BASELINE configs[0] at its stated size: the NumPy port on 500 sets x 300 trials at dt=.001/4000 and "
-                         "dt=.01/400 (about a minute of CPU time)")
+    ap.add_argument("--cpu-sample", action="store_true",
+                    help="time the NumPy port (BASELINE configs[0]) on 12 / 60 parameter sets instead of its stated 500 sets x 300 "
+                         "trials at dt=.001/4000 and dt=.01/400 (the default; about 35 s of CPU time)")
+    ap.add_argument("--cpu-full", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--no-ks", action="store_true")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the lockstep run that measures the VALU ceiling")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --share-device rehearse the multi-process path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dist", action="store_true",
+                    help="take the multi-rank code path whatever the world size: process group (RCCL for --backend nccl) with "
+                         "device_id, barrier(device_ids), the all-gather of --gather, the device-side all_reduce(MAX) of the "
+                         "elapsed time.  With --gpus 1 this runs every distributed call of the 8-GPU job on one GPU")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="issue the minibatch all-gather on the simulate stream (serialised) instead of on a communication "
+                         "stream with double-buffered outputs")
+    ap.add_argument("--train-mode", choices=["graph", "eager", "both"], default="both",
+                    help="--train: one hipGraph replay per iteration (GraphTrainer), the eager PyTorch loop, or both side by side")
+    ap.add_argument("--train-parallel", choices=["gather", "ddp"], default="gather",
+                    help="--train at world > 1: 'gather' = all-gather the simulated shards and train the same minibatch on every "
+                         "rank (replicated training, north_star's all-gather); 'ddp' = every rank trains on its own shard and the "
+                         "gradients are all-reduced (sharded training)")
     ap.add_argument("--train", action="store_true", help="BASELINE config 5: online simulation feeding the amortizer")
     ap.add_argument("--train-iters", type=int, default=150)
     ap.add_argument("--batch", type=int, default=32, help="--train: parameter sets per rank per training step")
@@ -86,22 +100,40 @@ def parse():
 
 
 # --------------------------------------------------------------------------------------------------- launcher
+def free_port():
+    import socket
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_gpus():
+    """Number of GPUs a worker would see, asked of a THROWAWAY child process: the launcher itself never loads the HIP runtime
+    (its children must be fresh processes, and a process that has touched the GPU must not be re-executed)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same command, one per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), wait for
     them and exit with the worst status.  Nothing in THIS process has touched the GPU or imported torch: the workers
     are children, never an exec of a process that initialised HIP.  Rank 0 prints the JSON line on the inherited
     stdout."""
-    import socket
     import subprocess
-    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # as torch.distributed.run does: N ranks each starting os.cpu_count() host threads oversubscribe the box (measured:
+        # a gloo all-gather of 6 MB takes 230 ms instead of 5 with 2 x 256 threads on a 16-core share)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst, alive = 0, list(procs)
     while alive:
@@ -152,13 +184,13 @@ def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
            "all_cores": {"value": vm, "cores": cores, "host_cpu_count": os.cpu_count(),
                          "sample": f"{Sm} sets, OpenMP over sets with {cores} threads, {tm:.1f} s"}}
     # the pure-Python/NumPy algorithm the reference runs when numba is absent (numba is not installed here): BASELINE
-    # configs[0].  Default: a bounded sample at the bench's dt and at the reference default dt=.01/400; --cpu-full: the
-    # stated 500 sets x 300 trials at both step sizes.
+    # configs[0].  Default: the stated 500 sets x 300 trials, at the bench's dt and at the reference default dt=.01/400
+    # (about 35 s); --cpu-sample: 12 / 60 sets.
     port = {"basic": numpy_port.basic_simulate_trials, "single": numpy_port.single_simulate_trials}.get(model_name)
     if port is not None:
         legs = {}
-        for tag, (pdt, pms, n_sets) in {"bench_dt": (dt, max_steps, 500 if a.cpu_full else 12),
-                                        "reference_default_dt.01_max400": (0.01, 400.0, 500 if a.cpu_full else 60)}.items():
+        for tag, (pdt, pms, n_sets) in {"bench_dt": (dt, max_steps, 12 if a.cpu_sample else 500),
+                                        "reference_default_dt.01_max400": (0.01, 400.0, 60 if a.cpu_sample else 500)}.items():
             np.random.seed(2023)
             rows = params[:n_sets, :7].astype(np.float64) if model_name == "single" else params[:n_sets].astype(np.float64)
             t0 = time.perf_counter()
@@ -170,7 +202,7 @@ def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
         out["numpy_port"] = dict(legs["bench_dt"], what="pure-Python/NumPy statement of the reference simulator "
                                  "(basic_ddm_dc.py:85-125 / single_trial_alpha_not_scaled.py:107-155; numba not installed)",
                                  host_cpu_count=os.cpu_count(), reference_default=legs["reference_default_dt.01_max400"],
-                                 full_config_1=bool(a.cpu_full))
+                                 full_config_1=not a.cpu_sample)
     return out
 
 
@@ -313,9 +345,13 @@ def worker(a):
         sys.exit("bench.py needs a ROCm GPU (no CPU fallback)")
     if a.share_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+                 f"(--share-device puts every rank on cuda:0)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or a.dist                     # --dist: the multi-rank code path at any world size
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -324,18 +360,18 @@ def worker(a):
     from bayesflow_nddms_amd import _lib, engine
     from bayesflow_nddms_amd import priors as prior_util
     ctx = dict(world=world, rank=rank, local_rank=local_rank, dev=dev, torch=torch, dist=dist, engine=engine, _lib=_lib,
-               prior_util=prior_util)
+               prior_util=prior_util, dist_on=dist_on)
     if a.train:
         train_bench(a, ctx)
     else:
         simulate_bench(a, ctx)
-    if world > 1:
+    if dist_on:
         barrier(a, ctx)
         dist.destroy_process_group()
 
 
 def barrier(a, ctx):
-    if ctx["world"] > 1:
+    if ctx["dist_on"]:
         if a.backend == "nccl":
             ctx["dist"].barrier(device_ids=[ctx["local_rank"]])
         else:
@@ -356,41 +392,81 @@ def simulate_bench(a, ctx):
     # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
     p_host = getattr(prior_util, prior_fn)(B, 2023 + rank)
     p_dev = torch.as_tensor(p_host).to(dev)
-    out_trials = None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev)
-    out_summary = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
+    # Output buffers.  With a minibatch all-gather (north_star's reassembly step) the collective runs on a COMMUNICATION
+    # stream and the outputs are double-buffered: step i+1's simulate is enqueued before step i's gather is waited on, so the
+    # two overlap (at weak scale the gather of the trials moves as many bytes over xGMI as the simulate
+    # takes time for).  A buffer is handed to the simulator again only after the gather that reads it has completed.
+    dist_on = ctx["dist_on"]
+    gather_on = dist_on and a.gather != "none"
+    if a.gather == "trials" and a.summary_only:
+        sys.exit("--gather trials needs the trials: drop --summary-only")
+    overlap = gather_on and not a.no_overlap
+    nbuf = 2 if overlap else 1
+    buf_trials = [None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    buf_summary = [torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     gathered = None
-    if world > 1 and a.gather != "none":
-        src = out_summary if a.gather == "summary" else out_trials
-        gathered = torch.empty((world,) + tuple(src.shape), dtype=torch.float32, device=dev)
+    if gather_on:
+        shape = tuple((buf_summary if a.gather == "summary" else buf_trials)[0].shape)
+        gathered = [torch.empty((world,) + shape, dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    # the communication stream has the higher priority: when a gather and the next simulate become runnable together the
+    # collective's few workgroups are placed first, and the persistent simulator grid (which otherwise holds every wave slot
+    # of the chip until its queue is empty) fills what is left
+    comm = torch.cuda.Stream(device=dev, priority=-1) if overlap else None
+    pending = [None] * nbuf                              # the gather in flight on buffer b
 
-    def step(i):
+    def all_gather(dst, src, async_op):
+        if a.backend == "nccl":
+            return dist.all_gather_into_tensor(dst, src, async_op=async_op)     # one RCCL all-gather per batch
+        return dist.all_gather(list(dst.unbind(0)), src, async_op=async_op)     # gloo rehearsal: list form
+
+    def step(i, ev=None):
         # every step is a fresh batch: global set index = (i*world + rank)*B + row, one seed
+        b = i % nbuf
+        if pending[b] is not None:
+            pending[b].wait()                           # (RCCL: the simulate stream waits, the host does not)
+            pending[b] = None
+        if ev is not None:
+            ev[0].record()                              # torch's current stream == the stream the kernel is launched on
         engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
-                        set_offset=(i * world + rank) * B, fast=fast, out_trials=out_trials, out_summary=out_summary,
+                        set_offset=(i * world + rank) * B, fast=fast, out_trials=buf_trials[b], out_summary=buf_summary[b],
                         want_trials=not a.summary_only, bridge=bridge, packed=packed)
-        if gathered is not None:
-            src = out_summary if a.gather == "summary" else out_trials
-            if a.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, src)              # one RCCL all-gather per batch
-            else:                                                       # gloo rehearsal: list form
-                dist.all_gather(list(gathered.unbind(0)), src)
+        if ev is not None:
+            ev[1].record()
+        if gather_on:
+            src = buf_summary[b] if a.gather == "summary" else buf_trials[b]
+            if overlap:
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    pending[b] = all_gather(gathered[b], src, True)
+            else:
+                all_gather(gathered[b], src, False)
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for i in range(a.warmup):
         step(i)
+    drain()
     barrier(a, ctx)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ev[i][0].record()              # torch's current stream == the stream the kernel is launched on
-        step(a.warmup + i)
-        ev[i][1].record()
+        step(a.warmup + i, ev[i])
+    drain()
     barrier(a, ctx)
     elapsed = time.perf_counter() - t0
     geometry = engine.last_launch()          # the timed launches' kernel variant, grid, ring, tiles (outside the timed region)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    last = (a.warmup + a.steps - 1) % nbuf       # the buffers the last step wrote
+    out_trials, out_summary = buf_trials[last], buf_summary[last]
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     if rank != 0:
         return
@@ -414,7 +490,9 @@ def simulate_bench(a, ctx):
                    "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
                    "gauss": a.gauss, "arithmetic": ARITHMETIC,
                    "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
-                   "parallelism": f"dp{world} over parameter sets, gather={a.gather}"},
+                   "parallelism": f"dp{world} over parameter sets, gather={a.gather}"
+                                  + (", all-gather on a communication stream, double-buffered outputs" if overlap else "")
+                                  + (f", distributed code path forced at world {world} ({a.backend})" if a.dist else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": KERNEL_NAME[a.model] % a.gauss,
@@ -506,99 +584,138 @@ def simulate_bench(a, ctx):
 def train_bench(a, ctx):
     """BASELINE config 5: basic_ddm_dc online simulation feeding the amortizer (PyTorch-ROCm DeepSet + coupling flow),
     the reference's training loop shape (basic_ddm_dc.py:199-202: batch 32, N ~ U{60..300} shared by the batch, dt=.01
-    / max_steps=400), simulation sharded over the ranks with ONE all-gather per minibatch.  Per rank and step: draw 32
-    parameter sets on the device (counter-based prior), simulate them, all-gather trials + parameters, one Adam step on
-    the gathered minibatch of 32*G sets (every rank holds the same batch and the same weights: no gradient exchange).
-    Reports iterations/s for prefetch off/on, the simulate launch in isolation (eager and as a hipGraph replay), and the
-    simulator's share of a step."""
+    / max_steps=400), simulation sharded over the ranks.  Per rank and step: draw `--batch` parameter sets on the device
+    (counter-based prior), simulate them, then either all-gather trials + parameters and run the same Adam step on the
+    gathered minibatch on every rank (--train-parallel gather: replicated training, north_star's all-gather) or train on
+    the local shard and all-reduce the gradients (--train-parallel ddp: sharded training).
+
+    Two drivers of the same loop are measured side by side (--train-mode):
+      eager  amortizer.Trainer: eager PyTorch, one loss read-back per step (round 2's figure; prefetch off / on)
+      graph  graph_trainer.GraphTrainer: one hipGraph replay per iteration (prior -> simulate -> forward -> backward ->
+             clip -> Adam captured; one graph per n_trials bucket), losses read back once at the end
+    plus the simulate launch in isolation (eager and as a hipGraph replay)."""
     world, rank, dev, torch, dist, engine = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine"))
+    dist_on = ctx["dist_on"]
     from bayesflow_nddms_amd import basic_ddm_dc
     from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
     from bayesflow_nddms_amd.distributed import shared_prior_N
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
     from bayesflow_nddms_amd.priors import DevicePrior
-    Bl = a.batch
+    Bl, warm = a.batch, 10
+    if a.train_parallel == "ddp" and a.train_mode != "graph":
+        sys.exit("--train-parallel ddp is implemented by the graph trainer: use --train-mode graph")
     results = {}
     for tag, dt, ms in (("dt.01_max400", 0.01, 400.0), ("dt.001_max4000", 0.001, 4000.0)):
-        prior = DevicePrior("basic", seed=2023)
-        counter = {"i": 0}
-
-        def generative_model(batch_size, dt=dt, ms=ms, prior=prior, counter=counter):
-            i = counter["i"]; counter["i"] += 1
-            n = shared_prior_N(2023, i)                                   # batch-shared N, no communication
-            base = i * batch_size * world
-            p = prior(batch_size, set_offset=base + rank * batch_size)    # this rank's rows of the global batch
-            r = engine.simulate(engine.BASIC_DDM_DC, p, n, dt=dt, max_steps=ms, seed=2023,
-                                set_offset=base + rank * batch_size, fast=True, want_summary=False)
-            data, pd = r["trials"], p
-            if world > 1:
-                gd = torch.empty((world,) + tuple(data.shape), dtype=torch.float32, device=dev)
-                gp = torch.empty((world,) + tuple(p.shape), dtype=torch.float32, device=dev)
-                if a.backend == "nccl":
-                    dist.all_gather_into_tensor(gd, data); dist.all_gather_into_tensor(gp, p)
-                else:
-                    dist.all_gather(list(gd.unbind(0)), data); dist.all_gather(list(gp.unbind(0)), p)
-                data, pd = gd.reshape(-1, n, 2), gp.reshape(-1, p.shape[1])
-            return {"prior_draws": pd, "sim_data": data, "sim_non_batchable_context": n}
-
         leg = {}
-        for prefetch in (False, True):
+        if a.train_mode in ("eager", "both"):
+            prior = DevicePrior("basic", seed=2023)
+            counter = {"i": 0}
+
+            def generative_model(batch_size, dt=dt, ms=ms, prior=prior, counter=counter):
+                i = counter["i"]; counter["i"] += 1
+                n = shared_prior_N(2023, i)                                   # batch-shared N, no communication
+                base = i * batch_size * world
+                p = prior(batch_size, set_offset=base + rank * batch_size)    # this rank's rows of the global batch
+                r = engine.simulate(engine.BASIC_DDM_DC, p, n, dt=dt, max_steps=ms, seed=2023,
+                                    set_offset=base + rank * batch_size, fast=True, want_summary=False)
+                data, pd = r["trials"], p
+                if dist_on:
+                    gd = torch.empty((world,) + tuple(data.shape), dtype=torch.float32, device=dev)
+                    gp = torch.empty((world,) + tuple(p.shape), dtype=torch.float32, device=dev)
+                    if a.backend == "nccl":
+                        dist.all_gather_into_tensor(gd, data); dist.all_gather_into_tensor(gp, p)
+                    else:
+                        dist.all_gather(list(gd.unbind(0)), data); dist.all_gather(list(gp.unbind(0)), p)
+                    data, pd = gd.reshape(-1, n, 2), gp.reshape(-1, p.shape[1])
+                return {"prior_draws": pd, "sim_data": data, "sim_non_batchable_context": n}
+
+            for prefetch in (False, True):
+                torch.manual_seed(0)
+                amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+                trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, device=dev)
+                counter["i"] = 0
+                trainer.train_online(epochs=1, iterations_per_epoch=warm, batch_size=Bl, save_checkpoint=False, prefetch=prefetch)
+                barrier(a, ctx)
+                t0 = time.perf_counter()
+                trainer.train_online(epochs=1, iterations_per_epoch=a.train_iters, batch_size=Bl, save_checkpoint=False,
+                                     prefetch=prefetch)
+                barrier(a, ctx)
+                el = time.perf_counter() - t0
+                h = trainer.loss_history
+                leg["eager_prefetch_on" if prefetch else "eager_prefetch_off"] = {
+                    "iterations_per_s": a.train_iters / el, "ms_per_iteration": el / a.train_iters * 1e3,
+                    "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:]))}
+            # training step alone on a fixed batch (no simulation)
+            fixed = basic_ddm_dc.configurator(generative_model(Bl))
+            for _ in range(5):
+                trainer._step(fixed)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.train_iters):
+                trainer._step(fixed)
+            torch.cuda.synchronize()
+            leg["eager_train_step_alone_ms"] = (time.perf_counter() - t0) / a.train_iters * 1e3
+        if a.train_mode in ("graph", "both"):
             torch.manual_seed(0)
             amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
-            trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, device=dev)
-            counter["i"] = 0
-            trainer.train_online(epochs=1, iterations_per_epoch=10, batch_size=Bl, save_checkpoint=False, prefetch=prefetch)
-            barrier(a, ctx)
-            t0 = time.perf_counter()
-            trainer.train_online(epochs=1, iterations_per_epoch=a.train_iters, batch_size=Bl, save_checkpoint=False,
-                                 prefetch=prefetch)
-            barrier(a, ctx)
-            el = time.perf_counter() - t0
-            h = trainer.loss_history
-            leg["prefetch_on" if prefetch else "prefetch_off"] = {
-                "iterations_per_s": a.train_iters / el, "ms_per_iteration": el / a.train_iters * 1e3,
-                "loss_first10": float(np.mean(h[10:20])), "loss_last10": float(np.mean(h[-10:]))}
-        # training step alone on a fixed batch (no simulation): what is left of an iteration is the simulator's share
-        fixed = basic_ddm_dc.configurator(generative_model(Bl))
-        for _ in range(5):
-            trainer._step(fixed)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.train_iters):
-            trainer._step(fixed)
-        torch.cuda.synchronize()
-        t_train = (time.perf_counter() - t0) / a.train_iters
-        leg["train_step_alone_ms"] = t_train * 1e3
-        leg["simulator_share_of_step_no_prefetch"] = max(0.0, 1.0 - t_train / (leg["prefetch_off"]["ms_per_iteration"] * 1e-3))
-        leg["simulator_share_of_step_prefetch"] = max(0.0, 1.0 - t_train / (leg["prefetch_on"]["ms_per_iteration"] * 1e-3))
+            with GraphTrainer(amortizer, batch_size=Bl, total_steps=warm + 2 * a.train_iters, dt=dt, max_steps=ms, seed=2023,
+                              device=dev, world=world, rank=rank, parallel=a.train_parallel, backend=a.backend,
+                              split=dist_on) as gt:
+                # (1) the first pass captures a graph whenever N falls into a new bucket: timed as "with capture"
+                barrier(a, ctx)
+                t0 = time.perf_counter()
+                gt.train_online(warm + a.train_iters)
+                barrier(a, ctx)
+                t_first = time.perf_counter() - t0
+                n_graphs = gt.n_graphs
+                # (2) steady state: the same number of iterations again (most buckets exist by now)
+                t0 = time.perf_counter()
+                gt.train_online(a.train_iters)
+                t_host = time.perf_counter() - t0                        # host time to enqueue the iterations
+                barrier(a, ctx)
+                el = time.perf_counter() - t0
+                h = gt.loss_history()
+                leg["graph"] = {"iterations_per_s": a.train_iters / el, "ms_per_iteration": el / a.train_iters * 1e3,
+                                "host_enqueue_ms_per_iteration": t_host / a.train_iters * 1e3,
+                                "gpu_bound": bool(t_host < 0.9 * el),
+                                "first_pass_ms_per_iteration_with_captures": t_first / (warm + a.train_iters) * 1e3,
+                                "graphs_captured": gt.n_graphs, "graphs_captured_in_first_pass": n_graphs,
+                                "buckets": gt.n_buckets, "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:])),
+                                "parallel": a.train_parallel if world > 1 else "one rank",
+                                "two_graphs_with_collective_between": bool(dist_on)}
+            if "eager_prefetch_on" in leg:
+                leg["graph_over_eager"] = leg["graph"]["iterations_per_s"] / max(leg["eager_prefetch_on"]["iterations_per_s"],
+                                                                                leg["eager_prefetch_off"]["iterations_per_s"])
         # the simulate launch in isolation at the mean shape (Bl sets x 180 trials, device-resident): eager vs graph replay
-        p = prior(Bl, set_offset=0)
+        p = DevicePrior("basic", seed=2023)(Bl, set_offset=0)
         out = torch.empty((Bl, 180, 2), dtype=torch.float32, device=dev)
         kw = dict(dt=dt, max_steps=ms, seed=2023, set_offset=0, fast=True, out_trials=out, want_summary=False)
         for _ in range(20):
             engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
         torch.cuda.synchronize()
-        n_rep = 500
+        n_rep = 300
         t0 = time.perf_counter()
         for _ in range(n_rep):
             engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
         t_host = (time.perf_counter() - t0) / n_rep                     # host time to enqueue
         torch.cuda.synchronize()
         t_eager = (time.perf_counter() - t0) / n_rep
-        side = torch.cuda.Stream(device=dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
-                engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
-        torch.cuda.synchronize()
-        for _ in range(20):
-            g.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_rep):
-            g.replay()
-        torch.cuda.synchronize()
-        t_graph = (time.perf_counter() - t0) / n_rep
-        # one launch, GPU time only
+        with engine.graph_memory():                                     # owns the library memory behind the captured launch
+            side = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):      # (a process group's watchdog may be polling)
+                    engine.simulate(engine.BASIC_DDM_DC, p, 180, **kw)
+            torch.cuda.synchronize()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
+                g.replay()
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / n_rep
+            del g
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
@@ -608,20 +725,31 @@ def train_bench(a, ctx):
         leg["simulate_launch_us"] = {"shape": f"{Bl} sets x 180 trials, device-resident parameters", "eager_back_to_back": t_eager * 1e6,
                                      "eager_host_enqueue": t_host * 1e6, "hipgraph_replay": t_graph * 1e6,
                                      "gpu_time_back_to_back": e0.elapsed_time(e1) / 50 * 1e3}
-        del g
+        if "graph" in leg:
+            leg["simulator_share_of_graph_iteration"] = leg["simulate_launch_us"]["gpu_time_back_to_back"] * 1e-3 / leg["graph"]["ms_per_iteration"]
         results[tag] = leg
     if rank == 0:
-        ref = results["dt.01_max400"]["prefetch_on"]
+        main_leg = results["dt.01_max400"]
+        ref = main_leg.get("graph") or main_leg["eager_prefetch_on"]
+        driver = "one hipGraph replay per iteration (GraphTrainer)" if "graph" in main_leg else "eager PyTorch loop (Trainer)"
+        if world == 1:
+            par = "one rank"
+        elif a.train_parallel == "gather" or "graph" not in main_leg:
+            par = (f"dp{world}: simulation sharded, one all-gather per minibatch, training step REPLICATED on every rank "
+                   f"(each trains the same {Bl * world} sets)")
+        else:
+            par = f"dp{world}: simulation AND training sharded ({Bl} sets per rank), flat gradient all-reduce"
         print(json.dumps({
             "metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE config 5)",
-            "value": ref["iterations_per_s"], "unit": "iterations/s", "n_gpus": world, "steps": a.train_iters, "warmup": 10,
+            "value": ref["iterations_per_s"], "unit": "iterations/s", "n_gpus": world, "steps": a.train_iters, "warmup": warm,
             "ms_per_step": ref["ms_per_iteration"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"basic_ddm_dc online training feed: {Bl} sets per rank per step (minibatch {Bl * world}), "
                                    f"N ~ U{{60..300}} per batch, dt=.01/max 400 (reference default; dt=.001/4000 also reported), "
-                                   f"device prior -> simulate -> all-gather -> DeepSet + 6-layer coupling flow, Adam",
-                       "arithmetic": ARITHMETIC, "parallelism": f"dp{world}: simulation sharded, one all-gather per minibatch, "
-                                                                  f"replicated training step", "backend": a.backend},
+                                   f"device prior -> simulate -> DeepSet + 6-layer coupling flow, Adam; {driver}",
+                       "arithmetic": ARITHMETIC, "parallelism": par, "backend": a.backend,
+                       "train_mode": a.train_mode},
+            "loss_first10": ref["loss_first10"], "loss_last10": ref["loss_last10"],
             "train": results}), flush=True)
 
 
@@ -630,7 +758,14 @@ def main():
     if a.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if not a.share_device:
+            have = visible_gpus()
+            if a.gpus > have:
+                sys.exit(f"bench.py: --gpus {a.gpus} but this node shows {have} GPU(s); nothing was started "
+                         f"(--share-device --backend gloo rehearses the multi-rank path on one GPU)")
         launch_ranks(a.gpus)                         # does not return
+    if "WORLD_SIZE" not in os.environ and a.dist:    # one rank, distributed code path: be our own launcher
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     worker(a)
 
 

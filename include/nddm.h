@@ -23,7 +23,9 @@
  *     that launch until the work it enqueued has COMPLETED (reuse is keyed on stream order or on a completion event, never
  *     on a launch count); the developer knobs (nddm_set_tuning, nddm_set_debug_trace) are read once, atomically, at entry.
  *   - hipGraph: a call made while `stream` is capturing is recorded as kernels only; the memory such a launch needs is
- *     allocated for that launch alone and lives until nddm_release_graph_memory().  Seed and set_offset are baked in.
+ *     allocated for that launch alone and lives until nddm_release_graph_memory().  Seed and set_offset are baked in;
+ *     nddm_simulate_indirect / nddm_draw_prior_indirect add a 64-bit offset read from DEVICE memory when the kernels run,
+ *     so a replayed graph moves along the random stream (a captured `*dev += B` between replays).
  *
  * Deliberate deviations from the boundary sketched for this path:
  *   - arithmetic is float32 on the device (state w, the Gaussian transform) with an INTEGER step index, so
@@ -43,7 +45,10 @@
 extern "C" {
 #endif
 
-#define NDDM_ABI_VERSION 1
+/* 2: the default Gaussian stream takes the angle from the LOW 23 bits of its word (round 2), the bridge-uniform stream
+ *    serves 8 steps per block (round 3), nddm_set_debug_counters became nddm_set_debug_trace, and the *_indirect entry
+ *    points and nddm_source_hash exist.  The same (seed, set_offset) gives different bits under ABI 1. */
+#define NDDM_ABI_VERSION 2
 #define NDDM_SUMMARY_K 10
 
 /* summary_stats[b, :] (single_trial_alpha_not_scaled.py:205-211,
@@ -183,12 +188,30 @@ int nddm_simulate(int32_t model, const float *params, const float *bounds, int64
                   int32_t max_steps, uint64_t seed, uint64_t set_offset, uint32_t flags, float ext_sigma, int32_t ext_mode,
                   float *out_trials, float *out_summary, float *out_extdata, void *stream);
 
+/* nddm_simulate with a device-resident part of the set offset: the global index of row 0 is
+ * set_offset + *set_offset_dev, read by the launch's pre-pass kernel when it RUNS on `stream` (set_offset_dev: device u64,
+ * NULL = 0).  For hipGraph capture: the graph bakes kernel arguments in, the word in device memory moves between replays
+ * (the training loop of basic_ddm_dc.py:199-202 as one graph per iteration).  The sum must stay below 2^60; it is reduced
+ * modulo 2^60 on the device, where it cannot be refused. */
+int nddm_simulate_indirect(int32_t model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
+                           int32_t max_steps, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags,
+                           float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
+                           void *stream);
+
 /* ---- prior / context samplers (basic_ddm_dc.py:50-80, single_trial_alpha_not_scaled.py:66-102) -------
  * On-device batched draw_prior(): out device f32 [B, P] in the model's parameter order
  * (P = nddm_model_nparams; gamma column of the single-trial family is filled with `gamma`).
  * Stream: Philox key (seed), counter (draw, 0, row_lo, row_hi | 2<<28). */
 int nddm_draw_prior(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, float gamma, float *out_params,
                     void *stream);
+
+/* the same with a device-resident part of the row offset (see nddm_simulate_indirect) */
+int nddm_draw_prior_indirect(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev,
+                             float gamma, float *out_params, void *stream);
+
+/* sha256 (hex) of the sources the library was built from, as build.py computed it ("unknown" for a hand-made build): the
+ * Python binding refuses a library whose sources have changed since */
+const char *nddm_source_hash(void);
 
 /* ---- debugging aid used by the parity tests: the 4 normals of Philox block (c0..c3) under key (k0,k1) --- */
 int nddm_debug_normals(const uint32_t *counters /* device u32 [n,4] */, int64_t n, uint32_t k0, uint32_t k1,

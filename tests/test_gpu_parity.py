@@ -456,3 +456,82 @@ def test_kernel_variants_and_geometry_do_not_change_results():
     finally:
         _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
     assert seen == {0, 1}
+
+
+@pytest.mark.parametrize("B", [32, 3000])
+def test_indirect_set_offset_equals_direct_and_moves_a_replayed_graph(B):
+    """nddm_simulate_indirect / nddm_draw_prior_indirect (include/nddm.h): the global index of row 0 is set_offset + a
+    64-bit word read from DEVICE memory when the launch runs.  Same bits as passing the sum directly (all the models whose
+    kernels read the set index in different places: path stream, latent FIFO, external datum), and a captured
+    [prior -> simulate -> word += B] moves along the random stream on every replay with no new kernel arguments."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    off = torch.tensor([2**33 + 12345], dtype=torch.int64, device="cuda")
+    direct = 1000 + 2**33 + 12345
+    for model, prior in ((engine.BASIC_DDM_DC, prior_util.basic_prior), (engine.SINGLE_TRIAL, prior_util.single_prior),
+                         (engine.ALPHA_NOT_SCALED, prior_util.alpha_ns_prior)):
+        p = torch.as_tensor(prior(B, 4)).cuda()
+        kw = dict(dt=.01, max_steps=400, seed=9, fast=True, want_ext=(model == engine.ALPHA_NOT_SCALED), ext_sigma=0.1)
+        a = engine.simulate(model, p, 77, set_offset=1000, set_offset_dev=off, **kw)
+        b = engine.simulate(model, p, 77, set_offset=direct, **kw)
+        assert torch.equal(a["trials"], b["trials"]) and torch.equal(torch.nan_to_num(a["summary"]), torch.nan_to_num(b["summary"]))
+        if "ext" in b:
+            assert torch.equal(a["ext"], b["ext"])
+    pa = engine.draw_prior_device(engine.BASIC_DDM_DC, B, seed=5, set_offset=1000, set_offset_dev=off)
+    pb = engine.draw_prior_device(engine.BASIC_DDM_DC, B, seed=5, set_offset=direct)
+    assert torch.equal(pa, pb)
+    # a captured iteration that advances its own offset
+    word = torch.zeros(1, dtype=torch.int64, device="cuda")
+    pr = torch.empty((B, 5), device="cuda")
+    out = torch.empty((B, 120, 2), device="cuda")
+    summ = torch.empty((B, 10), device="cuda")
+
+    def iteration():
+        engine.draw_prior_device(engine.BASIC_DDM_DC, B, seed=5, set_offset=0, set_offset_dev=word, out=pr)
+        engine.simulate(engine.BASIC_DDM_DC, pr, 120, dt=.01, max_steps=400, seed=6, set_offset=0, set_offset_dev=word,
+                        fast=True, out_trials=out, out_summary=summ)
+        word.add_(B)
+
+    with engine.graph_memory():
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            iteration()                                   # warm-up (moves the word)
+            torch.cuda.synchronize()
+            word.zero_()
+            with torch.cuda.graph(g, stream=side):
+                iteration()
+        for i in range(4):
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(word.item()) == (i + 1) * B
+            p_ref = engine.draw_prior_device(engine.BASIC_DDM_DC, B, seed=5, set_offset=i * B)
+            r = engine.simulate(engine.BASIC_DDM_DC, p_ref, 120, dt=.01, max_steps=400, seed=6, set_offset=i * B, fast=True)
+            assert torch.equal(pr, p_ref) and torch.equal(out, r["trials"])
+            assert torch.equal(torch.nan_to_num(summ), torch.nan_to_num(r["summary"]))
+        del g
+
+
+def test_ring_span_limit_of_the_tuning_override(oracle_mod):
+    """The hand-out packs the current slot's byte offset and the signed step to the next slot into 16 + 16 bits, so the
+    ring's slots must span < 32 KB: a tuning override beyond that is refused with ValueError instead of
+    wrapping silently, and the largest geometry below the limit (28 slots x 512 trials = 31,360 B) is bit-equal to the
+    oracle."""
+    from bayesflow_nddms_amd import _lib, engine
+    p = prior_util.basic_prior(40, 8)
+    L = _lib.lib()
+    try:
+        _lib.check(L.nddm_set_tuning(0, 48, 0, 0, 0, 512))
+        with pytest.raises(ValueError, match="span < 32 KB"):
+            engine.simulate(engine.BASIC_DDM_DC, p, 1024, dt=.01, max_steps=400, seed=3, set_offset=0, fast=False)
+        _lib.check(L.nddm_set_tuning(0, 64, 0, 0, 0, 300))          # 64 x 696 B: the example of the advisor's report
+        with pytest.raises(ValueError, match="span < 32 KB"):
+            engine.simulate(engine.BASIC_DDM_DC, p, 300, dt=.01, max_steps=400, seed=3, set_offset=0, fast=False)
+        _lib.check(L.nddm_set_tuning(0, 28, 0, 0, 0, 512))
+        g = engine.simulate(engine.BASIC_DDM_DC, p, 1024, dt=.01, max_steps=400, seed=3, set_offset=0, fast=False)
+        assert engine.last_launch()["ring"] == 28 and engine.last_launch()["tile_trials"] == 512
+    finally:
+        L.nddm_set_tuning(0, 0, 0, 0, 0, 0)
+    o = oracle_mod.philox_simulate(oracle_mod.M_BASIC, p, 1024, dt=.01, max_steps=400, seed=3, set_offset=0, threads=4)
+    assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))

@@ -232,3 +232,83 @@ def test_per_thread_default_stream_handle():
     assert not errors, errors
     for t, s in outs:
         assert torch.equal(t, ref["trials"]) and torch.equal(torch.nan_to_num(s), torch.nan_to_num(ref["summary"]))
+
+
+def _hip_runtime():
+    """The HIP runtime this process already uses (torch's copy), through ctypes: raw hipStreamCreate / hipStreamDestroy."""
+    import ctypes
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    assert path, "libamdhip64 is not mapped"
+    hip = ctypes.CDLL(path)
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    return hip
+
+
+def test_destroyed_stream_with_work_in_flight_and_a_recycled_handle():
+    """A C-ABI caller may destroy a stream whose last launches are still in flight and create a new one: handle values
+    are recycled.  The library's "same stream as last time" slot reuse must not hand the old stream's queue words to
+    the new stream while the old launch runs (it now waits on the slot's completion event).  Raw HIP streams and direct
+    C-ABI calls, as a C caller would make them (no torch object ever refers to the destroyed stream): a stream gets a long
+    launch and small ones queued behind it and is destroyed at once; new streams are created until the handle value
+    repeats (or 64 times) and launches go out on each; every result equals the serial reference."""
+    import ctypes
+    import torch
+    from bayesflow_nddms_amd import _lib, engine
+    hip, L = _hip_runtime(), _lib.lib()
+    p_dev = torch.as_tensor(prior_util.basic_prior(200000, 13)).cuda()
+    shapes = [(24 + 8 * i, 60 + 20 * i) for i in range(8)]                      # (B, N) of the small launches
+
+    def launch(stream, B, N, seed, out, summ):
+        _lib.check(L.nddm_basic_ddm_dc_simulate(p_dev.data_ptr(), B, N, 0.01, 400, seed, 0, 1, out.data_ptr(), summ.data_ptr(),
+                                                ctypes.c_void_p(stream)))
+
+    def buffers(B, N):
+        return torch.empty((B, N, 2), device="cuda"), torch.empty((B, 10), device="cuda")
+
+    ref = []
+    for i, (B, N) in enumerate(shapes):
+        o, s = buffers(B, N)
+        launch(None, B, N, 50 + i, o, s)
+        ref.append((o, s))
+    big_o, big_s = buffers(200000, 300)
+    torch.cuda.synchronize()
+    h = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+    old = h.value
+    _lib.check(L.nddm_basic_ddm_dc_simulate(p_dev.data_ptr(), 200000, 300, 0.001, 4000, 1, 0, 1, big_o.data_ptr(), big_s.data_ptr(),
+                                            ctypes.c_void_p(old)))                # ~7 ms of GPU time in front of the small launches
+    got_old = []
+    for i, (B, N) in enumerate(shapes):
+        o, s = buffers(B, N)
+        launch(old, B, N, 50 + i, o, s)
+        got_old.append((o, s))
+    assert hip.hipStreamDestroy(ctypes.c_void_p(old)) == 0      # work still pending: HIP finishes it, the handle is gone
+    made, got_new, recycled = [], [], False
+    for j in range(64):
+        h2 = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h2)) == 0
+        made.append(h2.value)
+        for i in ((j % len(shapes),) if h2.value != old else range(len(shapes))):
+            o, s = buffers(*shapes[i])
+            launch(h2.value, shapes[i][0], shapes[i][1], 50 + i, o, s)
+            got_new.append((i, o, s))
+        if h2.value == old:
+            recycled = True
+            break
+    torch.cuda.synchronize()
+    for i, (o, s) in enumerate(got_old):
+        assert _same(torch, o, ref[i][0]) and _same(torch, s, ref[i][1]), ("destroyed stream", i)
+    for i, o, s in got_new:
+        assert _same(torch, o, ref[i][0]) and _same(torch, s, ref[i][1]), ("new stream", i, recycled)
+    for v in made:
+        assert hip.hipStreamDestroy(ctypes.c_void_p(v)) == 0
+    # the library keeps working on torch's streams afterwards
+    r = engine.simulate(engine.BASIC_DDM_DC, p_dev[:shapes[0][0]], shapes[0][1], dt=0.01, max_steps=400, seed=50, set_offset=0, fast=True)
+    torch.cuda.synchronize()
+    assert _same(torch, r["trials"], ref[0][0]) and _same(torch, r["summary"], ref[0][1])

@@ -26,7 +26,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/nddm.h but not exported"
     assert set(syms) <= set(_lib.EXPORTS)
-    assert _lib.lib().nddm_abi_version() == 1
+    assert _lib.lib().nddm_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().nddm_source_hash().decode() == build.source_hash()
     assert _lib.lib().nddm_summary_k() == 10
     assert [_lib.lib().nddm_model_nparams(m) for m in range(6)] == [5, 8, 8, 6, 4, -1]
 
@@ -213,8 +214,10 @@ def test_shard_bounds_cover_and_partition():
 
 
 def test_bench_launcher_without_gpu_fails_loudly():
-    """bench.py --gpus 2 starts two fresh ranks; on a box without a GPU both refuse loudly (no CPU fallback) and the
-    launcher exits non-zero; a WORLD_SIZE that contradicts --gpus is refused before anything else happens."""
+    """bench.py --gpus N with more ranks than the node has GPUs is refused by the PARENT, before any rank is started (it asks
+    a throwaway child for the device count and never loads HIP itself); with --share-device two fresh ranks start, and on
+    a box without a GPU both refuse loudly (no CPU fallback) and the launcher exits non-zero; a WORLD_SIZE that contradicts
+    --gpus is refused before anything else happens."""
     import subprocess
     import sys
     import torch
@@ -224,6 +227,10 @@ def test_bench_launcher_without_gpu_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sets", "10", "--steps", "1"],
                        capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 2 but this node shows 0 GPU(s); nothing was started" in r.stderr and "{" not in r.stdout
+    assert "needs a ROCm GPU" not in r.stderr                       # no rank ever ran
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+                        "--sets", "10", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and r.stderr.count("needs a ROCm GPU") >= 1 and "{" not in r.stdout
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--sets", "10", "--steps", "1"],
                        capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
@@ -251,3 +258,43 @@ def test_ezdiff_matches_reference_known_answers():
         ez.ezdiff(np.array([0.5]), np.array([1.0, 1.0]))                   # length mismatch
     bad = np.zeros((2, 10)); bad[1, 0] = 5; bad[1, 5] = 0.4                 # row 0: nothing; row 1: zero variance
     assert np.isnan(ez.ez_from_summary(bad)).all()
+
+
+def test_staleness_is_decided_by_content_not_by_file_times(tmp_path):
+    """build.is_stale() compares the sha256 of the sources (and flags) with the hash compiled into the library: touching a
+    source leaves the library fresh, a snapshot with reordered mtimes does not trigger a rebuild."""
+    from bayesflow_nddms_amd import build
+    assert build.embedded_hash() == build.source_hash() and not build.is_stale()
+    src = build.SOURCES[0]
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime, os.path.getmtime(build.SO_PATH) + 1000.0))      # newer than the library
+        assert not build.is_stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    fake = tmp_path / "lib.so"
+    fake.write_bytes(b"\x7fELF....NDDM_SRC_HASH=" + b"0" * 64 + b"\0")
+    assert build.embedded_hash(str(fake)) == "0" * 64 and build.embedded_hash(str(tmp_path / "absent.so")) is None
+
+
+def test_graph_trainer_buckets_and_masked_pooling_equal_the_unpadded_batch():
+    """The n_trials buckets of graph_trainer (one hipGraph per bucket): 16 buckets cover 60..300, every N maps to a top >=
+    N within one bucket width; and the summary network on a batch PADDED to the bucket top with (mask, 1/N) equals the
+    network on the unpadded batch."""
+    import torch
+    from bayesflow_nddms_amd.amortizer import InvariantNetwork
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+    gt = GraphTrainer.__new__(GraphTrainer)
+    gt.n_min, gt.n_max, gt.n_buckets = 60, 300, 16
+    gt.width = -(-(gt.n_max - gt.n_min + 1) // gt.n_buckets)
+    tops = sorted({gt.bucket_top(n) for n in range(60, 301)})
+    assert len(tops) == 16 and tops[-1] == 300
+    assert all(0 <= gt.bucket_top(n) - n < gt.width for n in range(60, 301))
+    torch.manual_seed(1)
+    net = InvariantNetwork()
+    x = torch.randn(5, 91, 2)
+    n = 77
+    mask = (torch.arange(91) < n).float().view(1, 91, 1)
+    x_pad = x.clone()
+    x_pad[:, n:] = 1e3 * torch.randn(5, 91 - n, 2)                      # whatever the padding holds
+    assert torch.allclose(net(x_pad, mask, torch.tensor(1.0 / n)), net(x[:, :n]), atol=2e-5)

@@ -42,7 +42,9 @@ def waves_by_vgpr(v):
 
 def collect():
     with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run(["hipcc", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-std=c++17", "-c",
+        sys.path.insert(0, ROOT)
+        from bayesflow_nddms_amd.build import _hipcc
+        r = subprocess.run([_hipcc(), "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-std=c++17", "-c",
                             "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "k.o"), SRC],
                            capture_output=True, text=True, check=True)
     rows, cur = [], None
