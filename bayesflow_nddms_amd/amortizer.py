@@ -23,12 +23,38 @@ import torch
 from torch import nn
 
 
+class _PerSetLinearFn(torch.autograd.Function):
+    """y = x W^T + b for x [B, N, in] with the weight gradient computed per set and then summed: as ONE GEMM it is a
+    [in, B*N] x [B*N, out] product with a 64 x 64 result -- two workgroups on a 256-CU chip, 50 us at B*N = 9600 -- as a
+    batched GEMM over the B sets it is 6 us (+ a 32-row sum).  14 such products are a fifth of a graph-replayed iteration."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x.reshape(-1, x.shape[-1]), w.t()).view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = (g.reshape(-1, g.shape[-1]) @ w).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(g.transpose(1, 2), x).sum(0)
+        return gx, gw, g.sum((0, 1))
+
+
+class _Linear(nn.Linear):
+    def forward(self, x):
+        if x.dim() == 3 and x.is_cuda and torch.is_grad_enabled():
+            return _PerSetLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _mlp(d_in, d_hidden, d_out, n_hidden=2, act=nn.ReLU, keras_init=True):
     layers, d = [], d_in
     for _ in range(n_hidden):
-        layers += [nn.Linear(d, d_hidden), act()]
+        layers += [_Linear(d, d_hidden), act()]
         d = d_hidden
-    layers.append(nn.Linear(d, d_out))
+    layers.append(_Linear(d, d_out))
     # Keras-style initialisation (the reference's networks are BayesFlow/Keras Dense layers: Glorot weights, zero biases),
     # with He scaling on the hidden layers: PyTorch's Linear default shrinks the signal by ~0.58 per layer, and through the ~15
     # stacked layers of the summary network the data-dependent part of its output was 1e-5 of the bias-driven part at
