@@ -280,7 +280,7 @@ template <int MODEL, bool BRIDGE>
 static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, size_t lds_bytes, int n_chunks, int cus,
                         int grid_override, bool grid_forced, hipStream_t st)
 {
-    const bool cap4 = (A.max_k % (packed ? 8 : 4)) == 0;     // the step cap falls on a block boundary
+    const bool cap4 = (A.max_k % ((packed || BRIDGE) ? 8 : 4)) == 0;     // the step cap falls on a block boundary (bridge, packed: 8 steps per pass)
     const bool small = A.res16 == 2;
     constexpr bool HAS_VKEYS = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED || MODEL == NDDM_EXPLICIT_BOUNDARY);
 #define NDDM_ARGS A, fast, cap4, lds_bytes, n_chunks, cus, grid_override, grid_forced, st

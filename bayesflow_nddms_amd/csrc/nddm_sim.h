@@ -441,7 +441,7 @@ __device__ __forceinline__ bool in_range(float w, float h)
 
 
 // MODEL: enum nddm_model.  FAST: Gaussian transform.  SMALL: see below.  CAP4: max_steps is a multiple of 4, so the step cap is tested
-// once per Philox block instead of once per step.  BRIDGE: Brownian-bridge boundary correction (between two grid
+// once per Philox block instead of once per step (BRIDGE, PACKED: a multiple of 8, once per 8 steps).  BRIDGE: Brownian-bridge boundary correction (between two grid
 // points inside (0, a) the path still crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt))), which removes
 // the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama -- used for alpha_not_scaled, whose reference
 // generator is an exact first-passage sampler.
@@ -502,7 +502,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
     float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
     int k = 0;
-    uint32_t jit = 0;
+    // BRIDGE only: t0 = h - |w|, the distance to the nearer boundary carried from step to step; jraw = the crossing-uniform
+    // word of the trial's current step pair (its jitter bits are taken when the trial retires).  With the bridge, k counts the
+    // steps a trial SURVIVED: a trial that crossed at its (k+1)-th step stops with k < max_k, one that ran to the cap with
+    // k == max_k -- no crossed-flag is carried
+    [[maybe_unused]] float t0 = 0.0f;
+    [[maybe_unused]] uint32_t jraw = 0;
     uint32_t res_addr = 0;   // LDS byte address (relative to the slots) of the trial's staged result
     [[maybe_unused]] int tile = 0;   // !SMALL only: wave-local sequence number of the tile this lane works on
     bool invalid = false;
@@ -606,9 +611,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         // ------------------------------------------------------------ retire finished trials
         const unsigned long long fin_mask0 = has_m & ~act_m;
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
-            const uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
+            uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
             uint32_t tfix = (uint32_t)k;
-            if constexpr (BRIDGE) tfix = ((uint32_t)k << 8) - ((code == 1u || code == 2u) ? jit : 0u);
+            if constexpr (BRIDGE) {
+                // started: the trial began inside (0, a); stepped: ... and ended by crossing a boundary (at a grid point or, by
+                // the bridge test, between two) at step k + 1; otherwise it ran to the cap (k == max_k: timeout) or never moved
+                const bool started = t0 > 0.0f;
+                const bool stepped = started && k < A.max_k;
+                code = (stepped || !started) ? (w >= 0.0f ? 1u : 2u) : 0u;
+                // time in 1/256 step: the crossing step's index minus an 8-bit uniform jitter (the crossing happened somewhere
+                // inside the step), taken from the bits of the pair's word that the step's own decision did not use: bits 0..7
+                // for the pair's first step, 16..23 for its second
+                const uint32_t jit = (k & 1) ? ((jraw >> 16) & 0xffu) : (jraw & 0xffu);
+                tfix = (((uint32_t)k + (stepped ? 1u : 0u)) << 8) - (stepped ? jit : 0u);
+            }
             if (SMALL || rshift == 1) *reinterpret_cast<lds_u16 *>(res_addr + (SLOTS_OFF + DV * 4)) = (uint16_t)(tfix | (code << 14));
             else *reinterpret_cast<lds_u32 *>(res_addr + (SLOTS_OFF + DV * 4)) = tfix | (code << 30);
         }
@@ -765,12 +781,13 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
                 }
                 k = 0;
-                jit = 0;
+                if constexpr (BRIDGE) { t0 = h - __builtin_fabsf(w); jraw = 0u; }
             }
             if constexpr (LATENT) { const int n_ok = (int)__popcll(ok_mask); fifo_pos += n_ok; fifo_avail -= n_ok; }
             // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
             // are masked by has_m)
-            act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            if constexpr (BRIDGE) act_m = __builtin_amdgcn_ballot_w64(t0 > 0.0f) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            else act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
         // leave the loop for a refill once refill_thresh lanes hold a finished trial, or none is stepping, or after
@@ -784,7 +801,94 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const int leave_at = occupied < A.refill_thresh ? occupied : A.refill_thresh;
         int it = 0;
         for (;; ++it) {
-            [[maybe_unused]] bool active = (!BRIDGE && CAP4 && !PACKED) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
+            if constexpr (BRIDGE) {
+                // ---- Brownian-bridge stepping: 8 steps per pass -- two blocks of the path stream (counters k, k + 4: the
+                // stream of the plain kernel) and ONE block of stream 3, whose four words serve two steps each: the first
+                // step of a pair takes the whole word as a 32-bit uniform, the second its low 16 bits.
+                // A step from w to w1 ends the trial -- boundary side = sign(w1) -- when
+                //     u < exp(-2 d0 d1),   d0 = h - |w|,  d1 = h - |w1|    (noise units; 2^(-4 d0 d1) in the fast transform's),
+                // the probability that a Brownian bridge between two points on the same side of the interval's centre touched
+                // the nearer boundary; for d1 <= 0 (w1 outside: the crossing plain Euler-Maruyama sees) the right-hand side is
+                // >= 1 > u, so ONE compare decides both -- and narrows EXEC itself (v_cmpx).  The far boundary's bridge
+                // probability, <= exp(-2 h^2), is dropped: < 2^-23 as soon as the boundaries are 5.7 single-step standard
+                // deviations apart, below which an Euler-Maruyama path is no approximation of anything.
+                // d1 is carried to the next step as its d0; k counts the steps SURVIVED (incremented behind the compare).
+                const uint32_t blk = (uint32_t)k;                        // a multiple of 8 in every lane that is stepping
+                const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);    // stream 3, same constant folding as the path stream
+                __builtin_amdgcn_sched_barrier(0);       // (interleaved with the next block the two generators need 66 VGPRs: 7 waves)
+                unsigned long long &live = act_m;        // the lanes still stepping: narrowed in place (SGPR pairs are scarce here)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const u32x4 rb = philox4x32_10_path(blk + 4u * (uint32_t)half, pc, kbase);
+                    float r0, r1, c0, c1, c2, c3;
+                    polar_pair<FAST, true>(rb.x, rb.y, r0, c0, c1);
+                    polar_pair<FAST, true>(rb.z, rb.w, r1, c2, c3);
+                    const uint32_t ua = half ? u4.z : u4.x, ub = half ? u4.w : u4.y;
+                    if constexpr (FAST && CAP4) {
+                        float t1, m, uf;
+                        // per step: w1; d1; d0*d1; 2^(K - 4 d0 d1) with K = 32 (+ 1 ulp, so that "outside" beats a uniform that
+                        // rounds up to 2^32) or 16: the uniform's scale; the uniform's conversion (it also fills the slot a
+                        // transcendental's result needs before a VALU instruction may read it on gfx950); compare -> EXEC;
+                        // survivors count the step and carry d1.  The lane mask goes in and comes out in one SGPR pair.
+#define NDDM_BSTEP(R, T, CVT, KLIT) "v_fmac_f32 %[w], %[" R "], %[" T "]\n\tv_add_f32 %[w], %[mu], %[w]\n\tv_sub_f32 %[t1], %[h], |%[w]|\n\t" \
+    "v_mul_f32 %[m], %[t0], %[t1]\n\tv_fmaak_f32 %[m], -4.0, %[m], " KLIT "\n\tv_exp_f32 %[m], %[m]\n\t" CVT                    \
+    "v_cmpx_ge_f32_e64 vcc, %[uf], %[m]\n\tv_add_u32 %[k], 1, %[k]\n\tv_mov_b32 %[t0], %[t1]\n\t"
+#define NDDM_U32(W) "v_cvt_f32_u32 %[uf], %[" W "]\n\t"
+#define NDDM_U16(W) "v_and_b32 %[uf], 0xffff, %[" W "]\n\tv_cvt_f32_u32 %[uf], %[uf]\n\t"
+                        asm volatile("s_mov_b64 exec, %[lm]\n\t"
+                                     "v_mov_b32 %[jr], %[ua]\n\t"
+                                     NDDM_BSTEP("r0", "c0", NDDM_U32("ua"), "0x42000001") NDDM_BSTEP("r0", "c1", NDDM_U16("ua"), "0x41800000")
+                                     "v_mov_b32 %[jr], %[ub]\n\t"
+                                     NDDM_BSTEP("r1", "c2", NDDM_U32("ub"), "0x42000001") NDDM_BSTEP("r1", "c3", NDDM_U16("ub"), "0x41800000")
+                                     "s_nop 1\n\ts_mov_b64 %[lm], exec\n\ts_mov_b64 exec, -1"
+                                     : [w] "+v"(w), [k] "+v"(k), [t0] "+v"(t0), [jr] "+v"(jraw), [lm] "+s"(live), [t1] "=&v"(t1), [m] "=&v"(m),
+                                       [uf] "=&v"(uf)
+                                     : [mu] "v"(mu_dt), [h] "v"(h), [r0] "v"(r0), [r1] "v"(r1), [c0] "v"(c0), [c1] "v"(c1),
+                                       [c2] "v"(c2), [c3] "v"(c3), [ua] "v"(ua), [ub] "v"(ub)
+                                     : "vcc");
+#undef NDDM_BSTEP
+#undef NDDM_U32
+#undef NDDM_U16
+                    } else {
+                        // the same steps in C: the exact transform (bit-reproducible on a CPU: oracle/ddm_oracle.c), and
+                        // step caps that are not a multiple of 8 (tested per step)
+                        bool active = __builtin_amdgcn_inverse_ballot_w64(live);
+                        const float rr4[4] = {r0, r0, r1, r1}, tt4[4] = {c0, c1, c2, c3};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (active) {
+                                asm volatile("" ::: "memory");
+                                const uint32_t word = j < 2 ? ua : ub;
+                                const float w1 = __builtin_fmaf(rr4[j], tt4[j], w) + mu_dt;
+                                const float t1 = h - __builtin_fabsf(w1);
+                                const float m = t0 * t1;
+                                if ((j & 1) == 0) jraw = word;
+                                const float uf = (j & 1) ? (float)(word & 0xffffu) : (float)word;
+                                bool cross;
+                                if constexpr (FAST) {
+                                    const float kk = (j & 1) ? 16.0f : __uint_as_float(0x42000001u);
+                                    cross = !(uf >= __builtin_amdgcn_exp2f(__builtin_fmaf(-4.0f, m, kk)));
+                                } else {
+                                    const float u = uf * ((j & 1) ? 1.52587890625e-05f : 2.3283064365386963e-10f);   // 2^-16, 2^-32
+                                    cross = !(t1 > 0.0f) || u < exact_expf_neg(-2.0f * m);
+                                }
+                                w = w1;
+                                if (cross) active = false;
+                                else {
+                                    k++; t0 = t1;
+                                    if constexpr (!CAP4) active = k < A.max_k;
+                                }
+                            }
+                        }
+                        live = __builtin_amdgcn_ballot_w64(active);
+                    }
+                }
+                act_m &= __builtin_amdgcn_ballot_w64(k < A.max_k);
+                if ((int)__popcll(has_m & ~act_m) >= leave_at) break;
+                if (it >= it_limit) break;
+                continue;
+            }
+            [[maybe_unused]] bool active = (CAP4 && !PACKED) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
             // counter word 0 of the path stream = index of the block's first step (a multiple of NS: a lane only starts
             // a block after taking all NS steps of the previous one), so no shift is needed
             constexpr int NS = PACKED ? 8 : 4;
@@ -806,12 +910,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 polar_pair<FAST, true>(rb.z, rb.w, rr[2], tt[2], tt[3]);
                 rr[1] = rr[0]; rr[3] = rr[2];
             }
-            uint32_t ub[4] = {0u, 0u, 0u, 0u};
-            if constexpr (BRIDGE) {
-                const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);          // stream 3, same constant folding as the path stream
-                ub[0] = u4.x; ub[1] = u4.y; ub[2] = u4.z; ub[3] = u4.w;
-            }
-            if constexpr (!BRIDGE && CAP4 && !PACKED) {
+            if constexpr (CAP4 && !PACKED) {
                 // The four steps with the execution mask narrowed by the range compare itself (v_cmpx writes EXEC): fmac, add,
                 // k + 1, compare per step and not one scalar instruction in between.  As the compiler writes `if (active)` a
                 // step carries four (s_and_saveexec, s_cbranch_execz, s_and, s_or), and a SIMD issues one scalar instruction
@@ -842,24 +941,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     // keep this a real exec-masked region: selects through SGPR masks (v_cndmask_e64, ~4.2 cycles
                     // each on gfx950) cost more VALU issue than the predicated add / count they would replace
                     asm volatile("" ::: "memory");
-                    float w1 = __builtin_fmaf(rr[j], tt[j], w) + mu_dt;
-                    if constexpr (BRIDGE) {
-                        if (in_range(w1, h)) {
-                            // P(crossed) = exp(-2 d0 d1 / sigma^2 dt): in noise units the coefficient is a constant
-                            // (exact: -2 with e^x; fast: -2 * 2 ln 2 * log2 e = -4 with v_exp_f32's 2^x)
-                            constexpr float cb = FAST ? -4.0f : -2.0f;
-                            const float eu = cb * ((h - w) * (h - w1));      // distances to the upper boundary
-                            const float el = cb * ((h + w) * (h + w1));      // ... and to the lower one
-                            float pu, pl;
-                            if constexpr (FAST) { pu = __builtin_amdgcn_exp2f(eu); pl = __builtin_amdgcn_exp2f(el); }
-                            else { pu = exact_expf_neg(eu); pl = exact_expf_neg(el); }
-                            const float uu = (float)(ub[j & 3] >> 8) * 5.9604644775390625e-08f;      // [0, 1), 24 bits
-                            if (uu < pu) w1 = h;
-                            else if (uu >= 1.0f - pl) w1 = -h;
-                        }
-                        jit = ub[j & 3] & 0xffu;
-                    }
-                    w = w1;
+                    w = __builtin_fmaf(rr[j], tt[j], w) + mu_dt;
                     k++;
                     if (j < NS - 1) {
                         if constexpr (CAP4) active = in_range(w, h);

@@ -325,7 +325,7 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed,
     finally:
         L.nddm_set_tuning(0, 0, 0, 0, 0, 0)
     steps = float(B) * N * max_k
-    lane_eff = steps / (blocks * 64.0 * (8 if packed else 4))
+    lane_eff = steps / (blocks * 64.0 * (8 if (packed or bridge) else 4))       # steps per pass of the step loop
     sps = steps / (best * 1e-3)
     return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
             "kernel_ms": best, "clock_ghz_in_kernel": clock, "launch": engine.last_launch(),
@@ -510,7 +510,7 @@ def simulate_bench(a, ctx):
         achieved_steps = em_steps / (kern_ms * 1e-3)
         rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-        spb = 8 if packed else 4                     # Euler-Maruyama steps per Philox block
+        spb = 8 if (packed or bridge) else 4         # Euler-Maruyama steps per pass of the step loop (packed: one Philox block; bridge: two + one of crossing uniforms)
         if not a.no_ceiling:
             c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry)
             peak = c["steps_per_s_all_lanes_useful"]

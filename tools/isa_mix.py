@@ -203,7 +203,7 @@ def main():
               "unit": "SIMD cycles per wave64 Philox block (steps_per_block E-M steps x 64 lanes), sum of isolated issue costs", "kernels": {}}
     for name in names:
         r = tally(step_loop(kernel_insts(txt, KERNELS[name])), cost, sgpr_cost)
-        r["steps_per_block"] = 8 if KERNELS[name][5] else 4
+        r["steps_per_block"] = 8 if (KERNELS[name][5] or KERNELS[name][3]) else 4      # packed, bridge: 8 steps per pass
         result["kernels"][name] = r
         print(f"{name}: step loop = {r['valu']} VALU / {r['salu']} SALU / {r['lds']} LDS / {r['vmem']} VMEM instructions per block")
         for m in r["mix"]:

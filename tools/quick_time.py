@@ -48,7 +48,7 @@ def run(B, N, dt, ms, fast=True, tune=None, model=0, reps=3, trials_out=True, lo
     nresp = s[:, 0] + s[:, 1]
     tau = p[:, 3] - (0.5 * dt if bridge else 0.0)
     steps = float(((s[:, 3] - tau) / dt * nresp)[nresp > 0].sum() + s[:, 2].sum() * int(ms))
-    spb = 8 if packed else 4
+    spb = 8 if (packed or bridge) else 4
     cyc = best * 1e-3 * 2.4e9 * 1024 / (steps / 256)            # per 4 steps x 64 lanes, whatever the block size
     resident = d[3] * 1e-5 / span_ms / 1024.0
     print(f"model={model} B={B} N={N} dt={dt} cap={int(ms)} fast={fast} tune={tune} trials_out={trials_out} lockstep={lockstep} bridge={bridge} packed={packed}: "
