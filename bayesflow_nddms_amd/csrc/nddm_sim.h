@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // ring slots: [DV-dword record | staged results], 16-byte aligned.  Staged results: one 32-bit word per trial, or one
     // 16-bit word when the step cap allows (halves the LDS footprint, which is what lets the 7th and 8th wave per SIMD
     // stay resident at 300 trials per set)
-    const int rshift = (SMALL || A.res16) ? 1 : 2;                     // log2 bytes per staged result
+    const int rshift = SMALL ? 1 : (BRIDGE ? 2 : (A.res16 ? 1 : 2));   // log2 bytes per staged result (the bridge's times are 1/256 step: 32 bits)
     constexpr bool LATENT = model_has_latent(MODEL);
     const int stride = DV * 4 + (((N << rshift) + 15) & ~15);          // slot_stride_bytes()
     char *const slots = reinterpret_cast<char *>(lds_raw) + lds_header_bytes(MODEL);
