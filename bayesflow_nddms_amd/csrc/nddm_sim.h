@@ -448,8 +448,9 @@ __device__ __forceinline__ bool in_range(float w, float h)
 // (Tried and dropped: Philox round keys in VGPRs.  A VOP2 xor that reads an SGPR issues at ~4.2 instead of ~2.3
 // cycles on gfx950, but the 20 extra VGPRs cut residency from 7 to 5 waves per SIMD and the net was neutral.)
 // SMALL: results staged as 16-bit words and at most 512 trials per tile -- the shape of every launch that matters for
-// throughput.  A kernel that carries BOTH flush paths (32-bit DPP sums / 64-bit shuffles) needs 79 SGPRs and 60 VGPRs; the
-// SMALL one alone 72 and 44, which is what keeps 8 waves per SIMD resident (the SGPR file limits these kernels).
+// throughput.  A kernel that carries BOTH flush paths (32-bit DPP sums / 64-bit shuffles) needs 68-76 SGPRs and 52-66 VGPRs
+// (basic 68 / 52), the SMALL one alone 55-71 and 42-60 (basic 55 / 42; tools/resource_table.py prints every instantiation),
+// which is what keeps 8 waves per SIMD resident (the SGPR file limits these kernels: <= 74).
 // PACKED: NDDM_GAUSS_PACKED -- 8 Euler-Maruyama steps per Philox block (polar_pair_packed in nddm_rng.h); CAP4 then means
 // "max_steps is a multiple of 8".
 // VKEYS: the Philox round keys of the step loop are held in 13 VGPRs for the whole kernel instead of read from LDS every

@@ -353,6 +353,7 @@ def worker(a):
     dist_on = world > 1 or a.dist                     # --dist: the multi-rank code path at any world size
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")      # the process group's own streams: high priority as well
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -423,7 +424,7 @@ def simulate_bench(a, ctx):
         # every step is a fresh batch: global set index = (i*world + rank)*B + row, one seed
         b = i % nbuf
         if pending[b] is not None:
-            pending[b].wait()                           # (RCCL: the simulate stream waits, the host does not)
+            pending[b].wait()                           # (RCCL: the simulate stream waits for an event, the host does not)
             pending[b] = None
         if ev is not None:
             ev[0].record()                              # torch's current stream == the stream the kernel is launched on
@@ -439,7 +440,16 @@ def simulate_bench(a, ctx):
                 done.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
-                    pending[b] = all_gather(gathered[b], src, True)
+                    if a.backend == "nccl":
+                        # the blocking form runs the collective ON the current stream -- the high-priority communication
+                        # stream, which has a hardware queue of its own; the process group's internal stream (async_op=True)
+                        # was observed sharing the simulate stream's hardware queue, i.e. serialised with the next simulate
+                        # (profiles/r3_dist_overlap.md).  The simulate stream later waits for the event recorded behind it.
+                        all_gather(gathered[b], src, False)
+                        pending[b] = torch.cuda.Event()
+                        pending[b].record(comm)
+                    else:
+                        pending[b] = all_gather(gathered[b], src, True)
             else:
                 all_gather(gathered[b], src, False)
 
