@@ -727,6 +727,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             }
             has_m |= ok_mask;
             if (__builtin_amdgcn_inverse_ballot_w64(ok_mask)) {
+#ifdef NDDM_EXTRA_REFILL_VALU
+                // sensitivity experiment (tools/refill_sensitivity.sh): N extra full-rate VALU instructions per hand-out
+                { uint32_t dummy = (uint32_t)lane;
+#pragma unroll
+                  for (int e = 0; e < NDDM_EXTRA_REFILL_VALU; ++e) asm volatile("v_xor_b32 %0, 0x55, %0" : "+v"(dummy)); }
+#endif
                 const ArgsPtr H = fresh_args(Ak);
                 if constexpr (!SMALL) tile = tl;
                 // LDS byte address of the slot (kbase holds the LDS base: one v_mad_u32_u24), of the trial's result word
