@@ -503,11 +503,14 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
     float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
     int k = 0;
-    // BRIDGE only: t0 = h - |w|, the distance to the nearer boundary carried from step to step; jraw = the crossing-uniform
+    // BRIDGE only: ta / tb = h - |w|, the distance to the nearer boundary carried from step to step; jraw = the crossing-uniform
     // word of the trial's current step pair (its jitter bits are taken when the trial retires).  With the bridge, k counts the
     // steps a trial SURVIVED: a trial that crossed at its (k+1)-th step stops with k < max_k, one that ran to the cap with
     // k == max_k -- no crossed-flag is carried
-    [[maybe_unused]] float t0 = 0.0f;
+    // (the distance lives alternately in ta and tb: a step reads one and writes the other, so survivors need no copy; at
+    // the end of a pass -- an even number of steps -- the current one is ta again.  Both start as h - |w0|: a lane that never
+    // stepped has both <= 0, a lane that stepped has the one its last step READ > 0)
+    [[maybe_unused]] float ta = 0.0f, tb = 0.0f;
     [[maybe_unused]] uint32_t jraw = 0;
     uint32_t res_addr = 0;   // LDS byte address (relative to the slots) of the trial's staged result
     [[maybe_unused]] int tile = 0;   // !SMALL only: wave-local sequence number of the tile this lane works on
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             if constexpr (BRIDGE) {
                 // started: the trial began inside (0, a); stepped: ... and ended by crossing a boundary (at a grid point or, by
                 // the bridge test, between two) at step k + 1; otherwise it ran to the cap (k == max_k: timeout) or never moved
-                const bool started = t0 > 0.0f;
+                const bool started = fmaxf(ta, tb) > 0.0f;
                 const bool stepped = started && k < A.max_k;
                 code = (stepped || !started) ? (w >= 0.0f ? 1u : 2u) : 0u;
                 // time in 1/256 step: the crossing step's index minus an 8-bit uniform jitter (the crossing happened somewhere
@@ -788,12 +791,12 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
                 }
                 k = 0;
-                if constexpr (BRIDGE) { t0 = h - __builtin_fabsf(w); jraw = 0u; }
+                if constexpr (BRIDGE) { ta = h - __builtin_fabsf(w); tb = ta; jraw = 0u; }
             }
             if constexpr (LATENT) { const int n_ok = (int)__popcll(ok_mask); fifo_pos += n_ok; fifo_avail -= n_ok; }
             // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
             // are masked by has_m)
-            if constexpr (BRIDGE) act_m = __builtin_amdgcn_ballot_w64(t0 > 0.0f) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            if constexpr (BRIDGE) act_m = __builtin_amdgcn_ballot_w64(ta > 0.0f) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             else act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 // >= 1 > u, so ONE compare decides both -- and narrows EXEC itself (v_cmpx).  The far boundary's bridge
                 // probability, <= exp(-2 h^2), is dropped: < 2^-23 as soon as the boundaries are 5.7 single-step standard
                 // deviations apart, below which an Euler-Maruyama path is no approximation of anything.
-                // d1 is carried to the next step as its d0; k counts the steps SURVIVED (incremented behind the compare).
+                // d1 is the next step's d0 (two registers, used alternately); k counts the steps SURVIVED (incremented behind the compare).
                 const uint32_t blk = (uint32_t)k;                        // a multiple of 8 in every lane that is stepping
                 const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);    // stream 3, same constant folding as the path stream
                 __builtin_amdgcn_sched_barrier(0);       // (interleaved with the next block the two generators need 66 VGPRs: 7 waves)
@@ -832,23 +835,25 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     polar_pair<FAST, true>(rb.z, rb.w, r1, c2, c3);
                     const uint32_t ua = half ? u4.z : u4.x, ub = half ? u4.w : u4.y;
                     if constexpr (FAST && CAP4) {
-                        float t1, m, uf;
-                        // per step: w1; d1; d0*d1; 2^(K - 4 d0 d1) with K = 32 (+ 1 ulp, so that "outside" beats a uniform that
-                        // rounds up to 2^32) or 16: the uniform's scale; the uniform's conversion (it also fills the slot a
-                        // transcendental's result needs before a VALU instruction may read it on gfx950); compare -> EXEC;
-                        // survivors count the step and carry d1.  The lane mask goes in and comes out in one SGPR pair.
-#define NDDM_BSTEP(R, T, CVT, KLIT) "v_fmac_f32 %[w], %[" R "], %[" T "]\n\tv_add_f32 %[w], %[mu], %[w]\n\tv_sub_f32 %[t1], %[h], |%[w]|\n\t" \
-    "v_mul_f32 %[m], %[t0], %[t1]\n\tv_fmaak_f32 %[m], -4.0, %[m], " KLIT "\n\tv_exp_f32 %[m], %[m]\n\t" CVT                    \
-    "v_cmpx_ge_f32_e64 vcc, %[uf], %[m]\n\tv_add_u32 %[k], 1, %[k]\n\tv_mov_b32 %[t0], %[t1]\n\t"
+                        float m, uf;
+                        // per step: w1; d1 (into the other distance register); d0*d1; 2^(K - 4 d0 d1) with K = 32 (+ 1 ulp, so that
+                        // "outside" beats a uniform that rounds up to 2^32) or 16: the uniform's scale; the uniform's conversion
+                        // (it also fills the slot a transcendental's result needs before a VALU instruction may read it on
+                        // gfx950); compare -> EXEC; survivors count the step.  The lane mask goes in and comes out in one SGPR pair.
+#define NDDM_BSTEP(R, T, D0, D1, CVT, KLIT) "v_fmac_f32 %[w], %[" R "], %[" T "]\n\tv_add_f32 %[w], %[mu], %[w]\n\tv_sub_f32 %[" D1 "], %[h], |%[w]|\n\t" \
+    "v_mul_f32 %[m], %[" D0 "], %[" D1 "]\n\tv_fmaak_f32 %[m], -4.0, %[m], " KLIT "\n\tv_exp_f32 %[m], %[m]\n\t" CVT                        \
+    "v_cmpx_ge_f32_e64 vcc, %[uf], %[m]\n\tv_add_u32 %[k], 1, %[k]\n\t"
 #define NDDM_U32(W) "v_cvt_f32_u32 %[uf], %[" W "]\n\t"
 #define NDDM_U16(W) "v_and_b32 %[uf], 0xffff, %[" W "]\n\tv_cvt_f32_u32 %[uf], %[uf]\n\t"
                         asm volatile("s_mov_b64 exec, %[lm]\n\t"
                                      "v_mov_b32 %[jr], %[ua]\n\t"
-                                     NDDM_BSTEP("r0", "c0", NDDM_U32("ua"), "0x42000001") NDDM_BSTEP("r0", "c1", NDDM_U16("ua"), "0x41800000")
+                                     NDDM_BSTEP("r0", "c0", "ta", "tb", NDDM_U32("ua"), "0x42000001")
+                                     NDDM_BSTEP("r0", "c1", "tb", "ta", NDDM_U16("ua"), "0x41800000")
                                      "v_mov_b32 %[jr], %[ub]\n\t"
-                                     NDDM_BSTEP("r1", "c2", NDDM_U32("ub"), "0x42000001") NDDM_BSTEP("r1", "c3", NDDM_U16("ub"), "0x41800000")
+                                     NDDM_BSTEP("r1", "c2", "ta", "tb", NDDM_U32("ub"), "0x42000001")
+                                     NDDM_BSTEP("r1", "c3", "tb", "ta", NDDM_U16("ub"), "0x41800000")
                                      "s_nop 1\n\ts_mov_b64 %[lm], exec\n\ts_mov_b64 exec, -1"
-                                     : [w] "+v"(w), [k] "+v"(k), [t0] "+v"(t0), [jr] "+v"(jraw), [lm] "+s"(live), [t1] "=&v"(t1), [m] "=&v"(m),
+                                     : [w] "+v"(w), [k] "+v"(k), [ta] "+v"(ta), [tb] "+v"(tb), [jr] "+v"(jraw), [lm] "+s"(live), [m] "=&v"(m),
                                        [uf] "=&v"(uf)
                                      : [mu] "v"(mu_dt), [h] "v"(h), [r0] "v"(r0), [r1] "v"(r1), [c0] "v"(c0), [c1] "v"(c1),
                                        [c2] "v"(c2), [c3] "v"(c3), [ua] "v"(ua), [ub] "v"(ub)
@@ -868,7 +873,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                                 const uint32_t word = j < 2 ? ua : ub;
                                 const float w1 = __builtin_fmaf(rr4[j], tt4[j], w) + mu_dt;
                                 const float t1 = h - __builtin_fabsf(w1);
-                                const float m = t0 * t1;
+                                const float m = ((j & 1) ? tb : ta) * t1;
+                                if (j & 1) ta = t1; else tb = t1;           // (written whether or not the trial goes on, as the asm does)
                                 if ((j & 1) == 0) jraw = word;
                                 const float uf = (j & 1) ? (float)(word & 0xffffu) : (float)word;
                                 bool cross;
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                                 w = w1;
                                 if (cross) active = false;
                                 else {
-                                    k++; t0 = t1;
+                                    k++;
                                     if constexpr (!CAP4) active = k < A.max_k;
                                 }
                             }
