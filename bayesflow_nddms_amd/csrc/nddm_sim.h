@@ -825,7 +825,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 // d1 is the next step's d0 (two registers, used alternately); k counts the steps SURVIVED (incremented behind the compare).
                 const uint32_t blk = (uint32_t)k;                        // a multiple of 8 in every lane that is stepping
                 const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);    // stream 3, same constant folding as the path stream
-                __builtin_amdgcn_sched_barrier(0);       // (interleaved with the next block the two generators need 66 VGPRs: 7 waves)
+                // (no scheduling barrier here: the compiler interleaves the two generators)
                 unsigned long long &live = act_m;        // the lanes still stepping: narrowed in place (SGPR pairs are scarce here)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
