@@ -1,5 +1,6 @@
 #!/bin/bash
-# Re-collect every bench artifact that profiles/README.md lists (run on the GPU box through gpurun; ~6 min).
+# Re-collect every bench artifact that profiles/README.md lists (run on the GPU box through gpurun; ~8 min; the default bench
+# line now includes BASELINE configs[0] at full size, ~35 s of CPU time per model that has a NumPy port).
 # Writes gpurun_out/art/*; copy what you want judged into profiles/ (tools/refresh_artifacts.sh does not touch profiles/).
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,16 +8,20 @@ OUT=$ROOT/gpurun_out/art
 mkdir -p "$OUT"
 cd "$ROOT"
 run() { name=$1; shift; python3 bench.py "$@" > "$OUT/$name" 2> "$OUT/$name.err" && echo "ok $name" || { echo "FAILED $name"; tail -3 "$OUT/$name.err"; }; }
-run r2_bench_basic.json
-run r2_bench_single.json --model single
-run r2_bench_alpha_ns.json --model alpha_ns
-run r2_bench_alpha_ns_bridge.json --model alpha_ns_bridge
-run r2_bench_basic_dt01.json --dt 0.01 --max-steps 400
-run r2_bench_basic_packed.json --gauss packed
-run r2_bench_cpu_full.json --cpu-full
-run r2_train.json --train
-python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling > "$OUT/r2_two_rank_none.log" 2>&1 && echo "ok two_rank_none"
-python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling --gather summary > "$OUT/r2_two_rank_summary.log" 2>&1 && echo "ok two_rank_summary"
-python3 bench.py --gpus 2 --share-device --backend gloo --train --train-iters 60 > "$OUT/r2_two_rank_train.log" 2>&1 && echo "ok two_rank_train"
-python3 tools/quick_time.py > "$OUT/r2_quick_time.txt" 2>&1 && echo "ok quick_time"
-python3 tools/wave_timeline.py 0:1000000:300:0.001:4000 0:1000000:300:0.01:400 0:1000000:60:0.01:400 0:30000:300:0.001:4000 0:10000:300:0.001:4000 > "$OUT/r2_wave_timeline.txt" 2>&1 && echo "ok wave_timeline"
+run r3_bench_basic.json
+run r3_bench_single.json --model single
+run r3_bench_alpha_ns.json --model alpha_ns
+run r3_bench_alpha_ns_bridge.json --model alpha_ns_bridge
+run r3_bench_basic_dt01.json --dt 0.01 --max-steps 400
+run r3_bench_basic_packed.json --gauss packed
+run r3_train.json --train
+run r3_bench_dist_summary_world1.json --dist --backend nccl --gather summary --no-ceiling --no-ks --no-cpu-baseline
+run r3_bench_dist_trials_world1.json --dist --backend nccl --gather trials --no-ceiling --no-ks --no-cpu-baseline
+run r3_train_ddp_world1.json --train --dist --backend nccl --train-mode graph --train-parallel ddp
+python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling > "$OUT/r3_two_rank_none.log" 2>&1 && echo "ok two_rank_none"
+python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling --gather summary > "$OUT/r3_two_rank_summary.log" 2>&1 && echo "ok two_rank_summary"
+python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling --gather trials > "$OUT/r3_two_rank_trials.log" 2>&1 && echo "ok two_rank_trials"
+python3 bench.py --gpus 2 --share-device --backend gloo --train --train-iters 60 > "$OUT/r3_two_rank_train.log" 2>&1 && echo "ok two_rank_train"
+python3 tools/overlap_probe.py > "$OUT/r3_overlap_probe.txt" 2>&1 && echo "ok overlap_probe"
+python3 tools/quick_time.py > "$OUT/r3_quick_time.txt" 2>&1 && echo "ok quick_time"
+python3 tools/wave_timeline.py 0:1000000:300:0.001:4000 0:1000000:300:0.01:400 0:1000000:60:0.01:400 0:30000:300:0.001:4000 0:10000:300:0.001:4000 > "$OUT/r3_wave_timeline.txt" 2>&1 && echo "ok wave_timeline"
