@@ -862,7 +862,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 #undef NDDM_U32
 #undef NDDM_U16
                     } else {
-                        // the same steps in C: the exact transform (bit-reproducible on a CPU: oracle/ddm_oracle.c), and
+                        // the same steps in C: the exact transform (bit-reproducible on a CPU: the test suite restates it in plain C), and
                         // step caps that are not a multiple of 8 (tested per step)
                         bool active = __builtin_amdgcn_inverse_ballot_w64(live);
                         const float rr4[4] = {r0, r0, r1, r1}, tt4[4] = {c0, c1, c2, c3};
