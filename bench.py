@@ -3,7 +3,8 @@
 
 One "step" = one pass of the hot path over one batch: `--sets` parameter sets x `--trials` trials of the
 Euler-Maruyama simulator at dt=0.001 / max_steps=4000 (BASELINE.json configs[1]: basic_ddm_dc, 1M x 300; `--model
-single` = configs[3], `--model alpha_ns|alpha_ns_bridge` = configs[2]), parameters already resident in HBM, output =
+single` = configs[3], `--model alpha_ns_bridge` = configs[2] (`alpha_ns`: the same model without the bridge correction, a side
+figure that fails the KS bar)), parameters already resident in HBM, output =
 float32 pairs [B, 300, 2] + fused per-set summaries [B, 10].
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `python bench.py --gpus N` starts the N ranks
@@ -66,7 +67,8 @@ def parse():
                     help="fast (product default) | exact (bit-reproducible on a CPU) | packed = fast transform on the opt-in "
                          "NDDM_GAUSS_PACKED layout (8 normals per Philox block from 16 + 16 bit pairs; include/nddm.h)")
     ap.add_argument("--model", choices=list(MODELS), default="basic",
-                    help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns* = configs[2]")
+                    help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns_bridge = configs[2]; alpha_ns = "
+                         "the same model with plain Euler-Maruyama (fails the KS bar against the exact sampler: a side figure)")
     ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
     ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,7 +230,7 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
                                 max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, packed=packed, want_summary=False)
             h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K, signed=model_name == "single")
             per.append(round(dg.ks_signed(h, gold[f"{model_name}_hist_s{si}_c{ci}"]), 5))
-        return {"max": max(per), "per_set": per, "n_trials_per_side": 409600, "bar": 0.01,
+        return {"max": max(per), "per_set": per, "n_trials_per_side": 409600, "bar": 0.01, "meets_bar": bool(max(per) < 0.01),
                 "reference": f"NumPy reference simulator run on {len(per)} fixed parameter sets, tests/golden/ks_hist.npz"}
     path = os.path.join(ROOT, "tests", "golden", "ratcliff.npz")
     if not os.path.exists(path):
@@ -239,10 +241,11 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
         r = engine.simulate(engine.ALPHA_NOT_SCALED, np.tile(p, (2048, 1)), 200, dt=dt, max_steps=8.0 / dt, seed=777,
                             set_offset=si * 4096, fast=fast, bridge=bridge, packed=packed, want_summary=False)
         per.append(round(dg.ks_quantile_table(r["trials"][..., 0].cpu().numpy().ravel(), gold[f"yq_s{si}"]), 5))
-    return {"max": max(per), "per_set": per, "n_trials_per_side": "409600 vs 2e5", "bar": 0.01 if bridge else 0.10,
+    return {"max": max(per), "per_set": per, "n_trials_per_side": "409600 vs 2e5", "bar": 0.01, "meets_bar": bool(max(per) < 0.01),
             "reference": "simulratcliff (pyhddmjagsutils.py:47-176, the EXACT first-passage sampler alpha_not_scaled.py runs), "
-                         "tests/golden/ratcliff.npz" + ("" if bridge else "; plain Euler-Maruyama detects crossings O(sqrt(dt)) late: "
-                                                        "stated tolerance 0.10, the bridge mode meets 0.01")}
+                         "tests/golden/ratcliff.npz" + ("" if bridge else "; plain Euler-Maruyama detects crossings O(sqrt(dt)) late and "
+                                                        "FAILS the 0.01 bar (0.070): a side figure only -- `--model alpha_ns_bridge` is "
+                                                        "the BASELINE configs[2] measurement")}
 
 
 def pmc_traffic(model_name, B, N):
