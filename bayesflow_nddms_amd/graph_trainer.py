@@ -39,7 +39,7 @@ _PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5)}
 
 
 class _Bucket:
-    __slots__ = ("n_top", "params", "trials", "g_params", "g_trials", "graphs")
+    __slots__ = ("n_top", "params", "trials", "g_params", "g_trials", "t_params", "t_trials", "r_params", "r_trials", "graphs")
 
 
 class GraphTrainer:
@@ -91,6 +91,7 @@ class GraphTrainer:
             for st in self.optimizer.state.values():
                 st["step"].zero_()
         self._buckets = {}
+        self._replay = None
         # everything the trainer enqueues -- warm-up passes, captures, replays -- goes to ONE stream of its own: autograd's
         # gradient-accumulation nodes remember the stream they were first used on, and capture needs a non-default one
         self._stream = torch.cuda.Stream(device=self.dev)
@@ -138,54 +139,43 @@ class GraphTrainer:
         self.step_i += 1
         self.step_f += 1.0
 
-    def _collective(self, bk):
-        """The exchange step between the two graphs -- on a communication stream of its own, never on the stream that
-        captures: the process group's watchdog thread polls the events of its collectives (recorded on the stream they were
-        issued on), and HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent aborts the process)."""
+    def _on_comm_stream(self, fn):
+        """An exchange step between two graphs -- on a communication stream of its own, never on the stream that captures:
+        the process group's watchdog thread polls the events of its collectives (recorded on the stream they were issued
+        on), and HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent aborts the process)."""
         self._comm.wait_stream(self._stream)
         with torch.cuda.stream(self._comm):
-            self._collective_on_current_stream(bk)
+            fn()
         self._stream.wait_stream(self._comm)
 
-    def _collective_on_current_stream(self, bk):
+    def _gather(self, bk):
         import torch.distributed as dist
-        if self.parallel == "gather":
-            for dst, src in ((bk.g_trials, bk.trials), (bk.g_params, bk.params)):
-                if self.backend == "nccl":
-                    dist.all_gather_into_tensor(dst, src)
-                else:
-                    dist.all_gather(list(dst.unbind(0)), src)
-        else:
-            dist.all_reduce(self.flat)
+        for dst, src in ((bk.g_trials, bk.trials), (bk.g_params, bk.params)):
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(dst, src)
+            else:
+                dist.all_gather(list(dst.unbind(0)), src)
 
-    def _part_a(self, bk):
-        self._simulate(bk)
-        if self.parallel == "ddp" or not self._has_collective():
-            self._forward_backward(bk.params, bk.trials)
-
-    def _part_b(self, bk):
-        if self.parallel == "gather" and self._has_collective():
-            self._forward_backward(bk.g_params.view(-1, self.P), bk.g_trials.view(-1, bk.n_top, 2))
-        self._update(1.0 / self.world if (self.parallel == "ddp" and self._has_collective()) else 1.0)
+    def _all_reduce_gradients(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.flat)
 
     def _has_collective(self):
         import torch.distributed as dist
         return self.world > 1 or (self.split and dist.is_available() and dist.is_initialized())
 
-    def _eager_iteration(self, bk):
-        self._part_a(bk)
-        if self._has_collective():
-            self._collective(bk)
-        self._part_b(bk)
-
     # ------------------------------------------------------------------------------------------------ graphs
     def _mutable(self):
-        ts = list(self.params) + [self.offset, self.step_i, self.step_f, self.lr_t, self.n_f]
+        # (the flat gradient buffer too: a stretch that starts with the update clips it in place)
+        ts = list(self.params) + [self.offset, self.step_i, self.step_f, self.lr_t, self.n_f, self.flat]
         for st in self.optimizer.state.values():
             ts += [st["step"], st["exp_avg"], st["exp_avg_sq"]]
         return ts
 
     def _bucket(self, n_top):
+        """The static tensors of one n_trials bucket: this rank's simulated shard, (world > 1, gather) the reassembled
+        minibatch, and the training inputs `t_*` -- the shard, the gathered minibatch, or (experience replay) a staging
+        copy of a stored batch."""
         bk = self._buckets.get(n_top)
         if bk is not None:
             return bk
@@ -198,47 +188,109 @@ class GraphTrainer:
             if self.parallel == "gather" and self._has_collective():
                 bk.g_params = torch.empty((self.world, self.B, self.P), dtype=torch.float32, device=self.dev)
                 bk.g_trials = torch.empty((self.world, self.B, n_top, 2), dtype=torch.float32, device=self.dev)
-            bk.graphs = None
-            if self.use_graph:
-                # one eager pass at this shape first (GEMM heuristics, workspaces, autograd buffers), on a side stream, with
-                # every piece of state it touches put back afterwards: capturing must not cost an iteration
-                with torch.no_grad():
-                    snap = [t.clone() for t in self._mutable()]
-                self._eager_iteration(bk)
-                with torch.no_grad():
-                    for t, s0 in zip(self._mutable(), snap):
-                        t.copy_(s0)
-                torch.cuda.synchronize(self.dev)
-                parts = [lambda: self._part_a(bk), lambda: self._part_b(bk)] if (self.split or self._has_collective()) \
-                    else [lambda: (self._part_a(bk), self._part_b(bk))]
-                bk.graphs = []
-                for fn in parts:
-                    g = torch.cuda.CUDAGraph()
-                    # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
-                    # default (global) capture mode turns into an error that kills the process
-                    with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
-                        fn()
-                    bk.graphs.append(g)
+                bk.t_params, bk.t_trials = bk.g_params.view(-1, self.P), bk.g_trials.view(-1, n_top, 2)
+            else:
+                bk.t_params, bk.t_trials = bk.params, bk.trials
+            bk.r_params = bk.r_trials = None          # staging of a replayed batch: allocated by the first replay iteration
+            bk.graphs = {}
         self._buckets[n_top] = bk
         return bk
 
+    def _run(self, bk, key, fn):
+        """One graph-able stretch of the iteration on one bucket: captured at its first use -- after one eager pass at this
+        shape (GEMM heuristics, workspaces, autograd buffers) whose every effect on the trainer's state is rolled back, so
+        that capturing does not cost an iteration -- and replayed from then on."""
+        if not self.use_graph:
+            fn()
+            return
+        g = bk.graphs.get(key)
+        if g is None:
+            with torch.no_grad():
+                snap = [t.clone() for t in self._mutable()]
+            fn()
+            with torch.no_grad():
+                for t, s0 in zip(self._mutable(), snap):
+                    t.copy_(s0)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
+            # default (global) capture mode turns into an error that kills the process
+            with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
+                fn()
+            bk.graphs[key] = g
+        g.replay()
+
+    def _iteration(self, n, replay=None):
+        """simulate -> [all-gather] -> [experience replay: store, draw, stage] -> forward/backward -> [gradient all-reduce]
+        -> update.  Consecutive stretches with nothing eager between them are ONE graph: the whole iteration online at one
+        rank; simulate | forward/backward/update with an all-gather or the replay buffer in the middle; simulate +
+        forward/backward | update around a gradient all-reduce."""
+        coll, ddp = self._has_collective(), self.parallel == "ddp"
+        gather = coll and not ddp
+        bk = self._bucket(self.bucket_top(n))
+        self.n_f.fill_(float(n))
+        sim = lambda: self._simulate(bk)
+        if replay is None:
+            fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
+            up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
+            if not coll and not self.split:
+                self._run(bk, "sim+fb+up", lambda: (sim(), fb(), up()))
+            elif gather:
+                self._run(bk, "sim", sim)
+                self._on_comm_stream(lambda: self._gather(bk))
+                self._run(bk, "fb+up", lambda: (fb(), up()))
+            else:                                   # ddp, or the two-graph form forced at one rank without a process group
+                self._run(bk, "sim+fb", lambda: (sim(), fb()))
+                if coll:
+                    self._on_comm_stream(self._all_reduce_gradients)
+                self._run(bk, "up", up)
+            return
+        # experience replay (basic_ddm_dc.py:199-202 calls trainer.train_experience_replay): the fresh batch goes into the
+        # buffer, the step trains on a stored one -- of ITS bucket, with ITS N
+        self._run(bk, "sim", sim)
+        if gather:
+            self._on_comm_stream(lambda: self._gather(bk))
+        entry = (bk.t_params.clone(), bk.t_trials.clone(), n)
+        ring, rng, cap = replay
+        if len(ring) < cap:
+            ring.append(entry)
+        else:
+            ring[int(rng.integers(cap))] = entry
+        p_s, t_s, n_s = ring[int(rng.integers(len(ring)))]
+        bt = self._bucket(self.bucket_top(n_s))
+        if bt.r_params is None:
+            bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
+        bt.r_params.copy_(p_s); bt.r_trials.copy_(t_s)
+        self.n_f.fill_(float(n_s))
+        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
+        up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
+        if coll and ddp:
+            self._run(bt, "r:fb", fb)
+            self._on_comm_stream(self._all_reduce_gradients)
+            self._run(bt, "up", up)
+        else:
+            self._run(bt, "r:fb+up", lambda: (fb(), up()))
+
     def train_online(self, iterations):
-        """`iterations` training steps; returns nothing -- losses stay on the device until loss_history()."""
+        """`iterations` training steps, every batch fresh; returns nothing -- losses stay on the device until loss_history()."""
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
             for _ in range(int(iterations)):
-                n = shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max)     # batch-shared N (basic_ddm_dc.py:50-52, 131)
-                self.n_f.fill_(float(n))
-                bk = self._bucket(self.bucket_top(n))
-                if bk.graphs is None:
-                    self._eager_iteration(bk)
-                elif len(bk.graphs) == 1:
-                    bk.graphs[0].replay()
-                else:
-                    bk.graphs[0].replay()
-                    if self._has_collective():
-                        self._collective(bk)
-                    bk.graphs[1].replay()
+                self._iteration(shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max))   # batch-shared N (basic_ddm_dc.py:50-52, 131)
+                self.iteration += 1
+        torch.cuda.current_stream(self.dev).wait_stream(self._stream)
+
+    def train_experience_replay(self, iterations, capacity_in_batches=100, replay_seed=0):
+        """The reference's call (basic_ddm_dc.py:199-202): each iteration simulates one fresh batch into a buffer of
+        `capacity_in_batches` batches (every batch keeps its own N) and trains on a stored batch drawn at random -- the same
+        draws, in the same order, as amortizer.Trainer.train_experience_replay."""
+        import numpy as np
+        if self._replay is None:
+            self._replay = ([], np.random.default_rng(replay_seed), int(capacity_in_batches))
+        self._stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
+            for _ in range(int(iterations)):
+                self._iteration(shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max), self._replay)
                 self.iteration += 1
         torch.cuda.current_stream(self.dev).wait_stream(self._stream)
 
@@ -249,7 +301,7 @@ class GraphTrainer:
 
     @property
     def n_graphs(self):
-        return sum(len(b.graphs) for b in self._buckets.values() if b.graphs)
+        return sum(len(b.graphs) for b in self._buckets.values())
 
     # ------------------------------------------------------------------------------------------------ ownership
     def close(self):
@@ -261,6 +313,7 @@ class GraphTrainer:
         torch.cuda.synchronize(self.dev)
         had = any(b.graphs for b in self._buckets.values())
         self._buckets.clear()
+        self._replay = None
         if had:
             with torch.cuda.device(self.dev):
                 engine.release_graph_memory()

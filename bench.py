@@ -696,6 +696,23 @@ def train_bench(a, ctx):
                                 "buckets": gt.n_buckets, "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:])),
                                 "parallel": a.train_parallel if world > 1 else "one rank",
                                 "two_graphs_with_collective_between": bool(dist_on)}
+            # the reference's own call, trainer.train_experience_replay (basic_ddm_dc.py:199-202): simulate graph | buffer of
+            # 100 batches | training graph of the drawn batch's bucket
+            torch.manual_seed(0)
+            amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+            with GraphTrainer(amortizer, batch_size=Bl, total_steps=warm + 2 * a.train_iters, dt=dt, max_steps=ms, seed=2023,
+                              device=dev, world=world, rank=rank, parallel=a.train_parallel, backend=a.backend,
+                              split=dist_on) as gt:
+                gt.train_experience_replay(warm + a.train_iters)
+                barrier(a, ctx)
+                t0 = time.perf_counter()
+                gt.train_experience_replay(a.train_iters)
+                barrier(a, ctx)
+                el = time.perf_counter() - t0
+                h = gt.loss_history()
+                leg["graph_experience_replay"] = {"iterations_per_s": a.train_iters / el, "ms_per_iteration": el / a.train_iters * 1e3,
+                                                  "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:])),
+                                                  "graphs_captured": gt.n_graphs}
             if "eager_prefetch_on" in leg:
                 leg["graph_over_eager"] = leg["graph"]["iterations_per_s"] / max(leg["eager_prefetch_on"]["iterations_per_s"],
                                                                                 leg["eager_prefetch_off"]["iterations_per_s"])

@@ -103,3 +103,49 @@ def test_graph_trainer_equals_the_eager_iteration_and_tracks_the_classic_loop():
     tr = Trainer(am, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, learning_rate=1e-3)
     h_classic = tr.train_online(epochs=1, iterations_per_epoch=iters, batch_size=B, save_checkpoint=False, prefetch=False)
     assert np.allclose(h_graph[:20], h_classic[:20], rtol=2e-3, atol=2e-3), np.abs(np.array(h_graph[:20]) - np.array(h_classic[:20])).max()
+
+
+def test_graph_trainer_experience_replay_equals_eager_and_the_classic_loop():
+    """The reference trains with trainer.train_experience_replay (basic_ddm_dc.py:199-202): a fresh batch per iteration into a
+    buffer, the step on a stored batch drawn at random.  GraphTrainer's form (simulate graph | buffer | training graph of the
+    DRAWN batch's n_trials bucket) equals the same iteration run eagerly to 1e-4, makes the same draws as the classic
+    Trainer's loop (same buffer policy, same generator) and tracks its loss curve, and the loss goes down."""
+    import torch
+    from bayesflow_nddms_amd import basic_ddm_dc, engine
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    from bayesflow_nddms_amd.distributed import shared_prior_N
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+    from bayesflow_nddms_amd.priors import DevicePrior
+    iters, B, cap = 40, 32, 8
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+        with GraphTrainer(am, batch_size=B, total_steps=iters, seed=2023, learning_rate=1e-3, use_graph=use_graph) as gt:
+            gt.train_experience_replay(iters, capacity_in_batches=cap)
+            return gt.loss_history(), gt.n_graphs
+
+    h_graph, n_graphs = run(True)
+    h_eager, _ = run(False)
+    assert len(h_graph) == iters and n_graphs >= 6
+    assert np.allclose(h_graph, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h_graph) - np.array(h_eager)).max()
+    assert np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
+    prior, step = DevicePrior("basic", seed=2023), {"i": 0}
+
+    def generative_model(batch_size):
+        i = step["i"]; step["i"] += 1
+        n = shared_prior_N(2023, i)
+        p = prior(batch_size, set_offset=i * batch_size)
+        r = engine.simulate(engine.BASIC_DDM_DC, p, n, dt=0.01, max_steps=400.0, seed=2023, set_offset=i * batch_size,
+                            fast=True, want_summary=False)
+        return {"prior_draws": p, "sim_data": r["trials"], "sim_non_batchable_context": n}
+
+    torch.manual_seed(0)
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+    tr = Trainer(am, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, learning_rate=1e-3)
+    res = tr.train_experience_replay(epochs=1, iterations_per_epoch=iters, batch_size=B, capacity_in_batches=cap,
+                                     save_checkpoint=False, prefetch=False)
+    h_classic = res["train_losses"]
+    # (the padded-and-masked batch and the unpadded one differ in the last bits of every pooled mean, and the first steps of
+    # training amplify that: the curves stay within 1 % over the first 15 iterations)
+    assert np.allclose(h_graph[:15], h_classic[:15], rtol=1e-2, atol=1e-2), np.abs(np.array(h_graph[:20]) - np.array(h_classic[:20]))
