@@ -299,6 +299,54 @@ class GraphTrainer:
         self._stream.synchronize()
         return self.loss_buf[:min(self.iteration, self.loss_buf.numel())].cpu().numpy().tolist()
 
+    @torch.no_grad()
+    def validation_loss(self, conf):
+        """Loss on a configured data set (`validation_sims` of basic_ddm_dc.py:186-188, 199-202), computed eagerly."""
+        self._stream.synchronize()
+        return float(self.amortizer.compute_loss(conf))
+
+    # ---- checkpoint / resume: weights, Adam state, and the POSITION of the run -- iteration (it keys the batch-shared N),
+    # the device-side set offset, step counters and learning rate, the loss history, the replay buffer and its generator --
+    # so that a resumed run continues the random stream and reproduces the uninterrupted one
+    def state_dict(self):
+        self._stream.synchronize()
+        st = {"model": self.amortizer.state_dict(), "optimizer": self.optimizer.state_dict(), "iteration": self.iteration,
+              "offset": self.offset.cpu(), "step_i": self.step_i.cpu(), "step_f": self.step_f.cpu(), "lr": self.lr_t.cpu(),
+              "loss_buf": self.loss_buf.cpu(), "replay": None}
+        if self._replay is not None:
+            ring, rng, cap = self._replay
+            st["replay"] = {"ring": [(p.cpu(), t.cpu(), n) for p, t, n in ring], "rng": rng.bit_generator.state, "capacity": cap}
+        return st
+
+    def load_state_dict(self, st):
+        import numpy as np
+        self._stream.synchronize()
+        with torch.no_grad():
+            self.amortizer.load_state_dict(st["model"])
+            # Adam's state tensors are the ones the captured graphs hold: copy INTO them
+            src = st["optimizer"]["state"]
+            for i, p in enumerate(self.params):
+                for k in ("step", "exp_avg", "exp_avg_sq"):
+                    self.optimizer.state[p][k].copy_(src[i][k])
+            self.offset.copy_(st["offset"]); self.step_i.copy_(st["step_i"]); self.step_f.copy_(st["step_f"])
+            self.lr_t.copy_(st["lr"])
+            n = min(self.loss_buf.numel(), st["loss_buf"].numel())
+            self.loss_buf[:n].copy_(st["loss_buf"][:n])
+        self.iteration = int(st["iteration"])
+        self._replay = None
+        if st.get("replay") is not None:
+            rng = np.random.default_rng(0)
+            rng.bit_generator.state = st["replay"]["rng"]
+            self._replay = ([(p.to(self.dev), t.to(self.dev), n) for p, t, n in st["replay"]["ring"]], rng, st["replay"]["capacity"])
+
+    def save_checkpoint(self, path):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+
     @property
     def n_graphs(self):
         return sum(len(b.graphs) for b in self._buckets.values())

@@ -149,3 +149,31 @@ def test_graph_trainer_experience_replay_equals_eager_and_the_classic_loop():
     # (the padded-and-masked batch and the unpadded one differ in the last bits of every pooled mean, and the first steps of
     # training amplify that: the curves stay within 1 % over the first 15 iterations)
     assert np.allclose(h_graph[:15], h_classic[:15], rtol=1e-2, atol=1e-2), np.abs(np.array(h_graph[:20]) - np.array(h_classic[:20]))
+
+
+def test_graph_trainer_checkpoint_resume_reproduces_the_uninterrupted_run(tmp_path):
+    """A checkpoint carries the weights, Adam's state and the POSITION of the run (iteration -> batch-shared N, device-side set
+    offset, schedule, replay buffer and its generator): 25 iterations, save, a NEW trainer loads and runs 25 more == 50
+    iterations straight, loss for loss."""
+    import torch
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+
+    def make():
+        torch.manual_seed(0)
+        return GraphTrainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), batch_size=32,
+                            total_steps=50, seed=2023, learning_rate=1e-3)
+
+    with make() as gt:
+        gt.train_experience_replay(50, capacity_in_batches=8)
+        straight = gt.loss_history()
+    with make() as gt:
+        gt.train_experience_replay(25, capacity_in_batches=8)
+        gt.save_checkpoint(str(tmp_path / "gt.pt"))
+    torch.manual_seed(123)                                   # other initial weights: everything must come from the file
+    with GraphTrainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), batch_size=32, total_steps=50,
+                      seed=2023, learning_rate=1e-3) as gt:
+        gt.load_checkpoint(str(tmp_path / "gt.pt"))
+        gt.train_experience_replay(25, capacity_in_batches=8)
+        resumed = gt.loss_history()
+    assert len(resumed) == 50 and np.allclose(resumed, straight, rtol=1e-5, atol=1e-5), np.abs(np.array(resumed) - np.array(straight)).max()
