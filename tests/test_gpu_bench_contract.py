@@ -139,6 +139,21 @@ def test_bench_refuses_more_ranks_than_gpus_in_the_parent():
     assert len(r.stderr.strip().splitlines()) == 1 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py joins the ranks it is given (here two, sharing cuda:0 over gloo) and
+    rank 0 prints the one line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device",
+                        "--backend", "gloo", "--sets", "50000", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    d = _one_line(r)
+    assert d["n_gpus"] == 2 and abs(d["value"] - 2 * 50000 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
 def test_bench_refuses_a_world_size_it_was_not_asked_for():
     """--gpus N must describe the job that runs: under a launcher with another WORLD_SIZE the bench exits non-zero instead
     of silently measuring something else."""
