@@ -37,6 +37,8 @@ def _declare(L):
     L.nddm_explicit_boundary_simulate.argtypes = [fp, fp] + common + [fp, fp, vp]
     L.nddm_simulate.argtypes = [c.c_int32, fp, fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_simulate_indirect.argtypes = [c.c_int32, fp, fp] + common[:-1] + [fp, c.c_uint32, c.c_float, c.c_int32, fp, fp, fp, vp]
+    L.nddm_simulate_codes.argtypes = [c.c_int32, fp] + common[:-1] + [fp, c.c_uint32, fp, fp, fp, vp]
+    L.nddm_decode_codes.argtypes = [c.c_int32, fp, fp, c.c_int64, c.c_int32, c.c_float, fp, vp]
     L.nddm_draw_prior.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, c.c_float, fp, vp]
     L.nddm_draw_prior_indirect.argtypes = [c.c_int32, c.c_int64, c.c_uint64, c.c_uint64, fp, c.c_float, fp, vp]
     L.nddm_source_hash.restype = c.c_char_p
@@ -53,7 +55,7 @@ EXPORTS = [
     "nddm_single_trial_alt_simulate", "nddm_alpha_not_scaled_simulate", "nddm_explicit_boundary_simulate",
     "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_trace", "nddm_set_ordering",
     "nddm_release_graph_memory", "nddm_debug_set_slot_limit", "nddm_debug_last_launch",
-    "nddm_simulate_indirect", "nddm_draw_prior_indirect", "nddm_source_hash",
+    "nddm_simulate_indirect", "nddm_draw_prior_indirect", "nddm_source_hash", "nddm_simulate_codes", "nddm_decode_codes",
 ]
 
 

@@ -253,7 +253,7 @@ static int resident_waves(K kernel, size_t lds_bytes, int cus)
 }
 
 // one (MODEL, BRIDGE, SMALL, PACKED, VKEYS) variant: pick the Gaussian transform and the step-cap form, size the grid
-template <int MODEL, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS>
+template <int MODEL, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false>
 static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_bytes, int n_chunks, int cus, int grid_override,
                            bool grid_forced, hipStream_t st)
 {
@@ -266,10 +266,10 @@ static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_by
         g_last.grid_waves = waves; g_last.vkeys = VKEYS ? 1 : 0;                               \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
-    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS>));
-    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, SMALL, PACKED, VKEYS>));
-    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, SMALL, PACKED, VKEYS>));
-    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, SMALL, PACKED, VKEYS>));
+    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
+    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
+    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
+    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
 #undef NDDM_LAUNCH
 }
 
@@ -284,7 +284,11 @@ static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, si
     const bool small = A.res16 == 2;
     constexpr bool HAS_VKEYS = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED || MODEL == NDDM_EXPLICIT_BOUNDARY);
 #define NDDM_ARGS A, fast, cap4, lds_bytes, n_chunks, cus, grid_override, grid_forced, st
-    if constexpr (BRIDGE) launch_variant<MODEL, true, false, false, false>(NDDM_ARGS);
+    constexpr bool HAS_CODES = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED);
+    if (A.out_codes) {          // the wire-format variant (the host has checked: small, not packed, not the bridge); round keys from LDS
+        if constexpr (HAS_CODES) launch_variant<MODEL, false, true, false, false, true>(NDDM_ARGS);
+    }
+    else if constexpr (BRIDGE) launch_variant<MODEL, true, false, false, false>(NDDM_ARGS);
     else if (!small && !packed) launch_variant<MODEL, false, false, false, false>(NDDM_ARGS);
     else if constexpr (HAS_VKEYS) {
         if (packed && vkeys) launch_variant<MODEL, false, true, true, true>(NDDM_ARGS);     // NDDM_GAUSS_PACKED: the host has checked small
@@ -303,7 +307,8 @@ static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, si
 
 static int simulate(int model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,
                     int32_t max_steps, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags,
-                    float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream)
+                    float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_ext, void *stream,
+                    uint16_t *out_codes = nullptr)
 {
     g_err[0] = 0;
     int P;
@@ -332,7 +337,10 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (B == 0) return NDDM_OK;
     if (!params) return fail(NDDM_ERR_NULL, "params is NULL%s");
     if (model == NDDM_EXPLICIT_BOUNDARY && !bounds) return fail(NDDM_ERR_NULL, "bounds is NULL%s");
-    if (!out_trials && !out_summary && !out_ext) return fail(NDDM_ERR_NULL, "no output buffer given%s");
+    if (!out_trials && !out_summary && !out_ext && !out_codes) return fail(NDDM_ERR_NULL, "no output buffer given%s");
+    if (out_codes && ((model != NDDM_BASIC_DDM_DC && model != NDDM_ALPHA_NOT_SCALED) || bridge || packed || max_steps >= 16384))
+        return fail(NDDM_ERR_PARAM, "the 2-byte wire format exists for NDDM_BASIC_DDM_DC and NDDM_ALPHA_NOT_SCALED without NDDM_BRIDGE "
+                                    "or NDDM_GAUSS_PACKED, max_steps < 2^14%s");
     if (B * (((long long)n_trials + 511) / 512) >= (1ll << 31))
         return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
 
@@ -360,6 +368,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     SimArgs A;
     memset(&A, 0, sizeof A);
     A.params = params; A.bounds = bounds; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_ext;
+    A.out_codes = out_codes;
     A.B = B; A.n_trials = n_trials; A.max_k = max_steps; A.dt = dt; A.sqrt_dt = sqrtf(dt);
     A.tscale = bridge ? dt * 0.00390625f : dt;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
@@ -482,6 +491,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     // measured 0.4 / 2 / 3.3 % faster for single_trial / alpha_not_scaled / + bridge at dt=.001.)
     A.res16 = res16 ? (tile_n <= 512 ? 2 : 1) : 0;
     if (packed && A.res16 != 2) return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs tiles of <= 512 trials (tuning override?)%s");
+    if (out_codes && A.res16 != 2) return fail(NDDM_ERR_PARAM, "the 2-byte wire format needs tiles of <= 512 trials (tuning override?)%s");
     A.refill_thresh = tun.refill_thresh ? tun.refill_thresh : (max_steps <= 1000 ? 16 : 8);
     const long long n_chunks = (vB + spc - 1) / spc;
     A.n_chunks = (int)n_chunks;
@@ -746,6 +756,35 @@ int nddm_simulate(int32_t model, const float *params, const float *bounds, int64
     return nddm::simulate(model, params, model == NDDM_EXPLICIT_BOUNDARY ? bounds : nullptr, B, n_trials, dt, max_steps,
                           seed, set_offset, nullptr, flags, ext_sigma, ext_mode, out_trials, out_summary,
                           model == NDDM_ALPHA_NOT_SCALED ? out_extdata : nullptr, stream);
+}
+
+int nddm_simulate_codes(int32_t model, const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                        uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags, uint16_t *out_codes,
+                        float *out_trials, float *out_summary, void *stream)
+{
+    if (!out_codes) return nddm::fail(NDDM_ERR_NULL, "out_codes is NULL%s");
+    return nddm::simulate(model, params, nullptr, B, n_trials, dt, max_steps, seed, set_offset, set_offset_dev, flags, 0.0f, 0,
+                          out_trials, out_summary, nullptr, stream, out_codes);
+}
+
+int nddm_decode_codes(int32_t model, const uint16_t *codes, const float *params, int64_t B, int32_t n_trials, float dt,
+                      float *out_trials, void *stream)
+{
+    nddm::g_err[0] = 0;
+    if (model != NDDM_BASIC_DDM_DC && model != NDDM_ALPHA_NOT_SCALED)
+        return nddm::fail(NDDM_ERR_PARAM, "the 2-byte wire format exists for NDDM_BASIC_DDM_DC and NDDM_ALPHA_NOT_SCALED%s");
+    if (B < 0 || n_trials <= 0) return nddm::fail(NDDM_ERR_SHAPE, "B < 0 or n_trials <= 0%s");
+    if (!(dt > 0.0f) || !isfinite(dt)) return nddm::fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
+    if (B == 0) return NDDM_OK;
+    if (!codes || !params || !out_trials) return nddm::fail(NDDM_ERR_NULL, "null pointer%s");
+    const long long n = B * (long long)n_trials;
+    const int threads = 256;
+    hipLaunchKernelGGL(nddm::decode_codes_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0,
+                       reinterpret_cast<hipStream_t>(stream), (int)model, codes, params, nddm_model_nparams(model), 3, (long long)B,
+                       (int)n_trials, dt, reinterpret_cast<float2 *>(out_trials));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nddm::fail(NDDM_ERR_HIP, "decode kernel launch failed: %s", hipGetErrorString(e));
+    return NDDM_OK;
 }
 
 int nddm_simulate_indirect(int32_t model, const float *params, const float *bounds, int64_t B, int32_t n_trials, float dt,

@@ -114,6 +114,26 @@ __global__ void combine_partials_kernel(const unsigned long long *partials, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// the 2-byte wire format of a trial (step index | code << 14; nddm.h: nddm_simulate_codes) back to the float pair the
+// simulator would have written -- the same arithmetic as flush_set: rt = fma(float(k), dt, tau); basic: (rt, choice),
+// alpha_not_scaled: (choice * rt, (choice + 1) / 2).  One thread per trial; 2 B read, 8 B written.
+__global__ void decode_codes_kernel(int model, const uint16_t *codes, const float *params, int P, int tau_idx, long long B,
+                                    int n_trials, float dt, float2 *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (long long)n_trials) return;
+    const long long b = i / n_trials;
+    const uint32_t v = codes[i];
+    const uint32_t k = v & 0x3fffu, code = v >> 14;
+    const float ch = code == 1u ? 1.0f : (code == 2u ? -1.0f : 0.0f);
+    const float rt = __builtin_fmaf((float)k, dt, params[b * P + tau_idx]);
+    float2 o;
+    if (model == NDDM_BASIC_DDM_DC) { o.x = rt; o.y = ch; }
+    else { o.x = ch * rt; o.y = 0.5f * (ch + 1.0f); }
+    out[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
 // debugging kernel for the parity tests: 4 normals per counter
 template <bool FAST>
 __global__ void debug_normals_kernel(const uint32_t *ctr, long long n, uint32_t k0, uint32_t k1, float *out)

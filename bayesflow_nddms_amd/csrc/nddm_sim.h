@@ -35,6 +35,8 @@ struct SimArgs {
     float *out_trials;        // [B, N, 2] or null
     float *out_summary;       // [B, K] or null
     float *out_ext;           // [B] or null
+    uint16_t *out_codes;      // [B, N] or null: the trials in the 2-byte wire format (step index | code << 14), models whose second
+                              // column is a function of the code (basic, alpha_not_scaled without the bridge), cap < 2^14
     long long B;
     int n_trials;             // trials per TILE (a set is split into tiles_per_set tiles when it does not fit the LDS ring)
     int n_total;              // trials per set (row stride of out_trials / bounds)
@@ -319,7 +321,7 @@ __host__ __device__ constexpr int partial_words(bool has_zsum) { return has_zsum
 // SMALL: 16-bit staged results and at most 512 trials per tile, the shape of every launch that matters for throughput.
 // Then a lane's share of every sum fits 32 bits (<= 8 trials, k < 2^14), the two counters share one word (10 bits
 // each), and the seven cross-lane sums are DPP reductions of 32-bit values (the two sums of squares as 16-bit halves).
-template <int MODEL, bool FAST, bool SMALL>
+template <int MODEL, bool FAST, bool SMALL, bool CODES>
 __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, uint32_t *d, const void *res, uint32_t kbase)
 {
     using T = ModelTraits<MODEL>;
@@ -341,11 +343,19 @@ __device__ __forceinline__ void flush_set(ArgsPtr Ap, int lane, long long vset, 
     int n_up = 0, n_lo = 0, n_miss = 0;                                           // !SMALL
     unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
     float2 *out = Ap->out_trials ? reinterpret_cast<float2 *>(Ap->out_trials) + set_in_call * Ap->n_total + t0 : nullptr;
+    // CODES: the launch also (or only) wants the trials in the 2-byte wire format.  A kernel variant of its own: carried by the
+    // default kernels the extra pointer and store cost the headline 1.2-1.4 % (A/B on one box: 55 -> 60 SGPRs, 42 -> 44 VGPRs and a
+    // different schedule of the step loop), so they do not carry it
+    static_assert(!CODES || (SMALL && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED)), "wire-format kernels");
+    constexpr bool HAS_CODES = CODES;
+    [[maybe_unused]] uint16_t *codes = nullptr;
+    if constexpr (HAS_CODES) { if (Ap->out_codes) codes = Ap->out_codes + set_in_call * Ap->n_total + t0; }
     for (uint32_t j = (uint32_t)lane; j < (uint32_t)n_here; j += WAVE) {   // (unsigned: scalar base + 32-bit lane offset)
         uint32_t k, code;                                    // time in units of tscale (step index, or 1/256 step);
         if (SMALL || Ap->res16) {                            // code: 0 timeout, 1 upper, 2 lower, 3 invalid trial
             const uint32_t v = static_cast<const uint16_t *>(res)[j];
             k = v & 0x3fffu; code = v >> 14;
+            if constexpr (HAS_CODES) { if (codes) codes[j] = (uint16_t)v; }      // the staged word IS the wire format
         } else {
             const uint32_t v = static_cast<const uint32_t *>(res)[j];
             k = v & 0x3fffffffu; code = v >> 30;
@@ -456,7 +466,8 @@ __device__ __forceinline__ bool in_range(float w, float h)
 // VKEYS: the Philox round keys of the step loop are held in 13 VGPRs for the whole kernel instead of read from LDS every
 // block (nddm_rng.h): no LDS instruction and no wait in the loop.  Same VALU work; measured 1.6 % slower on a full grid
 // and 13-29 % faster when a wave has a SIMD (nearly) to itself, so the host picks it for small launches.
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS>
+// CODES: the variant that also stores the trials as 2-byte codes (flush_set); instantiated for basic / alpha_not_scaled, SMALL only.
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
     using T = ModelTraits<MODEL>;
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 }
                 uint32_t *const d = slot_rec(fslot);
                 const int set_in_call = __builtin_amdgcn_readfirstlane((int)d[D_VSET]);
-                flush_set<MODEL, FAST, SMALL>(fresh_args(Ak), lane, (long long)set_in_call, d, d + DV, kbase);
+                flush_set<MODEL, FAST, SMALL, CODES>(fresh_args(Ak), lane, (long long)set_in_call, d, d + DV, kbase);
                 flushed++;
                 to_retire += N;
                 dirty = 1;

@@ -50,12 +50,13 @@ class ShardedSimulator:
     params: the GLOBAL [B, P] parameter matrix (identical on every rank: drawn from a shared seed, or on the device
     with the counter-based prior), or a callable (lo, hi) -> rows [hi-lo, P] that materialises only this rank's block.
     simulate_fn(model, params_rows, n_trials, seed=, set_offset=, **kw) -> dict with 'trials' / 'summary' tensors;
-    the default is the HIP engine.  gather: 'trials' | 'summary' | 'both' | 'none'.
+    the default is the HIP engine.  gather: 'trials' | 'summary' | 'both' | 'none' | 'codes' (the trials, exchanged as 2-byte
+    codes + the parameter rows and decoded on arrival: basic_ddm_dc / alpha_not_scaled without the bridge, HIP engine only).
     """
 
     def __init__(self, model, simulate_fn=None, group=None, gather="trials"):
-        if gather not in ("trials", "summary", "both", "none"):
-            raise ValueError("gather must be 'trials', 'summary', 'both' or 'none'")
+        if gather not in ("trials", "summary", "both", "none", "codes"):
+            raise ValueError("gather must be 'trials', 'summary', 'both', 'none' or 'codes'")
         if simulate_fn is None:
             from . import engine
             simulate_fn = engine.simulate
@@ -69,6 +70,8 @@ class ShardedSimulator:
             world, rank = 1, 0
         lo, hi = shard_bounds(n_sets, world, rank)
         rows = params(lo, hi) if callable(params) else params[lo:hi]
+        if self.gather == "codes":
+            return self._gather_codes(rows, n_sets, n_trials, seed, set_offset + lo, world, rank, (lo, hi), kw)
         want_t = self.gather in ("trials", "both", "none")
         want_s = self.gather in ("summary", "both", "none")
         res = self.simulate_fn(self.model, rows, n_trials, seed=seed, set_offset=set_offset + lo,
@@ -82,6 +85,19 @@ class ShardedSimulator:
             else:
                 out[key] = res[key]
         return out
+
+
+    def _gather_codes(self, rows, n_sets, n_trials, seed, offset, world, rank, bounds, kw):
+        import torch
+        from . import engine
+        res = self.simulate_fn(self.model, rows, n_trials, seed=seed, set_offset=offset, want_trials=False, want_summary=False,
+                               want_codes=True, **kw)
+        codes, p = res["codes"], res["params"]
+        if world > 1:
+            codes = all_gather_rows(codes.view(torch.uint8), n_sets, self.group).view(torch.int16)     # bytes: RCCL has no int16
+            p = all_gather_rows(p, n_sets, self.group)
+        return {"rank": rank, "world_size": world, "rows": bounds,
+                "trials": engine.decode_codes(self.model, codes, p, kw.get("dt", 0.01))}
 
 
 def shared_prior_N(seed, step, n_min=60, n_max=300):

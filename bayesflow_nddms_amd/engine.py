@@ -92,7 +92,8 @@ def validate_params_host(model, params):
 
 def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
              bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, packed=False, want_trials=True, want_summary=True, want_ext=False,
-             out_trials=None, out_summary=None, stream_state=None, device=None, set_offset_dev=None):
+             out_trials=None, out_summary=None, stream_state=None, device=None, set_offset_dev=None, want_codes=False,
+             out_codes=None):
     """Run one batched simulation on the current ROCm device.
 
     params: array-like or torch tensor [B, P] (or [P]) in the reference's parameter order.
@@ -102,6 +103,10 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     set_offset_dev: optional device int64 tensor [1]; the global index of row 0 is then set_offset + its value WHEN THE
     LAUNCH RUNS (nddm_simulate_indirect) -- a launch captured into a hipGraph moves along the random stream by a captured
     `set_offset_dev += B` instead of new kernel arguments.
+
+    want_codes / out_codes: also (or, with want_trials=False, only) write the trials in the 2-byte wire format, int16 [B, n_trials]
+    holding uint16 (step index | code << 14) -- basic_ddm_dc and alpha_not_scaled without the bridge, max_steps < 2^14;
+    decode_codes() gives the float pairs back (include/nddm.h: nddm_simulate_codes).
 
     Returns a dict of torch tensors on the device: 'trials' f32 [B, n_trials, 2], 'summary' f32 [B, 10],
     'ext' f32 [B] (alpha_not_scaled only), plus 'seed' / 'set_offset' actually used.
@@ -166,6 +171,11 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
         if want_summary and out_summary is None:
             out_summary = torch.empty((B, SUMMARY_K), dtype=torch.float32, device=dev)
         out_ext = torch.empty((B,), dtype=torch.float32, device=dev) if (want_ext and model == ALPHA_NOT_SCALED) else None
+        if want_codes and out_codes is None:
+            out_codes = torch.empty((B, n_trials), dtype=torch.int16, device=dev)
+        if out_codes is not None and (tuple(out_codes.shape) != (B, n_trials) or out_codes.dtype != torch.int16
+                                      or not out_codes.is_contiguous() or not out_codes.is_cuda):
+            raise ValueError(f"out_codes must be a contiguous int16 device tensor of shape {(B, n_trials)}")
         for t, shape in ((out_trials, (B, n_trials, 2)), (out_summary, (B, SUMMARY_K))):
             if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous()
                                   or not t.is_cuda):
@@ -174,7 +184,13 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
         pt = lambda t: None if t is None else t.data_ptr()
         if B > 0:
             common = (B, n_trials, float(dt), max_k, seed, set_offset, flags)
-            if set_offset_dev is not None:
+            if set_offset_dev is not None and not (isinstance(set_offset_dev, torch.Tensor) and set_offset_dev.is_cuda
+                                                   and set_offset_dev.dtype == torch.int64 and set_offset_dev.numel() >= 1):
+                raise ValueError("set_offset_dev must be a device int64 tensor")
+            if out_codes is not None:
+                rc = L.nddm_simulate_codes(model, pt(p_dev), *common[:-1], pt(set_offset_dev), flags, pt(out_codes), pt(out_trials),
+                                           pt(out_summary), st)
+            elif set_offset_dev is not None:
                 if not (isinstance(set_offset_dev, torch.Tensor) and set_offset_dev.is_cuda and set_offset_dev.dtype == torch.int64
                         and set_offset_dev.numel() >= 1):
                     raise ValueError("set_offset_dev must be a device int64 tensor")
@@ -206,7 +222,23 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
         res["summary"] = out_summary
     if out_ext is not None:
         res["ext"] = out_ext
+    if out_codes is not None:
+        res["codes"] = out_codes
     return res
+
+
+def decode_codes(model, codes, params, dt, out_trials=None):
+    """The 2-byte wire format back to the float pairs the simulator writes: codes int16 [B, n_trials] (uint16 content), params
+    f32 [B, P] (tau is read from them), -> f32 [B, n_trials, 2], bit-identical to simulate()'s 'trials' (nddm_decode_codes)."""
+    torch = require_device()
+    B, n_trials = int(codes.shape[0]), int(codes.shape[1])
+    if out_trials is None:
+        out_trials = torch.empty((B, n_trials, 2), dtype=torch.float32, device=codes.device)
+    p = params.to(dtype=torch.float32).contiguous()
+    with torch.cuda.device(codes.device):
+        _lib.check(_lib.lib().nddm_decode_codes(model, codes.contiguous().data_ptr(), p.data_ptr(), B, n_trials, float(dt),
+                                                out_trials.data_ptr(), torch.cuda.current_stream(codes.device).cuda_stream))
+    return out_trials
 
 
 def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device=None, set_offset_dev=None, out=None):

@@ -69,7 +69,10 @@ def parse():
     ap.add_argument("--model", choices=list(MODELS), default="basic",
                     help="basic = BASELINE configs[1] (the headline); single = configs[3]; alpha_ns_bridge = configs[2]; alpha_ns = "
                          "the same model with plain Euler-Maruyama (fails the KS bar against the exact sampler: a side figure)")
-    ap.add_argument("--gather", choices=["none", "summary", "trials"], default="none")
+    ap.add_argument("--gather", choices=["none", "summary", "trials", "codes"], default="none",
+                    help="the minibatch all-gather in the timed region: fused summaries (40 B per set), float trials (8 B per trial), "
+                         "or `codes` = the trials in the 2-byte wire format (+ the parameter rows), decoded to the same floats on "
+                         "every rank after the gather (include/nddm.h: nddm_simulate_codes / nddm_decode_codes)")
     ap.add_argument("--summary-only", action="store_true", help="do not write the 8 B/trial (fused summaries only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle baseline sample")
@@ -402,14 +405,22 @@ def simulate_bench(a, ctx):
     # takes time for).  A buffer is handed to the simulator again only after the gather that reads it has completed.
     dist_on = ctx["dist_on"]
     gather_on = dist_on and a.gather != "none"
-    if a.gather == "trials" and a.summary_only:
-        sys.exit("--gather trials needs the trials: drop --summary-only")
+    if a.gather in ("trials", "codes") and a.summary_only:
+        sys.exit("--gather trials / codes needs the trials: drop --summary-only")
+    codes = a.gather == "codes"                       # the simulator writes 2-byte codes; floats appear after the gather, by decoding
+    if codes and (a.model not in ("basic", "alpha_ns") or a.max_steps >= 16384):
+        sys.exit("--gather codes: basic / alpha_ns (no bridge) with max_steps < 2^14")
     overlap = gather_on and not a.no_overlap
     nbuf = 2 if overlap else 1
-    buf_trials = [None if a.summary_only else torch.empty((B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    buf_trials = [None if (a.summary_only or codes) else torch.empty((B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    buf_codes = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(nbuf)] if codes else None
     buf_summary = [torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    gathered = None
-    if gather_on:
+    gathered = g_codes = g_params = None
+    if gather_on and codes:
+        g_codes = [torch.empty((world, B, N), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+        g_params = [torch.empty((world,) + tuple(p_dev.shape), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        gathered = [torch.empty((world, B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    elif gather_on:
         shape = tuple((buf_summary if a.gather == "summary" else buf_trials)[0].shape)
         gathered = [torch.empty((world,) + shape, dtype=torch.float32, device=dev) for _ in range(nbuf)]
     # the communication stream has the higher priority: when a gather and the next simulate become runnable together the
@@ -433,28 +444,40 @@ def simulate_bench(a, ctx):
             ev[0].record()                              # torch's current stream == the stream the kernel is launched on
         engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
                         set_offset=(i * world + rank) * B, fast=fast, out_trials=buf_trials[b], out_summary=buf_summary[b],
-                        want_trials=not a.summary_only, bridge=bridge, packed=packed)
+                        want_trials=not (a.summary_only or codes), bridge=bridge, packed=packed,
+                        out_codes=buf_codes[b] if codes else None)
         if ev is not None:
             ev[1].record()
+
+        def exchange(blocking):
+            """the collective(s) of this step on the current stream; returns the last one's handle (non-blocking form)"""
+            if not codes:
+                return all_gather(gathered[b], buf_summary[b] if a.gather == "summary" else buf_trials[b], not blocking)
+            all_gather(g_params[b], p_dev, False)                # tau travels with the codes (20 B per set)
+            all_gather(g_codes[b].view(torch.uint8), buf_codes[b].view(torch.uint8), False)     # (as bytes: RCCL has no 16-bit integer type;
+                                                                                                  #  always the blocking form: the decode needs them)
+            for r in range(world):                               # 2 B read + 8 B written per trial, beside the next simulate
+                engine.decode_codes(model_id, g_codes[b][r], g_params[b][r], a.dt, out_trials=gathered[b][r])
+            return None
+
         if gather_on:
-            src = buf_summary[b] if a.gather == "summary" else buf_trials[b]
             if overlap:
                 done = torch.cuda.Event()
                 done.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
-                    if a.backend == "nccl":
+                    if a.backend == "nccl" or codes:
                         # the blocking form runs the collective ON the current stream -- the high-priority communication
                         # stream, which has a hardware queue of its own; the process group's internal stream (async_op=True)
                         # was observed sharing the simulate stream's hardware queue, i.e. serialised with the next simulate
                         # (profiles/r3_dist_overlap.md).  The simulate stream later waits for the event recorded behind it.
-                        all_gather(gathered[b], src, False)
+                        exchange(True)
                         pending[b] = torch.cuda.Event()
                         pending[b].record(comm)
                     else:
-                        pending[b] = all_gather(gathered[b], src, True)
+                        pending[b] = exchange(False)
             else:
-                all_gather(gathered[b], src, False)
+                exchange(True)
 
     def drain():
         for b in range(nbuf):
@@ -490,7 +513,7 @@ def simulate_bench(a, ctx):
     trials_per_step = world * B * N
     value = trials_per_step * a.steps / elapsed
     P = p_host.shape[1]
-    alg_bytes = B * N * (0 if a.summary_only else 8) + B * (P * 4 + engine.SUMMARY_K * 4)
+    alg_bytes = B * N * (0 if a.summary_only else (2 if codes else 8)) + B * (P * 4 + engine.SUMMARY_K * 4)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     name = "basic_ddm_dc" if a.model == "basic" else a.model
     res = {
@@ -502,7 +525,9 @@ def simulate_bench(a, ctx):
                                f"dt={a.dt}, max_steps={a.max_steps:g}, params ~ reference prior (default_rng 2023)",
                    "sets_per_gpu": B, "n_trials": N, "dt": a.dt, "max_steps": a.max_steps,
                    "gauss": a.gauss, "arithmetic": ARITHMETIC,
-                   "outputs": "summaries only" if a.summary_only else "trials f32[B,N,2] + summaries f32[B,10]",
+                   "outputs": "summaries only" if a.summary_only else ("trials as 2-byte codes u16[B,N] + summaries f32[B,10]; floats by "
+                                                                                "decoding after the gather" if codes else
+                                                                                "trials f32[B,N,2] + summaries f32[B,10]"),
                    "parallelism": f"dp{world} over parameter sets, gather={a.gather}"
                                   + (", all-gather on a communication stream, double-buffered outputs" if overlap else "")
                                   + (f", distributed code path forced at world {world} ({a.backend})" if a.dist else "")},
@@ -515,7 +540,7 @@ def simulate_bench(a, ctx):
         "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
         "p_missing": p_missing,
     }
-    tr = None if a.summary_only else pmc_traffic(a.model, B, N)
+    tr = None if (a.summary_only or codes) else pmc_traffic(a.model, B, N)
     if tr:
         res["roofline"]["traffic"] = tr["bytes"]
         res["roofline"]["traffic_source"] = tr["source"]

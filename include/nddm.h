@@ -47,7 +47,7 @@ extern "C" {
 
 /* 2: the default Gaussian stream takes the angle from the LOW 23 bits of its word (round 2), the bridge-uniform stream
  *    serves 8 steps per block (round 3), nddm_set_debug_counters became nddm_set_debug_trace, and the *_indirect entry
- *    points and nddm_source_hash exist.  The same (seed, set_offset) gives different bits under ABI 1. */
+ *    points, nddm_simulate_codes / nddm_decode_codes and nddm_source_hash exist.  The same (seed, set_offset) gives different bits under ABI 1. */
 #define NDDM_ABI_VERSION 2
 #define NDDM_SUMMARY_K 10
 
@@ -197,6 +197,20 @@ int nddm_simulate_indirect(int32_t model, const float *params, const float *boun
                            int32_t max_steps, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags,
                            float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
                            void *stream);
+
+/* The trials in a 2-byte WIRE FORMAT, for the exchange step (the all-gather that reassembles a training
+ * minibatch on every rank).  out_codes[b, i] = step index | code << 14 (code 1 upper, 2 lower, 0 timeout) -- what the kernels
+ * stage in LDS anyway -- for the models whose second column is a function of the code: NDDM_BASIC_DDM_DC (rt, choice) and
+ * NDDM_ALPHA_NOT_SCALED without NDDM_BRIDGE (y, acc); max_steps < 2^14.  Gathering the float pairs moves 8 bytes per trial over
+ * every xGMI link, which at this simulator's rate IS a link's bandwidth; the codes are a quarter of that, and
+ * nddm_decode_codes (2 B read + 8 B written per trial, HBM-bound) gives back exactly the floats the simulator writes:
+ * rt = fma(float(k), dt, tau) with tau from the (gathered) parameter rows.  out_trials / out_summary may be given as well
+ * (NULL = not written); set_offset_dev as in nddm_simulate_indirect (NULL = 0). */
+int nddm_simulate_codes(int32_t model, const float *params, int64_t B, int32_t n_trials, float dt, int32_t max_steps,
+                        uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev, uint32_t flags, uint16_t *out_codes,
+                        float *out_trials, float *out_summary, void *stream);
+int nddm_decode_codes(int32_t model, const uint16_t *codes /* device u16 [B, n_trials] */, const float *params /* device f32 [B, P] */,
+                      int64_t B, int32_t n_trials, float dt, float *out_trials /* device f32 [B, n_trials, 2] */, void *stream);
 
 /* ---- prior / context samplers (basic_ddm_dc.py:50-80, single_trial_alpha_not_scaled.py:66-102) -------
  * On-device batched draw_prior(): out device f32 [B, P] in the model's parameter order

@@ -74,7 +74,7 @@ def _one_line(r):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gather", ["summary", "trials"])
+@pytest.mark.parametrize("gather", ["summary", "trials", "codes"])
 def test_bench_rccl_branch_runs_at_world_1(gather):
     """`bench.py --dist` takes the multi-rank code path on ONE GPU through bench.py itself: init_process_group("nccl",
     device_id=...), barrier(device_ids=...), all_gather_into_tensor on the communication stream (double-buffered outputs),
@@ -185,6 +185,7 @@ def test_two_fresh_ranks_union_equals_unsharded(tmp_path):
     shards = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2)]
     for sh in shards:
         assert torch.equal(sh["both"]["trials"], ft) and torch.equal(torch.nan_to_num(sh["both"]["summary"]), fs)
+        assert torch.equal(sh["codes"]["trials"], ft)               # exchanged as 2-byte codes, decoded on arrival: the same floats
     assert shards[0]["none"]["rows"] == (0, 501) and shards[1]["none"]["rows"] == (501, 1001)
     assert torch.equal(torch.cat([sh["none"]["trials"] for sh in shards]), ft)
     assert torch.equal(torch.nan_to_num(torch.cat([sh["none"]["summary"] for sh in shards])), fs)

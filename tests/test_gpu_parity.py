@@ -535,3 +535,39 @@ def test_ring_span_limit_of_the_tuning_override(oracle_mod):
     o = oracle_mod.philox_simulate(oracle_mod.M_BASIC, p, 1024, dt=.01, max_steps=400, seed=3, set_offset=0, threads=4)
     assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32))
     assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+
+
+@pytest.mark.parametrize("model", ["basic", "alpha_ns"])
+def test_wire_format_codes_decode_to_the_same_floats(model, oracle_mod):
+    """nddm_simulate_codes / nddm_decode_codes (include/nddm.h): the trials as 2-byte codes (step index | code << 14) for the
+    exchange step.  The codes equal the oracle's (step index, choice) -- every trial; decoding them gives bit for bit the float
+    pairs the simulator writes (also when it writes both in one launch, also for a sorted / multi-chunk launch and ragged N);
+    models and shapes without the format are refused."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    mid, om, prior = {"basic": (engine.BASIC_DDM_DC, oracle_mod.M_BASIC, prior_util.basic_prior),
+                      "alpha_ns": (engine.ALPHA_NOT_SCALED, oracle_mod.M_ALPHA_NS, prior_util.alpha_ns_prior)}[model]
+    for B, N, dt, ms in ((70, 300, 0.01, 400.0), (3000, 77, 0.001, 4000.0), (9, 700, 0.004, 1001.0)):
+        p = prior(B, 5)
+        kw = dict(dt=dt, max_steps=ms, seed=17, set_offset=3)
+        both = engine.simulate(mid, p, N, fast=False, want_codes=True, **kw)
+        only = engine.simulate(mid, p, N, fast=False, want_trials=False, want_summary=False, want_codes=True, **kw)
+        assert "trials" not in only and torch.equal(only["codes"], both["codes"])
+        dec = engine.decode_codes(mid, only["codes"], both["params"], dt)
+        assert torch.equal(dec.view(torch.int32), both["trials"].view(torch.int32))
+        o = oracle_mod.philox_simulate(om, p, N, dt=dt, max_steps=ms, seed=17, set_offset=3, want_k=True, threads=4)
+        c = only["codes"].cpu().numpy().view(np.uint16).astype(np.int64)
+        choice = o["trials"][..., 1] if model == "basic" else 2.0 * o["trials"][..., 1] - 1.0
+        timeout = (o["trials"][..., 0] == 0.0) if model == "alpha_ns" else (choice == 0)
+        code = np.where(timeout, 0, np.where(choice > 0, 1, 2))
+        assert np.array_equal(c & 0x3fff, o["k"]) and np.array_equal(c >> 14, code)
+        fastr = engine.simulate(mid, p, N, fast=True, want_codes=True, **kw)
+        assert torch.equal(engine.decode_codes(mid, fastr["codes"], fastr["params"], dt).view(torch.int32), fastr["trials"].view(torch.int32))
+    p = prior(8, 1)
+    with pytest.raises(ValueError, match="wire format"):
+        engine.simulate(mid, p, 50, dt=.001, max_steps=20000, want_codes=True)
+    with pytest.raises(ValueError, match="wire format"):
+        engine.simulate(engine.SINGLE_TRIAL, prior_util.single_prior(8, 1), 50, want_codes=True)
+    if model == "alpha_ns":
+        with pytest.raises(ValueError, match="wire format"):
+            engine.simulate(mid, p, 50, dt=.001, max_steps=4000, bridge=True, want_codes=True)

@@ -26,7 +26,8 @@ def test_fast_kernels_fit_eight_waves_per_simd():
         assert r.get("ScratchSize [bytes/lane]", 0) == 0, name               # no private scratch anywhere
         assert r.get("VGPRs Spill", 0) == 0 and r.get("SGPRs Spill", 0) == 0, name
     fast_small = [k for k in sims if ", fast," in k and "small=1" in k]
-    assert len(fast_small) == 32                             # 5 models x cap4 {0,1} x packed {0,1} + 3 models with a VGPR-keys variant
+    assert len(fast_small) == 36                             # 5 models x cap4 {0,1} x packed {0,1} + 3 models with a VGPR-keys variant
+                                                             # + the wire-format (codes) variant of basic / alpha_ns x cap4 {0,1}
     for name in fast_small:
         v, s = sims[name]["VGPRs"], sims[name]["TotalSGPRs"]
         assert rt.waves_by_vgpr(v) == 8 and rt.waves_by_sgpr(s) == 8, (name, v, s)

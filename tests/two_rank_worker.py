@@ -22,7 +22,7 @@ def main():
         from bayesflow_nddms_amd.distributed import ShardedSimulator
         p = torch.as_tensor(prior_util.basic_prior(B, 21)).cuda()
         res = {}
-        for gather in ("both", "none"):
+        for gather in ("both", "none", "codes"):
             sim = ShardedSimulator(engine.BASIC_DDM_DC, gather=gather)
             out = sim(p, B, N, seed=31, set_offset=12345, dt=0.001, max_steps=4000, fast=True)
             res[gather] = {k: v.cpu() for k, v in out.items() if isinstance(v, torch.Tensor)}

@@ -124,7 +124,7 @@ def disassemble(so_path=SO):
 
 def kernel_insts(txt, targs):
     """[(address, mnemonic, operand text, branch target or None)] of one sim_kernel instantiation."""
-    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dELb%dEEEvNS_7SimArgsE" % targs
+    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dELb%dELb0EEEvNS_7SimArgsE" % targs      # (..., CODES = false)
     lines = txt.splitlines()
     start = next(i for i, l in enumerate(lines) if l.endswith(f"<{sym}>:"))
     insts = []
