@@ -35,7 +35,9 @@ import torch
 from . import engine
 from .distributed import shared_prior_N
 
-_PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5)}
+# model -> (kernel, columns of the parameter rows the kernels take, leading columns that are the network's targets):
+# basic_ddm_dc.py:62-80 draws 5 parameters; single_trial_alpha_not_scaled.py:78-102 draws 7, the kernel takes an eighth (gamma = 1)
+_PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5, 5), "single": (engine.SINGLE_TRIAL, 8, 7)}
 
 
 class _Bucket:
@@ -55,7 +57,7 @@ class GraphTrainer:
         assert torch_ is torch
         self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.amortizer = amortizer.to(self.dev)
-        self.model_id, self.P = _PRIOR_MODEL[model]
+        self.model_id, self.P, self.P_net = _PRIOR_MODEL[model]
         self.B, self.T = int(batch_size), int(total_steps)
         self.n_min, self.n_max, self.n_buckets = int(n_min), int(n_max), int(n_buckets)
         self.width = -(-(self.n_max - self.n_min + 1) // self.n_buckets)
@@ -118,7 +120,7 @@ class GraphTrainer:
         mask = (self.arange[:n_top] < self.n_f).to(torch.float32).view(1, n_top, 1)
         conf = {"summary_conditions": trials, "summary_mask": (mask, 1.0 / self.n_f),
                 "direct_conditions": torch.log(self.n_f).view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
-                "parameters": params}
+                "parameters": params if self.P_net == self.P else params[:, :self.P_net]}
         loss = self.amortizer.compute_loss(conf)
         # gradients straight into the flat buffer with one multi-tensor copy (accumulating into pre-set .grad views costs one
         # add kernel per parameter tensor plus the zero fill)

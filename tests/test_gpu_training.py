@@ -177,3 +177,22 @@ def test_graph_trainer_checkpoint_resume_reproduces_the_uninterrupted_run(tmp_pa
         gt.train_experience_replay(25, capacity_in_batches=8)
         resumed = gt.loss_history()
     assert len(resumed) == 50 and np.allclose(resumed, straight, rtol=1e-5, atol=1e-5), np.abs(np.array(resumed) - np.array(straight)).max()
+
+
+def test_graph_trainer_single_trial_model():
+    """The same loop for single_trial_alpha_not_scaled (its script trains the same way, :193-230): 7 target parameters, data
+    (choicert, z1); the graph-replayed history equals the eager one and the loss goes down."""
+    import torch
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=7), InvariantNetwork())
+        with GraphTrainer(am, model="single", batch_size=32, total_steps=60, seed=2023, learning_rate=1e-3, use_graph=use_graph) as gt:
+            gt.train_online(60)
+            return gt.loss_history()
+
+    h_graph, h_eager = run(True), run(False)
+    assert np.allclose(h_graph, h_eager, rtol=1e-4, atol=1e-4)
+    assert np.all(np.isfinite(h_graph)) and np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
