@@ -17,6 +17,7 @@ run r3_bench_basic_packed.json --gauss packed
 run r3_train.json --train
 run r3_bench_dist_summary_world1.json --dist --backend nccl --gather summary --no-ceiling --no-ks --no-cpu-baseline
 run r3_bench_dist_trials_world1.json --dist --backend nccl --gather trials --no-ceiling --no-ks --no-cpu-baseline
+run r3_bench_dist_codes_world1.json --dist --backend nccl --gather codes --no-ceiling --no-ks --no-cpu-baseline
 run r3_train_ddp_world1.json --train --dist --backend nccl --train-mode graph --train-parallel ddp
 python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling > "$OUT/r3_two_rank_none.log" 2>&1 && echo "ok two_rank_none"
 python3 bench.py --gpus 2 --share-device --backend gloo --sets 100000 --steps 3 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling --gather summary > "$OUT/r3_two_rank_summary.log" 2>&1 && echo "ok two_rank_summary"
