@@ -216,8 +216,8 @@ enum { D_A = 0, D_B = 4,                             // r[0..3], r[4..7]
                                                      // virtual set (set * tiles_per_set + tile)
        D_CA = 12, D_CB = 13, D_HP1K = 14, D_X1 = 15, // Philox constants of the set (PathSet in nddm_rng.h)
        D_C3 = 16, D_SETLO = 17,                      // high set word (28 bits), low set word (auxiliary stream's counter)
-       D_ZSUM = 20,                                  // [20..23] fixed-point sums of z and z^2 (models with a z summary), or
-       D_BCA = 20, D_BCB = 21, D_BHP1K = 22, D_BX1 = 23 }; // PathSet of the bridge-uniform stream (stream 3; BRIDGE only)
+       D_ZSUM = 20,                                  // [20..23] fixed-point sums of z and z^2 (models with a z summary)
+       D_SPARE = 20 };                               // [20..23] unused by the models without a z summary
 constexpr int DV = 24;                               // one layout for every model: only two LDS base addresses stay live
 static_assert(D_SIC == R_SET && D_TAU == R_TAU, "the LDS record starts with the loaded record");
 constexpr int LDS_HEADER_DWORDS = 32;                // key table [0,20) | debug stamps [20,28) | kC kD kE [28,31)
@@ -530,7 +530,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // balloted costs v_cndmask + v_cmp each time; __builtin_amdgcn_inverse_ballot_w64 turns a mask into exec for free)
     unsigned long long has_m = 0ull, act_m = 0ull;
     PathCtr pc = {0u, 0u, 0u, 0u, 0u};
-    PathCtr pcb = {0u, 0u, 0u, 0u, 0u};           // bridge-uniform stream (BRIDGE only)
     [[maybe_unused]] PathKeys pkeys;              // VKEYS: the step loop's Philox round keys
     if constexpr (VKEYS) pkeys.init(A.k0, A.k1);
 
@@ -609,11 +608,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 PathSet ps;
                 ps.init(s_lo, s_hi, R->k0, R->k1);              // stream 0: no tag bits in c2
                 d[D_CA] = ps.cA; d[D_CB] = ps.cB; d[D_HP1K] = ps.hP1k; d[D_X1] = ps.X1;
-                if constexpr (BRIDGE) {
-                    PathSet pb;
-                    pb.init(s_lo, s_hi | 0x30000000u, R->k0, R->k1);
-                    d[D_BCA] = pb.cA; d[D_BCB] = pb.cB; d[D_BHP1K] = pb.hP1k; d[D_BX1] = pb.X1;
-                }
                 d[D_SETLO] = s_lo;
                 d[D_C3] = s_hi;
                 d[D_TBASE] = (uint32_t)(qt * N);
@@ -797,10 +791,6 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 }
                 const uint4 kq = *reinterpret_cast<const uint4 *>(lds_raw + 28);       // kC, kD, kE of PathCtr::init
                 pc.init(d1.x, d1.y, d1.z, d1.w, trial, kq.x, kq.y, kq.z);
-                if constexpr (BRIDGE) {
-                    const u32v4 d4 = rq[D_BCA / 4];
-                    pcb.init(d4.x, d4.y, d4.z, d4.w, trial, kq.x, kq.y, kq.z);
-                }
                 k = 0;
                 if constexpr (BRIDGE) { ta = h - __builtin_fabsf(w); tb = ta; jraw = 0u; }
             }
@@ -824,7 +814,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         for (;; ++it) {
             if constexpr (BRIDGE) {
                 // ---- Brownian-bridge stepping: 8 steps per pass -- two blocks of the path stream (counters k, k + 4: the
-                // stream of the plain kernel) and ONE block of stream 3, whose four words serve two steps each: the first
+                // stream of the plain kernel) and ONE block of crossing uniforms, whose four words serve two steps each: the first
                 // step of a pair takes the whole word as a 32-bit uniform, the second its low 16 bits.
                 // A step from w to w1 ends the trial -- boundary side = sign(w1) -- when
                 //     u < exp(-2 d0 d1),   d0 = h - |w|,  d1 = h - |w1|    (noise units; 2^(-4 d0 d1) in the fast transform's),
@@ -835,7 +825,9 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 // deviations apart, below which an Euler-Maruyama path is no approximation of anything.
                 // d1 is the next step's d0 (two registers, used alternately); k counts the steps SURVIVED (incremented behind the compare).
                 const uint32_t blk = (uint32_t)k;                        // a multiple of 8 in every lane that is stepping
-                const u32x4 u4 = philox4x32_10_path(blk, pcb, kbase);    // stream 3, same constant folding as the path stream
+                // the crossing uniforms: the PATH stream's own generator at draw index k | 2^31 (k < 2^22 with the bridge): no second
+                // set of per-trial Philox constants to compute at every hand-out and to hold in five VGPRs
+                const u32x4 u4 = philox4x32_10_path(blk | 0x80000000u, pc, kbase);
                 // (no scheduling barrier here: the compiler interleaves the two generators)
                 unsigned long long &live = act_m;        // the lanes still stepping: narrowed in place (SGPR pairs are scarce here)
 #pragma unroll
