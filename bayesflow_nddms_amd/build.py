@@ -83,5 +83,41 @@ def build_hip(force=False, verbose=False):
     return SO_PATH
 
 
+# ---- the amortizer's fused coupling kernels (csrc/train_kernels.hip -> libnddm_train.so): not part of the simulator's C ABI; the
+# PyTorch path is the fallback wherever this library is absent or the shape is not covered
+TRAIN_SO_PATH = os.path.join(_HERE, "libnddm_train.so")
+TRAIN_SOURCE = os.path.join(_HERE, "csrc", "train_kernels.hip")
+
+
+def train_source_hash():
+    with open(TRAIN_SOURCE, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def build_train(force=False, verbose=False):
+    """Compile csrc/train_kernels.hip for gfx950; stale = other source content than the one recorded beside the library."""
+    stamp = TRAIN_SO_PATH + ".srchash"
+    fresh = os.path.exists(TRAIN_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == train_source_hash()
+    if fresh and not force:
+        return TRAIN_SO_PATH
+    import fcntl
+    with open(TRAIN_SO_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        tmp = f"{TRAIN_SO_PATH}.{os.getpid()}.tmp"
+        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", tmp, TRAIN_SOURCE]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, TRAIN_SO_PATH)
+            with open(stamp, "w") as f:
+                f.write(train_source_hash())
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return TRAIN_SO_PATH
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_train(force=True, verbose=True))
