@@ -36,11 +36,13 @@ struct Args {
 // grid = ceil(R / TRF) workgroups of 256 threads over tiles of TRF = 8 rows (four workgroups at batch 32: the work is latency,
 // not arithmetic, so it is spread).  Thread t: hidden unit j = t % 128, row half rh = t / 128 (TRF / 2 rows each).
 constexpr int TRF = 8, RPT = TRF / 2;
+constexpr int TRFP = TRF + 4;   // row stride of the transposed activations in LDS: lanes index the UNIT, and a stride of 8 (or 32)
+                                // floats puts a whole wave on two banks; + 4 keeps 16-byte alignment and leaves 4-way conflicts
 __global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, float *s_out, float *h1_out, float *h2_out)
 {
     __shared__ float in_s[TRF][DI_MAX];
-    __shared__ float h1t[H][TRF];         // transposed: [unit][row]
-    __shared__ float h2t[H][TRF];
+    __shared__ __attribute__((aligned(16))) float h1t[H][TRFP];        // transposed: [unit][row]
+    __shared__ __attribute__((aligned(16))) float h2t[H][TRFP];
     __shared__ float o_s[TRF][M_MAX];
     const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7;
     const int r0 = blockIdx.x * TRF, DI = A.Dh + A.C, M = 2 * A.Dt;
@@ -129,16 +131,19 @@ struct BwdOut {
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
 };
 constexpr int NTB = 1024;
+constexpr int TRP = TR + 4;      // (as TRFP: unpadded, the transposing stores and every per-unit read were 32-way bank conflicts)
 
 __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *s_in, const float *h1_in, const float *h2_in,
                                                            const float *gy, const float *gs, BwdOut O)
 {
     __shared__ float in_s[TR][DI_MAX];
-    __shared__ float h1t[H][TR];
-    __shared__ float h2t[H][TR];          // later: d(pre-activation 1), transposed
-    __shared__ float da2t[H][TR];
+    __shared__ __attribute__((aligned(16))) float h1t[H][TRP];
+    __shared__ __attribute__((aligned(16))) float h2t[H][TRP];         // later: d(pre-activation 1), transposed
+    __shared__ __attribute__((aligned(16))) float da2t[H][TRP];
     __shared__ float do_s[TR][M_MAX];
+    __shared__ float w2s[H][H];           // W2 staged once (64 KB of gfx950's 160 KB): its column reads below were the kernel's latency
     const int t = threadIdx.x, j = t & (H - 1), g = t >> 7;
+    for (int p = t; p < H * H; p += NTB) w2s[p >> 7][p & (H - 1)] = A.W2[p];
     const int DI = A.Dh + A.C, M = 2 * A.Dt;
     float dW2[16], dW1[DI_MAX / 8], dW3[M_MAX / 8];
     float db2 = 0.0f, db1 = 0.0f, db3 = 0.0f;
@@ -208,17 +213,20 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *
         // layer 2 weight gradient: thread (row j of dW2, columns 16 g .. 16 g + 15); rows outside, columns unrolled (the
         // accumulators are the only register array)
 #pragma unroll 2
-        for (int r = 0; r < TR; ++r) {
-            const float av = da2t[j][r];
+        for (int rr = 0; rr < TR / 4; ++rr) {          // four rows per 16-byte LDS read: a quarter of the LDS instructions
+            const float4 av = *reinterpret_cast<const float4 *>(&da2t[j][4 * rr]);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) dW2[q] = fmaf(av, h1t[16 * g + q][r], dW2[q]);
-            if (g == 0) db2 += av;
+            for (int q = 0; q < 16; ++q) {
+                const float4 hv = *reinterpret_cast<const float4 *>(&h1t[16 * g + q][4 * rr]);
+                dW2[q] = fmaf(av.w, hv.w, fmaf(av.z, hv.z, fmaf(av.y, hv.y, fmaf(av.x, hv.x, dW2[q]))));
+            }
+            if (g == 0) db2 += (av.x + av.y) + (av.z + av.w);
         }
-        // d h1 -> d(pre-activation 1): thread (unit i = j, rows 4 g .. 4 g + 3); W2 read by columns (coalesced over i)
+        // d h1 -> d(pre-activation 1): thread (unit i = j, rows 4 g .. 4 g + 3); W2 by columns, from LDS
         float da1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
         for (int jj = 0; jj < H; ++jj) {
-            const float w = A.W2[(long long)jj * H + j];
+            const float w = w2s[jj][j];
             const float *ar = &da2t[jj][4 * g];
 #pragma unroll
             for (int q = 0; q < 4; ++q) da1[q] = fmaf(w, ar[q], da1[q]);
