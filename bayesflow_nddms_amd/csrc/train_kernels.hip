@@ -13,7 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace {
+namespace nddm_train {
 
 constexpr int H = 128;        // hidden width
 constexpr int TR = 32;        // rows per tile
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *
     if (t < M) O.gb3[t] = db3;
 }
 
-}  // namespace
+}  // namespace nddm_train
+
+using namespace nddm_train;
 
 extern "C" {
 
