@@ -24,10 +24,10 @@ def lib():
     fp, vp, i32, f32 = c.c_void_p, c.c_void_p, c.c_int, c.c_float
     L.nddm_train_coupling_supported.argtypes = [i32] * 4
     L.nddm_train_coupling_supported.restype = i32
-    L.nddm_train_coupling_fwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, fp, fp, fp, f32, i32, fp, fp, fp, fp, vp]
+    L.nddm_train_coupling_fwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, fp, fp, fp, f32, i32, fp, i32, fp, i32, fp, fp, vp]
     L.nddm_train_coupling_fwd.restype = i32
-    L.nddm_train_coupling_bwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, f32, i32, fp, fp, fp, fp, fp,
-                                          fp, i32, fp, fp, i32, fp, fp, fp, fp, fp, fp, vp]
+    L.nddm_train_coupling_bwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, f32, i32, fp, i32, fp, fp, fp, i32, fp, i32,
+                                          fp, i32, fp, i32, i32, fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, vp]
     L.nddm_train_coupling_bwd.restype = i32
     _lib = L
     return _lib

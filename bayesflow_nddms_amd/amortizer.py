@@ -109,51 +109,75 @@ class InvariantNetwork(nn.Module):
         return self.post_pool(pooled)
 
 
-class _FusedCouplingFn(torch.autograd.Function):
-    """One conditional affine-coupling half-layer as ONE kernel each way (csrc/train_kernels.hip): concatenate, three Linear
-    layers with two ELUs, soft clamp, exp, multiply-add -- 33 launches of a few microseconds each at batch 32 in PyTorch.
-    Returns (y, s): the transformed half and the clamped log-scales (their sum is the layer's log|det|)."""
+class _FusedCouplingLayerFn(torch.autograd.Function):
+    """One whole flow layer -- ActNorm, fixed permutation, both conditional affine-coupling half-layers -- with the
+    half-layers as ONE hand-written kernel each way (csrc/train_kernels.hip: concatenate, three Linear layers with two ELUs,
+    soft clamp, exp, multiply-add; 33 PyTorch launches of a few microseconds at batch 32) and NO autograd bookkeeping
+    between them: the kernels read and write column slices of [R, D] buffers through row strides, the second half-layer
+    accumulates into the first one's input and condition gradients, so the slices, concatenations and per-row selects that
+    cost autograd ~20 tiny launches per layer backward are gone.  Returns (y, s): the layer's output and the clamped log-scales
+    of its D transformed columns (their row sums are its coupling log|det|)."""
 
     @staticmethod
-    def forward(ctx, L, clamp, xh, cond, xtr, W1, b1, W2, b2, W3, b3):
-        R, Dh, C, Dt = xh.shape[0], xh.shape[1], cond.shape[1], xtr.shape[1]
-        cond = cond.contiguous()
-        y = torch.empty((R, Dt), dtype=torch.float32, device=xh.device)
-        s = torch.empty_like(y)
-        h1 = torch.empty((R, W2.shape[0]), dtype=torch.float32, device=xh.device)
-        h2 = torch.empty_like(h1)
-        st = torch.cuda.current_stream(xh.device).cuda_stream
-        rc = L.nddm_train_coupling_fwd(xh.data_ptr(), xh.stride(0), Dh, cond.data_ptr(), C, xtr.data_ptr(), xtr.stride(0), Dt,
-                                       W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
-                                       float(clamp), R, y.data_ptr(), s.data_ptr(), h1.data_ptr(), h2.data_ptr(), st)
+    def forward(ctx, L, clamp, d1, x, cond, scale, bias, pmat, W1a, b1a, W2a, b2a, W3a, b3a, W1b, b1b, W2b, b2b, W3b, b3b):
+        R, D, C = x.shape[0], x.shape[1], cond.shape[1]
+        d2, Hd, F = D - d1, W2a.shape[0], 4
+        x, cond = x.contiguous(), cond.contiguous()
+        ex = torch.exp(scale)
+        z = torch.addcmul(bias, x, ex) @ pmat                                  # ActNorm, then z[:, perm]
+        out, s_all = torch.empty_like(z), torch.empty_like(z)
+        h = torch.empty((4, R, Hd), dtype=torch.float32, device=x.device)      # saved activations of both sub-networks
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        zp, op, sp, hp, cp = z.data_ptr(), out.data_ptr(), s_all.data_ptr(), h.data_ptr(), cond.data_ptr()
+        hb = R * Hd * F
+        # half A (net 1): conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s_all[:, :d2]
+        rc = L.nddm_train_coupling_fwd(zp, D, d1, cp, C, zp + d1 * F, D, d2, W1a.data_ptr(), b1a.data_ptr(), W2a.data_ptr(),
+                                       b2a.data_ptr(), W3a.data_ptr(), b3a.data_ptr(), float(clamp), R, op + d1 * F, D, sp, D,
+                                       hp, hp + hb, st)
+        # half B (net 2): conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s_all[:, d2:]
+        rc |= L.nddm_train_coupling_fwd(op + d1 * F, D, d2, cp, C, zp, D, d1, W1b.data_ptr(), b1b.data_ptr(), W2b.data_ptr(),
+                                        b2b.data_ptr(), W3b.data_ptr(), b3b.data_ptr(), float(clamp), R, op, D, sp + d2 * F, D,
+                                        hp + 2 * hb, hp + 3 * hb, st)
         if rc != 0:
             raise RuntimeError(f"nddm_train_coupling_fwd failed ({rc})")
-        ctx.L, ctx.clamp = L, float(clamp)
-        ctx.save_for_backward(xh, cond, xtr, W1, W2, W3, s, h1, h2)
-        return y, s
+        ctx.L, ctx.clamp, ctx.d1 = L, float(clamp), d1
+        ctx.save_for_backward(x, cond, ex, pmat, z, out, s_all, h, W1a, W2a, W3a, W1b, W2b, W3b)
+        return out, s_all
 
     @staticmethod
-    def backward(ctx, gy, gs):
-        xh, cond, xtr, W1, W2, W3, s, h1, h2 = ctx.saved_tensors
-        R, Dh, C, Dt = xh.shape[0], xh.shape[1], cond.shape[1], xtr.shape[1]
-        dev = xh.device
-        gy = gy.contiguous() if gy is not None else torch.zeros_like(s)
-        gs = gs.contiguous() if gs is not None else torch.zeros_like(s)
-        gxh = torch.empty((R, Dh), dtype=torch.float32, device=dev)
+    def backward(ctx, g_out, g_s):
+        x, cond, ex, pmat, z, out, s_all, h, W1a, W2a, W3a, W1b, W2b, W3b = ctx.saved_tensors
+        L, d1, F = ctx.L, ctx.d1, 4
+        R, D, C = x.shape[0], x.shape[1], cond.shape[1]
+        d2, Hd, dev = D - d1, W2a.shape[0], x.device
+        g_out = g_out.contiguous() if g_out is not None else torch.zeros_like(out)
+        g_s = g_s.contiguous() if g_s is not None else torch.zeros_like(out)
+        gz = torch.empty_like(z)
         gcond = torch.empty((R, C), dtype=torch.float32, device=dev)
-        gxtr = torch.empty((R, Dt), dtype=torch.float32, device=dev)
-        gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
-        gb1 = torch.empty(W1.shape[0], dtype=torch.float32, device=dev)
-        gb2 = torch.empty(W2.shape[0], dtype=torch.float32, device=dev)
-        gb3 = torch.empty(W3.shape[0], dtype=torch.float32, device=dev)
-        rc = ctx.L.nddm_train_coupling_bwd(xh.data_ptr(), xh.stride(0), Dh, cond.data_ptr(), C, xtr.data_ptr(), xtr.stride(0), Dt,
-                                           W1.data_ptr(), W2.data_ptr(), W3.data_ptr(), ctx.clamp, R, s.data_ptr(), h1.data_ptr(),
-                                           h2.data_ptr(), gy.data_ptr(), gs.data_ptr(), gxh.data_ptr(), Dh, gcond.data_ptr(),
-                                           gxtr.data_ptr(), Dt, gW1.data_ptr(), gb1.data_ptr(), gW2.data_ptr(), gb2.data_ptr(),
-                                           gW3.data_ptr(), gb3.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        g_y2 = torch.empty((R, d2), dtype=torch.float32, device=dev)           # through net 2's conditioning input
+        gW = [torch.empty_like(w) for w in (W1a, W2a, W3a, W1b, W2b, W3b)]
+        gb = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in (W1a, W2a, W3a, W1b, W2b, W3b)]
+        st = torch.cuda.current_stream(dev).cuda_stream
+        zp, op, sp, hp, cp = z.data_ptr(), out.data_ptr(), s_all.data_ptr(), h.data_ptr(), cond.data_ptr()
+        gop, gsp, gzp, hb = g_out.data_ptr(), g_s.data_ptr(), gz.data_ptr(), R * Hd * F
+        # half B: d out[:, :d1] -> d z[:, :d1] (written), d y2 (own buffer), d cond (written)
+        rc = L.nddm_train_coupling_bwd(op + d1 * F, D, d2, cp, C, zp, D, d1, W1b.data_ptr(), W2b.data_ptr(), W3b.data_ptr(),
+                                       ctx.clamp, R, sp + d2 * F, D, hp + 2 * hb, hp + 3 * hb, gop, D, None, 0, gsp + d2 * F, D,
+                                       g_y2.data_ptr(), d2, 0, gcond.data_ptr(), 0, gzp, D,
+                                       gW[3].data_ptr(), gb[3].data_ptr(), gW[4].data_ptr(), gb[4].data_ptr(), gW[5].data_ptr(),
+                                       gb[5].data_ptr(), st)
+        # half A: d out[:, d1:] + d y2 -> d z[:, d1:] (written), d z[:, :d1] and d cond (accumulated)
+        rc |= L.nddm_train_coupling_bwd(zp, D, d1, cp, C, zp + d1 * F, D, d2, W1a.data_ptr(), W2a.data_ptr(), W3a.data_ptr(),
+                                        ctx.clamp, R, sp, D, hp, hp + hb, gop + d1 * F, D, g_y2.data_ptr(), d2, gsp, D,
+                                        gzp, D, 1, gcond.data_ptr(), 1, gzp + d1 * F, D,
+                                        gW[0].data_ptr(), gb[0].data_ptr(), gW[1].data_ptr(), gb[1].data_ptr(), gW[2].data_ptr(),
+                                        gb[2].data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"nddm_train_coupling_bwd failed ({rc})")
-        return None, None, gxh, gcond, gxtr, gW1, gb1, gW2, gb2, gW3, gb3
+        gu = gz @ pmat.t()                                                     # back through the permutation
+        gx = gu * ex                                                           # ... and the ActNorm
+        return (None, None, None, gx, gcond, (gx * x).sum(0), gu.sum(0), None,
+                gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3], gW[4], gb[4], gW[5], gb[5])
 
 
 class _AffineCoupling(nn.Module):
@@ -183,19 +207,17 @@ class _AffineCoupling(nn.Module):
               and L.nddm_train_coupling_supported(hid, self.d2, cond.shape[1], self.d1))
         return L if ok else None
 
-    def _half(self, L, net, xh, cond, xtr):
-        return _FusedCouplingFn.apply(L, self.clamp, xh, cond, xtr, net[0].weight, net[0].bias, net[2].weight, net[2].bias,
-                                      net[4].weight, net[4].bias)
+    def fused_layer(self, L, x, cond, scale, bias, pmat):
+        """ActNorm(scale, bias) -> permutation -> this coupling layer, fused (see _FusedCouplingLayerFn): -> (y, s [R, D])."""
+        n1, n2 = self.net1, self.net2
+        return _FusedCouplingLayerFn.apply(L, self.clamp, self.d1, x, cond, scale, bias, pmat,
+                                           n1[0].weight, n1[0].bias, n1[2].weight, n1[2].bias, n1[4].weight, n1[4].bias,
+                                           n2[0].weight, n2[0].bias, n2[2].weight, n2[2].bias, n2[4].weight, n2[4].bias)
 
     def forward(self, x, cond):
         """-> (y, [s_a, s_b]): the log-scales are summed ONCE by the caller for all layers (one cat + one sum instead of a
-        sum and an add per half layer, forward and backward)."""
+        sum and an add per half layer, forward and backward).  (The PyTorch composition; the fused form is fused_layer.)"""
         x1, x2 = x[:, :self.d1], x[:, self.d1:]
-        L = self._fused_lib(x, cond)
-        if L is not None:
-            y2, sa = self._half(L, self.net1, x1, cond, x2)
-            y1, sb = self._half(L, self.net2, y2, cond, x1)
-            return torch.cat([y1, y2], dim=-1), [sa, sb]
         sa, t = self._st(self.net1, x1, cond)
         y2 = torch.addcmul(t, x2, torch.exp(sa))               # x2 * exp(s) + t, one kernel fewer each way
         sb, t = self._st(self.net2, y2, cond)
@@ -226,18 +248,23 @@ class InvertibleNetwork(nn.Module):
             perm = torch.randperm(num_params, generator=g)
             self.register_buffer(f"perm{i}", perm)
             self.register_buffer(f"pmat{i}", torch.eye(num_params)[:, perm].contiguous())
-        self.an_scale = nn.Parameter(torch.zeros(num_coupling_layers, num_params))
-        self.an_bias = nn.Parameter(torch.zeros(num_coupling_layers, num_params))
+        # one parameter per layer (not rows of one matrix: selecting a row costs autograd a zero-fill and a copy each way)
+        self.an_scale = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
+        self.an_bias = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
 
     def forward(self, theta, cond):
         z, scales = theta, []
-        an = torch.exp(self.an_scale)
+        L = self.layers[0]._fused_lib(theta, cond) if len(self.layers) else None
         for i, layer in enumerate(self.layers):
-            z = torch.addcmul(self.an_bias[i], z, an[i])
+            if L is not None:
+                z, s_all = layer.fused_layer(L, z, cond, self.an_scale[i], self.an_bias[i], getattr(self, f"pmat{i}"))
+                scales.append(s_all)
+                continue
+            z = torch.addcmul(self.an_bias[i], z, torch.exp(self.an_scale[i]))
             z = z @ getattr(self, f"pmat{i}")                 # == z[:, perm]
             z, s2 = layer(z, cond)
             scales += s2
-        return z, torch.cat(scales, dim=-1).sum(-1) + self.an_scale.sum()
+        return z, torch.cat(scales, dim=-1).sum(-1) + torch.cat(list(self.an_scale)).sum()
 
     def inverse(self, z, cond):
         x = z

@@ -38,7 +38,7 @@ struct Args {
 constexpr int TRF = 8, RPT = TRF / 2;
 constexpr int TRFP = TRF + 4;   // row stride of the transposed activations in LDS: lanes index the UNIT, and a stride of 8 (or 32)
                                 // floats puts a whole wave on two banks; + 4 keeps 16-byte alignment and leaves 4-way conflicts
-__global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, float *s_out, float *h1_out, float *h2_out)
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, int ldy, float *s_out, int lds, float *h1_out, float *h2_out)
 {
     __shared__ float in_s[TRF][DI_MAX];
     __shared__ __attribute__((aligned(16))) float h1t[H][TRFP];        // transposed: [unit][row]
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, flo
         const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
         if (row >= A.R) continue;
         const float s = A.clamp * tanhf(o_s[r][d] / A.clamp);
-        s_out[(long long)row * A.Dt + d] = s;
-        y[(long long)row * A.Dt + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
+        s_out[(long long)row * lds + d] = s;
+        y[(long long)row * ldy + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
     }
 }
 
@@ -129,12 +129,18 @@ struct BwdOut {
     float *gcond;              // [R, C]
     float *gxtr; int ldgt;     // [R, Dt]
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
+    int acc_gxh, acc_gcond;    // add to what gxh / gcond hold instead of overwriting (the second half-layer of a coupling layer)
+};
+struct BwdIn {
+    const float *s; int lds;       // [R, Dt] clamped log-scales saved by the forward
+    const float *gy; int ldgy;     // [R, Dt] gradient of the transformed half
+    const float *gy2; int ldgy2;   // optional second contribution to it (null: none)
+    const float *gs; int ldgs;     // [R, Dt] gradient of the log-scales
 };
 constexpr int NTB = 1024;
 constexpr int TRP = TR + 4;      // (as TRFP: unpadded, the transposing stores and every per-unit read were 32-way bank conflicts)
 
-__global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *s_in, const float *h1_in, const float *h2_in,
-                                                           const float *gy, const float *gs, BwdOut O)
+__global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, BwdIn I, const float *h1_in, const float *h2_in, BwdOut O)
 {
     __shared__ float in_s[TR][DI_MAX];
     __shared__ __attribute__((aligned(16))) float h1t[H][TRP];
@@ -171,8 +177,10 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *
             const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
             float d_os = 0.0f, d_t = 0.0f;
             if (row < A.R) {
-                const float s = s_in[(long long)row * A.Dt + d], es = expf(s), gg = gy[(long long)row * A.Dt + d];
-                const float d_sc = fmaf(gg * A.xtr[(long long)row * A.ldt + d], es, gs[(long long)row * A.Dt + d]);
+                const float s = I.s[(long long)row * I.lds + d], es = expf(s);
+                float gg = I.gy[(long long)row * I.ldgy + d];
+                if (I.gy2) gg += I.gy2[(long long)row * I.ldgy2 + d];
+                const float d_sc = fmaf(gg * A.xtr[(long long)row * A.ldt + d], es, I.gs[(long long)row * I.ldgs + d]);
                 const float u = s / A.clamp;
                 d_os = d_sc * (1.0f - u * u);
                 d_t = gg;
@@ -259,8 +267,13 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, const float *
             float acc = 0.0f;
 #pragma unroll 4
             for (int jj = 0; jj < H; ++jj) acc = fmaf(A.W1[jj * DI + c], h2t[jj][r], acc);
-            if (c < A.Dh) O.gxh[(long long)row * O.ldgh + c] = acc;
-            else O.gcond[(long long)row * A.C + (c - A.Dh)] = acc;
+            if (c < A.Dh) {
+                float *o = &O.gxh[(long long)row * O.ldgh + c];
+                *o = O.acc_gxh ? *o + acc : acc;
+            } else {
+                float *o = &O.gcond[(long long)row * A.C + (c - A.Dh)];
+                *o = O.acc_gcond ? *o + acc : acc;
+            }
         }
     }
 #pragma unroll
@@ -287,23 +300,28 @@ int nddm_train_coupling_supported(int hidden, int Dh, int C, int Dt)
 
 int nddm_train_coupling_fwd(const float *xh, int ldh, int Dh, const float *cond, int C, const float *xtr, int ldt, int Dt,
                             const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
-                            float clamp, int R, float *y, float *s, float *h1, float *h2, void *stream)
+                            float clamp, int R, float *y, int ldy, float *s, int lds, float *h1, float *h2, void *stream)
 {
     if (!nddm_train_coupling_supported(H, Dh, C, Dt) || R <= 0) return 1;
     Args A = {xh, ldh, Dh, cond, C, xtr, ldt, Dt, W1, b1, W2, b2, W3, b3, clamp, R};
-    hipLaunchKernelGGL(coupling_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, y, s, h1, h2);
+    hipLaunchKernelGGL(coupling_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, y, ldy,
+                       s, lds, h1, h2);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+/* gy2 (optional, may be NULL): a second contribution to the gradient of the transformed half, added in the kernel.
+ * acc_gxh / acc_gcond: add to the values gxh / gcond already hold (the other half-layer's contribution) instead of overwriting. */
 int nddm_train_coupling_bwd(const float *xh, int ldh, int Dh, const float *cond, int C, const float *xtr, int ldt, int Dt,
-                            const float *W1, const float *W2, const float *W3, float clamp, int R, const float *s, const float *h1,
-                            const float *h2, const float *gy, const float *gs, float *gxh, int ldgh, float *gcond, float *gxtr,
+                            const float *W1, const float *W2, const float *W3, float clamp, int R, const float *s, int lds,
+                            const float *h1, const float *h2, const float *gy, int ldgy, const float *gy2, int ldgy2,
+                            const float *gs, int ldgs, float *gxh, int ldgh, int acc_gxh, float *gcond, int acc_gcond, float *gxtr,
                             int ldgt, float *gW1, float *gb1, float *gW2, float *gb2, float *gW3, float *gb3, void *stream)
 {
     if (!nddm_train_coupling_supported(H, Dh, C, Dt) || R <= 0) return 1;
     Args A = {xh, ldh, Dh, cond, C, xtr, ldt, Dt, W1, nullptr, W2, nullptr, W3, nullptr, clamp, R};
-    BwdOut O = {gxh, ldgh, gcond, gxtr, ldgt, gW1, gb1, gW2, gb2, gW3, gb3};
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), A, s, h1, h2, gy, gs, O);
+    BwdIn I = {s, lds, gy, ldgy, gy2, ldgy2, gs, ldgs};
+    BwdOut O = {gxh, ldgh, gcond, gxtr, ldgt, gW1, gb1, gW2, gb2, gW3, gb3, acc_gxh, acc_gcond};
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), A, I, h1, h2, O);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

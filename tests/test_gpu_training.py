@@ -198,15 +198,18 @@ def test_graph_trainer_single_trial_model():
     assert np.all(np.isfinite(h_graph)) and np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
 
 
-def test_fused_coupling_half_layer_equals_the_pytorch_path():
-    """csrc/train_kernels.hip: one conditional affine-coupling half-layer (concatenate, three Linear layers, two ELUs, soft
-    clamp, exp, multiply-add) as ONE kernel each way.  Outputs and EVERY gradient (inputs, condition, all six parameter
-    tensors of both sub-networks) equal the PyTorch composition to float32 round-off, for row counts that are not a multiple of
-    the kernel's 32-row tile and span several tiles; the whole flow agrees too, and shapes the kernel does not cover fall back."""
+def test_fused_coupling_layer_equals_the_pytorch_path():
+    """csrc/train_kernels.hip: a conditional affine-coupling half-layer (concatenate, three Linear layers, two ELUs, soft
+    clamp, exp, multiply-add) as ONE kernel each way, and a whole flow layer (ActNorm, permutation, both half-layers) as one
+    autograd node around four launches that read / write column slices through row strides.  Outputs and EVERY gradient
+    (input, condition, ActNorm scale and bias, all twelve parameter tensors of both sub-networks) equal the PyTorch
+    composition to float32 round-off, for row counts that are not a multiple of the kernel's 32-row tile and span several
+    tiles; the whole flow agrees too, and shapes the kernel does not cover fall back."""
     import torch
     from bayesflow_nddms_amd import _train_lib
     from bayesflow_nddms_amd.amortizer import InvertibleNetwork, _AffineCoupling
-    assert _train_lib.lib() is not None, "libnddm_train.so did not build / load"
+    L = _train_lib.lib()
+    assert L is not None, "libnddm_train.so did not build / load"
     torch.manual_seed(3)
     for R in (32, 5, 77, 256):
         layer = _AffineCoupling(5, 11, 128).cuda()
@@ -214,17 +217,26 @@ def test_fused_coupling_half_layer_equals_the_pytorch_path():
             p.data.mul_(3.0)
         x = torch.randn(R, 5, device="cuda", requires_grad=True)
         cond = torch.randn(R, 11, device="cuda", requires_grad=True)
+        scale = (0.3 * torch.randn(5, device="cuda")).requires_grad_()
+        bias = torch.randn(5, device="cuda", requires_grad=True)
+        perm = torch.randperm(5)
+        pmat = torch.eye(5)[:, perm].cuda()
         wy, ws = torch.randn(R, 5, device="cuda"), torch.randn(R, 5, device="cuda")
         out = {}
         for fused in (True, False):
-            layer.fused = fused
-            y, ss = layer(x, cond)
-            loss = (y * wy).sum() + (torch.cat(ss, dim=-1) * ws).sum()
-            grads = torch.autograd.grad(loss, [x, cond] + list(layer.parameters()))
-            out[fused] = [y.detach()] + [s_.detach() for s_ in ss] + [g.detach() for g in grads]
+            if fused:
+                assert layer._fused_lib(x, cond) is L
+                y, s_all = layer.fused_layer(L, x, cond, scale, bias, pmat)
+            else:
+                z = torch.addcmul(bias, x, torch.exp(scale))[:, perm.cuda()]
+                y, ss = layer(z, cond)
+                s_all = torch.cat(ss, dim=-1)
+            loss = (y * wy).sum() + (s_all * ws).sum()
+            grads = torch.autograd.grad(loss, [x, cond, scale, bias] + list(layer.parameters()))
+            out[fused] = [y.detach(), s_all.detach()] + [g.detach() for g in grads]
         for a, b in zip(out[True], out[False]):
-            scale = float(b.abs().max()) + 1e-6
-            assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (R, a.shape, float((a - b).abs().max()), scale)
+            mag = float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= 2e-5 * mag + 1e-6, (R, a.shape, float((a - b).abs().max()), mag)
     net = InvertibleNetwork(num_params=5).cuda()
     theta, cond = torch.randn(64, 5, device="cuda"), torch.randn(64, 11, device="cuda")
     res = {}
