@@ -1,4 +1,4 @@
-"""ctypes binding of libnddm_train.so: the fused coupling half-layer of the amortizer's flow (csrc/train_kernels.hip).
+"""ctypes binding of libnddm_train.so: the amortizer's flow as one kernel each way (csrc/train_kernels.hip).
 Optional: `lib()` returns None when the library cannot be built or loaded, and the amortizer then runs its PyTorch path."""
 import ctypes
 import os
@@ -22,12 +22,13 @@ def lib():
         return None
     c = ctypes
     fp, vp, i32, f32 = c.c_void_p, c.c_void_p, c.c_int, c.c_float
-    L.nddm_train_coupling_supported.argtypes = [i32] * 4
-    L.nddm_train_coupling_supported.restype = i32
-    L.nddm_train_coupling_fwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, fp, fp, fp, f32, i32, fp, i32, fp, i32, fp, fp, vp]
-    L.nddm_train_coupling_fwd.restype = i32
-    L.nddm_train_coupling_bwd.argtypes = [fp, i32, i32, fp, i32, fp, i32, i32, fp, fp, fp, f32, i32, fp, i32, fp, fp, fp, i32, fp, i32,
-                                          fp, i32, fp, i32, i32, fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, vp]
-    L.nddm_train_coupling_bwd.restype = i32
+    L.nddm_train_flow_supported.argtypes = [i32] * 5
+    L.nddm_train_flow_supported.restype = i32
+    #                               L    R    D    d1   C    clamp params perm theta cond z_all out_all s_all h_all ld stream
+    L.nddm_train_flow_fwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, fp, fp, fp, fp, fp, fp, fp, vp]
+    L.nddm_train_flow_fwd.restype = i32
+    #                               ... params perm grads theta cond z_all out_all s_all h_all g_z g_ld gz gy2 gx gcond stream
+    L.nddm_train_flow_bwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
+    L.nddm_train_flow_bwd.restype = i32
     _lib = L
     return _lib

@@ -109,75 +109,61 @@ class InvariantNetwork(nn.Module):
         return self.post_pool(pooled)
 
 
-class _FusedCouplingLayerFn(torch.autograd.Function):
-    """One whole flow layer -- ActNorm, fixed permutation, both conditional affine-coupling half-layers -- with the
-    half-layers as ONE hand-written kernel each way (csrc/train_kernels.hip: concatenate, three Linear layers with two ELUs,
-    soft clamp, exp, multiply-add; 33 PyTorch launches of a few microseconds at batch 32) and NO autograd bookkeeping
-    between them: the kernels read and write column slices of [R, D] buffers through row strides, the second half-layer
-    accumulates into the first one's input and condition gradients, so the slices, concatenations and per-row selects that
-    cost autograd ~20 tiny launches per layer backward are gone.  Returns (y, s): the layer's output and the clamped log-scales
-    of its D transformed columns (their row sums are its coupling log|det|)."""
+class _FusedFlowFn(torch.autograd.Function):
+    """The whole conditional flow -- per layer an ActNorm, a fixed permutation and two conditional affine-coupling half-layers
+    (concatenate, three Linear layers with two ELUs, soft clamp, exp, multiply-add) -- as ONE hand-written kernel forward and ONE
+    backward (csrc/train_kernels.hip) and one autograd node: at batch 32 the PyTorch composition is ~400 launches of a few
+    microseconds each way, with a slice / concatenate / select bookkeeping kernel between any two.
+    -> (z [R, D], log|det| [R]).  params: per layer ActNorm log-scale and bias, then weight, bias x 3 of both sub-networks."""
 
     @staticmethod
-    def forward(ctx, L, clamp, d1, x, cond, scale, bias, pmat, W1a, b1a, W2a, b2a, W3a, b3a, W1b, b1b, W2b, b2b, W3b, b3b):
-        R, D, C = x.shape[0], x.shape[1], cond.shape[1]
-        d2, Hd, F = D - d1, W2a.shape[0], 4
-        x, cond = x.contiguous(), cond.contiguous()
-        ex = torch.exp(scale)
-        z = torch.addcmul(bias, x, ex) @ pmat                                  # ActNorm, then z[:, perm]
-        out, s_all = torch.empty_like(z), torch.empty_like(z)
-        h = torch.empty((4, R, Hd), dtype=torch.float32, device=x.device)      # saved activations of both sub-networks
-        st = torch.cuda.current_stream(x.device).cuda_stream
-        zp, op, sp, hp, cp = z.data_ptr(), out.data_ptr(), s_all.data_ptr(), h.data_ptr(), cond.data_ptr()
-        hb = R * Hd * F
-        # half A (net 1): conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s_all[:, :d2]
-        rc = L.nddm_train_coupling_fwd(zp, D, d1, cp, C, zp + d1 * F, D, d2, W1a.data_ptr(), b1a.data_ptr(), W2a.data_ptr(),
-                                       b2a.data_ptr(), W3a.data_ptr(), b3a.data_ptr(), float(clamp), R, op + d1 * F, D, sp, D,
-                                       hp, hp + hb, st)
-        # half B (net 2): conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s_all[:, d2:]
-        rc |= L.nddm_train_coupling_fwd(op + d1 * F, D, d2, cp, C, zp, D, d1, W1b.data_ptr(), b1b.data_ptr(), W2b.data_ptr(),
-                                        b2b.data_ptr(), W3b.data_ptr(), b3b.data_ptr(), float(clamp), R, op, D, sp + d2 * F, D,
-                                        hp + 2 * hb, hp + 3 * hb, st)
+    def forward(ctx, L, clamp, d1, perms, theta, cond, *params):
+        import ctypes
+        nl, (R, D), C = len(perms), theta.shape, cond.shape[1]
+        Hd, dev = params[4].shape[0], theta.device
+        theta, cond = theta.contiguous(), cond.contiguous()
+        saved = torch.empty(3 * nl * R * D + 4 * nl * R * Hd, dtype=torch.float32, device=dev)
+        z_all, out_all, s_all = (saved[i * nl * R * D:(i + 1) * nl * R * D].view(nl, R, D) for i in range(3))
+        h_all = saved[3 * nl * R * D:]
+        ld = torch.empty(R, dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * (14 * nl))(*[p.data_ptr() for p in params])
+        perm = (ctypes.c_int * (nl * D))(*[int(v) for p in perms for v in p])
+        rc = L.nddm_train_flow_fwd(nl, R, D, d1, C, float(clamp), ptrs, perm, theta.data_ptr(), cond.data_ptr(), z_all.data_ptr(),
+                                   out_all.data_ptr(), s_all.data_ptr(), h_all.data_ptr(), ld.data_ptr(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
-            raise RuntimeError(f"nddm_train_coupling_fwd failed ({rc})")
-        ctx.L, ctx.clamp, ctx.d1 = L, float(clamp), d1
-        ctx.save_for_backward(x, cond, ex, pmat, z, out, s_all, h, W1a, W2a, W3a, W1b, W2b, W3b)
-        return out, s_all
+            raise RuntimeError(f"nddm_train_flow_fwd failed ({rc})")
+        ctx.L, ctx.clamp, ctx.d1, ctx.perm, ctx.ptrs, ctx.nl = L, float(clamp), d1, perm, ptrs, nl
+        ctx.save_for_backward(theta, cond, saved, *params)
+        return out_all[nl - 1], ld
 
     @staticmethod
-    def backward(ctx, g_out, g_s):
-        x, cond, ex, pmat, z, out, s_all, h, W1a, W2a, W3a, W1b, W2b, W3b = ctx.saved_tensors
-        L, d1, F = ctx.L, ctx.d1, 4
-        R, D, C = x.shape[0], x.shape[1], cond.shape[1]
-        d2, Hd, dev = D - d1, W2a.shape[0], x.device
-        g_out = g_out.contiguous() if g_out is not None else torch.zeros_like(out)
-        g_s = g_s.contiguous() if g_s is not None else torch.zeros_like(out)
-        gz = torch.empty_like(z)
-        gcond = torch.empty((R, C), dtype=torch.float32, device=dev)
-        g_y2 = torch.empty((R, d2), dtype=torch.float32, device=dev)           # through net 2's conditioning input
-        gW = [torch.empty_like(w) for w in (W1a, W2a, W3a, W1b, W2b, W3b)]
-        gb = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in (W1a, W2a, W3a, W1b, W2b, W3b)]
-        st = torch.cuda.current_stream(dev).cuda_stream
-        zp, op, sp, hp, cp = z.data_ptr(), out.data_ptr(), s_all.data_ptr(), h.data_ptr(), cond.data_ptr()
-        gop, gsp, gzp, hb = g_out.data_ptr(), g_s.data_ptr(), gz.data_ptr(), R * Hd * F
-        # half B: d out[:, :d1] -> d z[:, :d1] (written), d y2 (own buffer), d cond (written)
-        rc = L.nddm_train_coupling_bwd(op + d1 * F, D, d2, cp, C, zp, D, d1, W1b.data_ptr(), W2b.data_ptr(), W3b.data_ptr(),
-                                       ctx.clamp, R, sp + d2 * F, D, hp + 2 * hb, hp + 3 * hb, gop, D, None, 0, gsp + d2 * F, D,
-                                       g_y2.data_ptr(), d2, 0, gcond.data_ptr(), 0, gzp, D,
-                                       gW[3].data_ptr(), gb[3].data_ptr(), gW[4].data_ptr(), gb[4].data_ptr(), gW[5].data_ptr(),
-                                       gb[5].data_ptr(), st)
-        # half A: d out[:, d1:] + d y2 -> d z[:, d1:] (written), d z[:, :d1] and d cond (accumulated)
-        rc |= L.nddm_train_coupling_bwd(zp, D, d1, cp, C, zp + d1 * F, D, d2, W1a.data_ptr(), W2a.data_ptr(), W3a.data_ptr(),
-                                        ctx.clamp, R, sp, D, hp, hp + hb, gop + d1 * F, D, g_y2.data_ptr(), d2, gsp, D,
-                                        gzp, D, 1, gcond.data_ptr(), 1, gzp + d1 * F, D,
-                                        gW[0].data_ptr(), gb[0].data_ptr(), gW[1].data_ptr(), gb[1].data_ptr(), gW[2].data_ptr(),
-                                        gb[2].data_ptr(), st)
+    def backward(ctx, g_z, g_ld):
+        import ctypes
+        theta, cond, saved, *params = ctx.saved_tensors
+        L, nl, d1 = ctx.L, ctx.nl, ctx.d1
+        (R, D), C, dev = theta.shape, cond.shape[1], theta.device
+        Hd = params[4].shape[0]
+        n_rd = nl * R * D
+        g_z = g_z.contiguous() if g_z is not None else torch.zeros_like(theta)
+        g_ld = g_ld.contiguous() if g_ld is not None else torch.zeros(R, dtype=torch.float32, device=dev)
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes) + 2 * R * D + R * (D - d1) + R * C, dtype=torch.float32, device=dev)
+        grads, o = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[o:o + n].view(p.shape))
+            o += n
+        gz, gx, gy2, gcond = flat[o:o + R * D], flat[o + R * D:o + 2 * R * D], flat[o + 2 * R * D:o + 2 * R * D + R * (D - d1)], \
+            flat[o + 2 * R * D + R * (D - d1):]
+        gptr = (ctypes.c_void_p * (14 * nl))(*[g.data_ptr() for g in grads])
+        sp, F = saved.data_ptr(), 4
+        rc = L.nddm_train_flow_bwd(nl, R, D, d1, C, ctx.clamp, ctx.ptrs, ctx.perm, gptr, theta.data_ptr(), cond.data_ptr(),
+                                   sp, sp + n_rd * F, sp + 2 * n_rd * F, sp + 3 * n_rd * F, g_z.data_ptr(), g_ld.data_ptr(),
+                                   gz.data_ptr(), gy2.data_ptr(), gx.data_ptr(), gcond.data_ptr(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
-            raise RuntimeError(f"nddm_train_coupling_bwd failed ({rc})")
-        gu = gz @ pmat.t()                                                     # back through the permutation
-        gx = gu * ex                                                           # ... and the ActNorm
-        return (None, None, None, gx, gcond, (gx * x).sum(0), gu.sum(0), None,
-                gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3], gW[4], gb[4], gW[5], gb[5])
+            raise RuntimeError(f"nddm_train_flow_bwd failed ({rc})")
+        return (None, None, None, None, gx.view(R, D), gcond.view(R, C), *grads)
 
 
 class _AffineCoupling(nn.Module):
@@ -193,30 +179,10 @@ class _AffineCoupling(nn.Module):
         s, t = net(torch.cat([h, cond], dim=-1)).chunk(2, dim=-1)
         return self.clamp * torch.tanh(s / self.clamp), t
 
-    fused = True          # use the fused HIP half-layer where it applies (GPU, float32, hidden width 128; else PyTorch)
-
-    def _fused_lib(self, x, cond):
-        if not (self.fused and x.is_cuda and x.dtype == torch.float32 and cond.dtype == torch.float32):
-            return None
-        from . import _train_lib
-        L = _train_lib.lib()
-        hid = self.net1[0].weight.shape[0]
-        if L is None or len(self.net1) != 5 or not isinstance(self.net1[1], nn.ELU):
-            return None
-        ok = (L.nddm_train_coupling_supported(hid, self.d1, cond.shape[1], self.d2)
-              and L.nddm_train_coupling_supported(hid, self.d2, cond.shape[1], self.d1))
-        return L if ok else None
-
-    def fused_layer(self, L, x, cond, scale, bias, pmat):
-        """ActNorm(scale, bias) -> permutation -> this coupling layer, fused (see _FusedCouplingLayerFn): -> (y, s [R, D])."""
-        n1, n2 = self.net1, self.net2
-        return _FusedCouplingLayerFn.apply(L, self.clamp, self.d1, x, cond, scale, bias, pmat,
-                                           n1[0].weight, n1[0].bias, n1[2].weight, n1[2].bias, n1[4].weight, n1[4].bias,
-                                           n2[0].weight, n2[0].bias, n2[2].weight, n2[2].bias, n2[4].weight, n2[4].bias)
 
     def forward(self, x, cond):
         """-> (y, [s_a, s_b]): the log-scales are summed ONCE by the caller for all layers (one cat + one sum instead of a
-        sum and an add per half layer, forward and backward).  (The PyTorch composition; the fused form is fused_layer.)"""
+        sum and an add per half layer, forward and backward).  (The PyTorch composition; the fused form is _FusedFlowFn.)"""
         x1, x2 = x[:, :self.d1], x[:, self.d1:]
         sa, t = self._st(self.net1, x1, cond)
         y2 = torch.addcmul(t, x2, torch.exp(sa))               # x2 * exp(s) + t, one kernel fewer each way
@@ -251,15 +217,36 @@ class InvertibleNetwork(nn.Module):
         # one parameter per layer (not rows of one matrix: selecting a row costs autograd a zero-fill and a copy each way)
         self.an_scale = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
         self.an_bias = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
+        self.fused = True           # the hand-written kernels where they apply (False: always the PyTorch composition)
+        self._refresh_host_perms()  # (host copies: reading the buffers back would synchronise, which a graph capture forbids)
+        self.register_load_state_dict_post_hook(self._refresh_host_perms)
+
+    def _fused_lib(self, theta, cond):
+        """libnddm_train.so if the fused flow covers this network and these tensors, else None (the PyTorch composition)."""
+        if not (self.fused and len(self.layers) and theta.is_cuda and theta.dtype == torch.float32 and cond.dtype == torch.float32):
+            return None
+        l0 = self.layers[0]
+        if any(len(n) != 5 or not isinstance(n[1], nn.ELU) for l in self.layers for n in (l.net1, l.net2)):
+            return None
+        from . import _train_lib
+        L = _train_lib.lib()
+        ok = L is not None and L.nddm_train_flow_supported(l0.net1[0].weight.shape[0], len(self.layers), self.num_params, l0.d1,
+                                                           cond.shape[1])
+        return L if ok else None
+
+    def _refresh_host_perms(self, *_):
+        self._perm_host = [getattr(self, f"perm{i}").tolist() for i in range(len(self.layers))]
 
     def forward(self, theta, cond):
+        L = self._fused_lib(theta, cond)
+        if L is not None:
+            params = []
+            for i, l in enumerate(self.layers):
+                params += [self.an_scale[i], self.an_bias[i]]
+                params += [t for n in (l.net1, l.net2) for k in (0, 2, 4) for t in (n[k].weight, n[k].bias)]
+            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, theta, cond, *params)
         z, scales = theta, []
-        L = self.layers[0]._fused_lib(theta, cond) if len(self.layers) else None
         for i, layer in enumerate(self.layers):
-            if L is not None:
-                z, s_all = layer.fused_layer(L, z, cond, self.an_scale[i], self.an_bias[i], getattr(self, f"pmat{i}"))
-                scales.append(s_all)
-                continue
             z = torch.addcmul(self.an_bias[i], z, torch.exp(self.an_scale[i]))
             z = z @ getattr(self, f"pmat{i}")                 # == z[:, perm]
             z, s2 = layer(z, cond)

@@ -1,10 +1,13 @@
-// train_kernels.hip -- fused forward / backward of ONE conditional affine-coupling half-layer of the amortizer's flow
-// (bayesflow_nddms_amd/amortizer.py::_AffineCoupling; the stand-in for bf.networks.InvertibleNetwork, basic_ddm_dc.py:163-165),
-// for the batch sizes of the online-training loop (32 sets per rank: basic_ddm_dc.py:199-202).
+// train_kernels.hip -- the amortizer's conditional normalising flow (bayesflow_nddms_amd/amortizer.py::InvertibleNetwork; the
+// stand-in for bf.networks.InvertibleNetwork, basic_ddm_dc.py:163-165) as ONE kernel forward and ONE backward, for the batch
+// sizes of the online-training loop (32 sets per rank: basic_ddm_dc.py:199-202): per layer an ActNorm, a fixed permutation and
+// two conditional affine-coupling half-layers.
 //
 // At batch 32 the flow is ~400 of the ~650 kernels of a graph-replayed training iteration, each a 3-5 microsecond launch that
 // touches a few kilobytes: concatenate, three GEMMs of 32 rows, two ELUs, the soft clamp, exp, multiply-add, and twice that
-// backward -- 33 launches per half-layer, twelve half-layers.  Here a half-layer is ONE launch each way:
+// backward -- 33 launches per half-layer, twelve half-layers.  Here a half-layer is one device function each way, and the
+// kernels walk the layers (rows are independent forward; backward one workgroup owns every row, so the weight gradients are
+// plain register sums); everything between the layers (slices, concatenations, ActNorm, permutation) is index arithmetic:
 //     in = [x_h | cond]  ->  h1 = elu(W1 in + b1)  ->  h2 = elu(W2 h1 + b2)  ->  (o_s | o_t) = W3 h2 + b3
 //     s = clamp * tanh(o_s / clamp),   y = x_tr * exp(s) + o_t                      (returns y and s; log|det| = sum of s)
 // Not MFMA work: 32 x 128 x 128 multiply-adds per GEMM is a microsecond of plain FMAs; what is bought is launches.
@@ -38,14 +41,15 @@ struct Args {
 constexpr int TRF = 8, RPT = TRF / 2;
 constexpr int TRFP = TRF + 4;   // row stride of the transposed activations in LDS: lanes index the UNIT, and a stride of 8 (or 32)
                                 // floats puts a whole wave on two banks; + 4 keeps 16-byte alignment and leaves 4-way conflicts
-__global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, int ldy, float *s_out, int lds, float *h1_out, float *h2_out)
+__device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, float *y, int ldy, float *s_out, int lds, float *h1_out,
+                                               float *h2_out)
 {
     __shared__ float in_s[TRF][DI_MAX];
     __shared__ __attribute__((aligned(16))) float h1t[H][TRFP];        // transposed: [unit][row]
     __shared__ __attribute__((aligned(16))) float h2t[H][TRFP];
     __shared__ float o_s[TRF][M_MAX];
     const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7;
-    const int r0 = blockIdx.x * TRF, DI = A.Dh + A.C, M = 2 * A.Dt;
+    const int DI = A.Dh + A.C, M = 2 * A.Dt;
     for (int p = t; p < TRF * DI; p += 256) {
         const int r = p / DI, c = p - r * DI, row = r0 + r;
         float v = 0.0f;
@@ -115,6 +119,52 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(Args A, float *y, int
         s_out[(long long)row * lds + d] = s;
         y[(long long)row * ldy + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
     }
+    __syncthreads();                  // the outputs are visible to the workgroup, and the LDS arrays are free again
+}
+
+// ---- the whole flow forward.  grid = ceil(R / TRF) workgroups of 256 threads, each takes its rows through every layer.
+constexpr int L_MAX = 8, D_MAX = 8;
+struct HalfP { const float *W1, *b1, *W2, *b2, *W3, *b3; };
+struct LayerP { const float *scale, *bias; HalfP a, b; };
+struct FlowP { LayerP layer[L_MAX]; unsigned char perm[L_MAX][D_MAX]; };
+struct FlowDims { int L, R, D, d1, C; float clamp; };
+struct FlowSaved { float *z_all, *out_all, *s_all, *h_all; };    // [L, R, D] permuted ActNorm outputs, layer outputs, clamped
+                                                                  // log-scales; [L, 4, R, H] activations of the sub-networks
+__global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
+{
+    const int t = threadIdx.x, r0 = blockIdx.x * TRF, D = Q.D, d1 = Q.d1, d2 = D - d1;
+    const long long RD = (long long)Q.R * D, RH = (long long)Q.R * H;
+    for (int hl = 0; hl < 2 * Q.L; ++hl) {                  // half-layers: ONE copy of the tile function's code
+        const int l = hl >> 1;
+        const bool second = hl & 1;
+        const LayerP &Y = P.layer[l];
+        const float *x = l ? S.out_all + (l - 1) * RD : theta;
+        float *z = S.z_all + l * RD, *out = S.out_all + l * RD, *sl = S.s_all + l * RD, *h = S.h_all + 4 * l * RH;
+        if (!second) {
+            if (t < TRF * D) {                               // ActNorm, then the permutation: z[:, c] = u[:, perm[c]]
+                const int r = t / D, c = t - r * D, row = r0 + r;
+                if (row < Q.R) {
+                    const int p = P.perm[l][c];
+                    z[(long long)row * D + c] = fmaf(x[(long long)row * D + p], expf(Y.scale[p]), Y.bias[p]);
+                }
+            }
+            __syncthreads();
+        }
+        // first:  conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s[:, :d2]
+        // second: conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s[:, d2:]
+        const HalfP &W = second ? Y.b : Y.a;
+        const Args A = {second ? out + d1 : z, D, second ? d2 : d1, cond, Q.C, second ? z : z + d1, D, second ? d1 : d2,
+                        W.W1, W.b1, W.W2, W.b2, W.W3, W.b3, Q.clamp, Q.R};
+        coupling_fwd_tile(A, r0, second ? out : out + d1, D, second ? sl + d2 : sl, D, h + (second ? 2 : 0) * RH,
+                          h + (second ? 3 : 1) * RH);
+    }
+    if (t < TRF && r0 + t < Q.R) {                           // log|det| of the row: every log-scale, and the ActNorms'
+        const int row = r0 + t;
+        float acc = 0.0f;
+        for (int l = 0; l < Q.L; ++l)
+            for (int d = 0; d < D; ++d) acc += S.s_all[l * RD + (long long)row * D + d] + P.layer[l].scale[d];
+        ld[row] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -135,12 +185,12 @@ struct BwdIn {
     const float *s; int lds;       // [R, Dt] clamped log-scales saved by the forward
     const float *gy; int ldgy;     // [R, Dt] gradient of the transformed half
     const float *gy2; int ldgy2;   // optional second contribution to it (null: none)
-    const float *gs; int ldgs;     // [R, Dt] gradient of the log-scales
+    const float *gs;               // [R] gradient of the row's log|det| (= of every one of its log-scales)
 };
 constexpr int NTB = 1024;
 constexpr int TRP = TR + 4;      // (as TRFP: unpadded, the transposing stores and every per-unit read were 32-way bank conflicts)
 
-__global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, BwdIn I, const float *h1_in, const float *h2_in, BwdOut O)
+__device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I, const float *h1_in, const float *h2_in, const BwdOut &O)
 {
     __shared__ float in_s[TR][DI_MAX];
     __shared__ __attribute__((aligned(16))) float h1t[H][TRP];
@@ -149,7 +199,7 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, BwdIn I, cons
     __shared__ float do_s[TR][M_MAX];
     __shared__ float w2s[H][H];           // W2 staged once (64 KB of gfx950's 160 KB): its column reads below were the kernel's latency
     const int t = threadIdx.x, j = t & (H - 1), g = t >> 7;
-    for (int p = t; p < H * H; p += NTB) w2s[p >> 7][p & (H - 1)] = A.W2[p];
+    for (int p = t; p < H * H; p += NTB) (&w2s[0][0])[p] = A.W2[p];     // (flat: one address register and immediates)
     const int DI = A.Dh + A.C, M = 2 * A.Dt;
     float dW2[16], dW1[DI_MAX / 8], dW3[M_MAX / 8];
     float db2 = 0.0f, db1 = 0.0f, db3 = 0.0f;
@@ -180,7 +230,7 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, BwdIn I, cons
                 const float s = I.s[(long long)row * I.lds + d], es = expf(s);
                 float gg = I.gy[(long long)row * I.ldgy + d];
                 if (I.gy2) gg += I.gy2[(long long)row * I.ldgy2 + d];
-                const float d_sc = fmaf(gg * A.xtr[(long long)row * A.ldt + d], es, I.gs[(long long)row * I.ldgs + d]);
+                const float d_sc = fmaf(gg * A.xtr[(long long)row * A.ldt + d], es, I.gs[row]);
                 const float u = s / A.clamp;
                 d_os = d_sc * (1.0f - u * u);
                 d_t = gg;
@@ -286,42 +336,128 @@ __global__ __launch_bounds__(NTB) void coupling_bwd_kernel(Args A, BwdIn I, cons
     if (t < M) O.gb3[t] = db3;
 }
 
+// ---- the whole flow backward: one workgroup of 1024 threads, half-layers last to first.  The host resolves every half-layer's
+// pointers into a table in the kernel arguments (the loop body then reads its operands like a one-half-layer kernel would).
+struct HalfB {
+    const float *xh, *xtr, *W1, *W2, *W3, *s, *h1, *h2, *gy, *gy2;
+    float *gxh, *gxtr, *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
+    int Dh, Dt, ldgh, acc_gxh, acc_gcond, norm;          // norm: the layer's ActNorm / permutation backward follows (-1: no)
+};
+struct NormB { const float *x, *scale; float *gscale, *gbias; unsigned char perm[D_MAX]; };
+struct FlowB { HalfB half[2 * L_MAX]; NormB norm[L_MAX]; };
+struct FlowBwdBuf {
+    const float *g_ld;             // [R] gradient of the flow's log|det|
+    const float *gz;               // [R, D] scratch the half-layers write: gradient of a layer's permuted ActNorm output
+    float *gx;                     // [R, D]: gradient of a layer's input; after layer 0, of theta
+    float *gcond;                  // [R, C]
+};
+__global__ __launch_bounds__(NTB) void flow_bwd_kernel(FlowDims Q, FlowB T, const float *cond, FlowBwdBuf U)
+{
+    const int t = threadIdx.x, D = Q.D;
+    for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
+        const HalfB &X = T.half[hl];
+        const Args A = {X.xh, D, X.Dh, cond, Q.C, X.xtr, D, X.Dt, X.W1, nullptr, X.W2, nullptr, X.W3, nullptr, Q.clamp, Q.R};
+        const BwdIn I = {X.s, D, X.gy, D, X.gy2, D - Q.d1, U.g_ld};
+        const BwdOut O = {X.gxh, X.ldgh, U.gcond, X.gxtr, D, X.gW1, X.gb1, X.gW2, X.gb2, X.gW3, X.gb3, X.acc_gxh, X.acc_gcond};
+        coupling_bwd_body(A, I, X.h1, X.h2, O);
+        if (X.norm < 0) continue;
+        __syncthreads();
+        // back through the permutation and the ActNorm: 32 threads per column
+        const NormB &N = T.norm[X.norm];
+        if (t < 32 * D) {
+            const int c = t >> 5, i = t & 31, p = N.perm[c];
+            const float ex = expf(N.scale[p]);
+            float sb = 0.0f, ss = 0.0f, sd = 0.0f;
+            for (int row = i; row < Q.R; row += 32) {
+                const float g = U.gz[(long long)row * D + c], gxv = g * ex;
+                U.gx[(long long)row * D + p] = gxv;
+                sb += g;
+                ss = fmaf(gxv, N.x[(long long)row * D + p], ss);
+                sd += U.g_ld[row];
+            }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                sb += __shfl_xor(sb, m, 32);
+                ss += __shfl_xor(ss, m, 32);
+                sd += __shfl_xor(sd, m, 32);
+            }
+            if (i == 0) { N.gbias[p] = sb; N.gscale[p] = ss + sd; }
+        }
+        // (the next half-layer's first tile starts with a barrier: U.gx is visible by then)
+    }
+}
+
 }  // namespace nddm_train
 
 using namespace nddm_train;
 
 extern "C" {
 
-// returns 0, or 1 for shapes the fused path does not cover (the caller then takes the PyTorch path)
-int nddm_train_coupling_supported(int hidden, int Dh, int C, int Dt)
+// 1 for the shapes the fused flow covers (the caller takes the PyTorch path otherwise)
+int nddm_train_flow_supported(int hidden, int L, int D, int d1, int C)
 {
-    return (hidden == H && Dh >= 1 && C >= 0 && Dh + C <= DI_MAX && Dt >= 1 && 2 * Dt <= M_MAX) ? 1 : 0;
+    const int d2 = D - d1;
+    return (hidden == H && L >= 1 && L <= L_MAX && D >= 2 && D <= D_MAX && d1 >= 1 && d2 >= 1 && d1 + C <= DI_MAX && d2 + C <= DI_MAX
+            && C >= 0 && 2 * d1 <= M_MAX && 2 * d2 <= M_MAX) ? 1 : 0;
 }
 
-int nddm_train_coupling_fwd(const float *xh, int ldh, int Dh, const float *cond, int C, const float *xtr, int ldt, int Dt,
-                            const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
-                            float clamp, int R, float *y, int ldy, float *s, int lds, float *h1, float *h2, void *stream)
+/* params: L x 14 device pointers per layer -- ActNorm log-scale [D] and bias [D], then W1 [H, Dh + C], b1 [H], W2 [H, H], b2 [H],
+ * W3 [2 Dt, H], b3 [2 Dt] of sub-network 1 (conditioned on the first d1 columns) and of sub-network 2; perm: L x D host ints. */
+static void fill(FlowP &P, int L, int D, const void *const *params, const int *perm)
 {
-    if (!nddm_train_coupling_supported(H, Dh, C, Dt) || R <= 0) return 1;
-    Args A = {xh, ldh, Dh, cond, C, xtr, ldt, Dt, W1, b1, W2, b2, W3, b3, clamp, R};
-    hipLaunchKernelGGL(coupling_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, y, ldy,
-                       s, lds, h1, h2);
+    for (int l = 0; l < L; ++l) {
+        const float *const *q = reinterpret_cast<const float *const *>(params) + 14 * l;
+        P.layer[l] = {q[0], q[1], {q[2], q[3], q[4], q[5], q[6], q[7]}, {q[8], q[9], q[10], q[11], q[12], q[13]}};
+        for (int d = 0; d < D; ++d) P.perm[l][d] = (unsigned char)perm[l * D + d];
+    }
+}
+
+/* -> z = out_all[L - 1] and ld [R] (log|det|, ActNorm terms included); z_all / out_all / s_all [L, R, D] and h_all [L, 4, R, H]
+ * are what the backward needs. */
+int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
+                        const float *theta, const float *cond, float *z_all, float *out_all, float *s_all, float *h_all, float *ld,
+                        void *stream)
+{
+    if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
+    for (int i = 0; i < L * D; ++i) if (perm[i] < 0 || perm[i] >= D) return 1;
+    FlowP P = {};
+    fill(P, L, D, params, perm);
+    const FlowDims Q = {L, R, D, d1, C, clamp};
+    const FlowSaved S = {z_all, out_all, s_all, h_all};
+    hipLaunchKernelGGL(flow_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta,
+                       cond, S, ld);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-/* gy2 (optional, may be NULL): a second contribution to the gradient of the transformed half, added in the kernel.
- * acc_gxh / acc_gcond: add to the values gxh / gcond already hold (the other half-layer's contribution) instead of overwriting. */
-int nddm_train_coupling_bwd(const float *xh, int ldh, int Dh, const float *cond, int C, const float *xtr, int ldt, int Dt,
-                            const float *W1, const float *W2, const float *W3, float clamp, int R, const float *s, int lds,
-                            const float *h1, const float *h2, const float *gy, int ldgy, const float *gy2, int ldgy2,
-                            const float *gs, int ldgs, float *gxh, int ldgh, int acc_gxh, float *gcond, int acc_gcond, float *gxtr,
-                            int ldgt, float *gW1, float *gb1, float *gW2, float *gb2, float *gW3, float *gb3, void *stream)
+/* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results.
+ * gz [R, D] and gy2 [R, D - d1] are scratch; gx [R, D] ends as the gradient of theta, gcond [R, C] as that of the condition. */
+int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
+                        void *const *grads, const float *theta, const float *cond, float *z_all, float *out_all, float *s_all,
+                        float *h_all, const float *g_z, const float *g_ld, float *gz, float *gy2, float *gx, float *gcond, void *stream)
 {
-    if (!nddm_train_coupling_supported(H, Dh, C, Dt) || R <= 0) return 1;
-    Args A = {xh, ldh, Dh, cond, C, xtr, ldt, Dt, W1, nullptr, W2, nullptr, W3, nullptr, clamp, R};
-    BwdIn I = {s, lds, gy, ldgy, gy2, ldgy2, gs, ldgs};
-    BwdOut O = {gxh, ldgh, gcond, gxtr, ldgt, gW1, gb1, gW2, gb2, gW3, gb3, acc_gxh, acc_gcond};
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), A, I, h1, h2, O);
+    if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
+    for (int i = 0; i < L * D; ++i) if (perm[i] < 0 || perm[i] >= D) return 1;
+    const int d2 = D - d1;
+    const long long RD = (long long)R * D, RH = (long long)R * H;
+    FlowB T = {};
+    for (int l = 0; l < L; ++l) {
+        const float *const *q = reinterpret_cast<const float *const *>(params) + 14 * l;
+        float *const *g = reinterpret_cast<float *const *>(grads) + 14 * l;
+        const float *x = l ? out_all + (l - 1) * RD : theta;
+        const float *z = z_all + l * RD, *out = out_all + l * RD, *sl = s_all + l * RD, *h = h_all + 4 * l * RH;
+        const float *g_out = l == L - 1 ? g_z : gx;
+        // sub-network 2 (runs first): d out[:, :d1] -> d z[:, :d1] (written), d out[:, d1:] through its input (gy2), d cond
+        T.half[2 * l + 1] = {out + d1, z, q[8], q[10], q[12], sl + d2, h + 2 * RH, h + 3 * RH, g_out, nullptr,
+                             gy2, gz, g[8], g[9], g[10], g[11], g[12], g[13], d2, d1, d2, 0, l != L - 1, -1};
+        // sub-network 1: d out[:, d1:] + gy2 -> d z[:, d1:] (written), d z[:, :d1] and d cond (accumulated)
+        T.half[2 * l] = {z, z + d1, q[2], q[4], q[6], sl, h, h + RH, g_out + d1, gy2,
+                         gz, gz + d1, g[2], g[3], g[4], g[5], g[6], g[7], d1, d2, D, 1, 1, l};
+        T.norm[l] = {x, q[0], g[0], g[1], {}};
+        for (int d = 0; d < D; ++d) T.norm[l].perm[d] = (unsigned char)perm[l * D + d];
+    }
+    const FlowDims Q = {L, R, D, d1, C, clamp};
+    const FlowBwdBuf U = {g_ld, gz, gx, gcond};
+    hipLaunchKernelGGL(flow_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), Q, T, cond, U);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -198,56 +198,39 @@ def test_graph_trainer_single_trial_model():
     assert np.all(np.isfinite(h_graph)) and np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
 
 
-def test_fused_coupling_layer_equals_the_pytorch_path():
-    """csrc/train_kernels.hip: a conditional affine-coupling half-layer (concatenate, three Linear layers, two ELUs, soft
-    clamp, exp, multiply-add) as ONE kernel each way, and a whole flow layer (ActNorm, permutation, both half-layers) as one
-    autograd node around four launches that read / write column slices through row strides.  Outputs and EVERY gradient
-    (input, condition, ActNorm scale and bias, all twelve parameter tensors of both sub-networks) equal the PyTorch
-    composition to float32 round-off, for row counts that are not a multiple of the kernel's 32-row tile and span several
-    tiles; the whole flow agrees too, and shapes the kernel does not cover fall back."""
+def test_fused_flow_equals_the_pytorch_path():
+    """csrc/train_kernels.hip: the whole conditional flow (per layer ActNorm, permutation, two coupling half-layers of three
+    Linear layers, two ELUs, soft clamp, exp, multiply-add) as ONE kernel forward and ONE backward behind one autograd node.
+    Output, log|det| and EVERY gradient (theta, condition, ActNorm scales and biases, all twelve parameter tensors of every
+    layer) equal the PyTorch composition to float32 round-off, for one and six layers and row counts that are not a multiple
+    of the kernels' 8- and 32-row tiles and span several of them; shapes the kernels do not cover fall back."""
     import torch
     from bayesflow_nddms_amd import _train_lib
-    from bayesflow_nddms_amd.amortizer import InvertibleNetwork, _AffineCoupling
-    L = _train_lib.lib()
-    assert L is not None, "libnddm_train.so did not build / load"
+    from bayesflow_nddms_amd.amortizer import InvertibleNetwork
+    assert _train_lib.lib() is not None, "libnddm_train.so did not build / load"
     torch.manual_seed(3)
-    for R in (32, 5, 77, 256):
-        layer = _AffineCoupling(5, 11, 128).cuda()
-        for p in layer.parameters():                     # larger weights than the default initialisation: every path matters
-            p.data.mul_(3.0)
-        x = torch.randn(R, 5, device="cuda", requires_grad=True)
+    for layers, R, D in ((1, 32, 5), (1, 5, 5), (2, 77, 5), (6, 256, 5), (6, 32, 8), (3, 40, 2)):
+        net = InvertibleNetwork(num_params=D, num_coupling_layers=layers, seed=layers).cuda()
+        with torch.no_grad():
+            for p in net.parameters():                   # larger weights than the initialisation, ActNorms away from identity
+                p.mul_(3.0 if layers == 1 else 1.5)
+            for p in list(net.an_scale) + list(net.an_bias):
+                p.copy_(0.3 * torch.randn_like(p))
+        theta = torch.randn(R, D, device="cuda", requires_grad=True)
         cond = torch.randn(R, 11, device="cuda", requires_grad=True)
-        scale = (0.3 * torch.randn(5, device="cuda")).requires_grad_()
-        bias = torch.randn(5, device="cuda", requires_grad=True)
-        perm = torch.randperm(5)
-        pmat = torch.eye(5)[:, perm].cuda()
-        wy, ws = torch.randn(R, 5, device="cuda"), torch.randn(R, 5, device="cuda")
-        out = {}
+        wz, wl = torch.randn(R, D, device="cuda"), torch.randn(R, device="cuda")
+        res = {}
         for fused in (True, False):
-            if fused:
-                assert layer._fused_lib(x, cond) is L
-                y, s_all = layer.fused_layer(L, x, cond, scale, bias, pmat)
-            else:
-                z = torch.addcmul(bias, x, torch.exp(scale))[:, perm.cuda()]
-                y, ss = layer(z, cond)
-                s_all = torch.cat(ss, dim=-1)
-            loss = (y * wy).sum() + (s_all * ws).sum()
-            grads = torch.autograd.grad(loss, [x, cond, scale, bias] + list(layer.parameters()))
-            out[fused] = [y.detach(), s_all.detach()] + [g.detach() for g in grads]
-        for a, b in zip(out[True], out[False]):
+            net.fused = fused
+            assert (net._fused_lib(theta, cond) is not None) == fused
+            z, ld = net(theta, cond)
+            g = torch.autograd.grad((z * wz).sum() + (ld * wl).sum(), [theta, cond] + list(net.parameters()))
+            res[fused] = [z.detach(), ld.detach()] + [t.detach() for t in g]
+        for k, (a, b) in enumerate(zip(res[True], res[False])):
             mag = float(b.abs().max()) + 1e-6
-            assert float((a - b).abs().max()) <= 2e-5 * mag + 1e-6, (R, a.shape, float((a - b).abs().max()), mag)
-    net = InvertibleNetwork(num_params=5).cuda()
-    theta, cond = torch.randn(64, 5, device="cuda"), torch.randn(64, 11, device="cuda")
-    res = {}
-    for fused in (True, False):
-        for l in net.layers:
-            l.fused = fused
-        z, ld = net(theta, cond)
-        g = torch.autograd.grad((0.5 * (z ** 2).sum(-1) - ld).mean(), list(net.parameters()))
-        res[fused] = [z.detach(), ld.detach()] + [t.detach() for t in g]
-    for a, b in zip(res[True], res[False]):
-        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6), float((a - b).abs().max())
-    small = _AffineCoupling(2, 11, 32).cuda()            # hidden width 32: not covered -> the PyTorch path, silently
-    y, ss = small(torch.randn(8, 2, device="cuda"), torch.randn(8, 11, device="cuda"))
-    assert y.shape == (8, 2)
+            assert float((a - b).abs().max()) <= 5e-5 * mag + 1e-6, (layers, R, D, k, a.shape, float((a - b).abs().max()), mag)
+        x = net.inverse(res[True][0], cond.detach())     # and the (PyTorch) inverse undoes the fused forward
+        assert torch.allclose(x, theta.detach(), atol=2e-3), float((x - theta).abs().max())
+    small = InvertibleNetwork(num_params=5, hidden=32).cuda()          # hidden width 32: not covered -> the PyTorch path, silently
+    z, ld = small(torch.randn(8, 5, device="cuda"), torch.randn(8, 11, device="cuda"))
+    assert z.shape == (8, 5) and ld.shape == (8,)
