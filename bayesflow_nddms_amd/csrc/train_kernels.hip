@@ -23,6 +23,14 @@ constexpr int TR = 32;        // rows per tile
 constexpr int DI_MAX = 32;    // inputs of the sub-network (x_h columns + condition columns)
 constexpr int M_MAX = 16;     // outputs (2 * transformed columns)
 
+#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of workgroup 0 (tools/_flow_stamps.py)
+__device__ unsigned long long g_stamps[8192];
+__device__ int g_nstamps;
+#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 __device__ __forceinline__ float elu(float v) { return v > 0.0f ? v : expm1f(v); }
 __device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }   // alpha = 1
 
@@ -37,19 +45,36 @@ struct Args {
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid = ceil(R / TRF) workgroups of 256 threads over tiles of TRF = 8 rows (four workgroups at batch 32: the work is latency,
-// not arithmetic, so it is spread).  Thread t: hidden unit j = t % 128, row half rh = t / 128 (TRF / 2 rows each).
+// not arithmetic, so it is spread).  Layers 1 and 3 are plain FMAs (thread t: hidden unit j = t % 128, row half rh = t / 128);
+// layer 2, the 128 x 128 product, is v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain) on operands read from LDS --
+// W2 is staged there with coalesced loads (a thread streaming its own row of W2 from global memory was address-processing
+// bound: 64 cache lines per wave instruction, 4.4 of the half-layer's 11 microseconds).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TRF = 8, RPT = TRF / 2;
-constexpr int TRFP = TRF + 4;   // row stride of the transposed activations in LDS: lanes index the UNIT, and a stride of 8 (or 32)
-                                // floats puts a whole wave on two banks; + 4 keeps 16-byte alignment and leaves 4-way conflicts
+constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2 in LDS: the MFMA operand reads (16 lanes down
+                                // a column, 4 lanes along it) then touch every bank exactly twice per wave
 __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, float *y, int ldy, float *s_out, int lds, float *h1_out,
                                                float *h2_out)
 {
     __shared__ float in_s[TRF][DI_MAX];
-    __shared__ __attribute__((aligned(16))) float h1t[H][TRFP];        // transposed: [unit][row]
-    __shared__ __attribute__((aligned(16))) float h2t[H][TRFP];
+    __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TRF..15 stay zero (the MFMA tile has 16 rows)
+    __shared__ __attribute__((aligned(16))) float h2r[TRF][LDR];
     __shared__ float o_s[TRF][M_MAX];
+    __shared__ float w3s[M_MAX][H + 1];       // W3, fetched while layers 1 and 2 run (+ 1: the rows' readers are lanes m)
+    __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
     const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7;
     const int DI = A.Dh + A.C, M = 2 * A.Dt;
+    {   // W2: 16-byte loads, coalesced; in flight while layer 1 runs
+        const float4 *src = reinterpret_cast<const float4 *>(A.W2);
+#pragma unroll
+        for (int k = 0; k < H * H / 4 / 256; ++k) {
+            const int p4 = t + 256 * k;
+            *reinterpret_cast<float4 *>(&w2s[p4 >> 5][4 * (p4 & 31)]) = src[p4];
+        }
+    }
+    for (int p = t; p < M * H; p += 256) w3s[p >> 7][p & (H - 1)] = A.W3[p];
+    for (int p = t; p < (16 - TRF) * H; p += 256) h1r[TRF + (p >> 7)][p & (H - 1)] = 0.0f;
     for (int p = t; p < TRF * DI; p += 256) {
         const int r = p / DI, c = p - r * DI, row = r0 + r;
         float v = 0.0f;
@@ -57,12 +82,13 @@ __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, f
         in_s[r][c] = v;
     }
     __syncthreads();
+    STAMP(1);
     {   // layer 1 (register arrays are only ever indexed by unrolled constants: no private scratch)
         float acc[RPT];
         const float b = A.b1[j];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) acc[q] = b;
-#pragma unroll 2
+#pragma unroll 4
         for (int c = 0; c < DI; ++c) {
             const float wv = A.W1[j * DI + c];
 #pragma unroll
@@ -72,46 +98,52 @@ __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, f
         for (int q = 0; q < RPT; ++q) {
             const int r = rh * RPT + q;
             const float v = elu(acc[q]);
-            h1t[j][r] = v;
+            h1r[r][j] = v;
             if (r0 + r < A.R) h1_out[(long long)(r0 + r) * H + j] = v;
         }
     }
     __syncthreads();
-    {   // layer 2: thread j streams its own row of W2
-        float acc[RPT];
-        const float b = A.b2[j];
+    STAMP(2);
+    {   // layer 2: wave w owns units [32 w, 32 w + 32) as two 16 x 16 tiles (two independent accumulators);
+        // lane l: A[row l & 15][k = l >> 4] = h1[row][4 s + k], B[k][unit l & 15] = W2[unit][4 s + k]
+        const int lane = t & 63, w = t >> 6, n = lane & 15, kk = lane >> 4;
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+        const float *ap = &h1r[n][kk], *bp0 = &w2s[32 * w + n][kk], *bp1 = &w2s[32 * w + 16 + n][kk];
+#pragma unroll 8
+        for (int s4 = 0; s4 < H; s4 += 4) {
+            const float a = ap[s4];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[s4], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[s4], acc1, 0, 0, 0);
+        }
+        // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register: rows < TRF live in lanes 0..31
+        if (kk < TRF / 4) {
+            const int u0 = 32 * w + n, u1 = u0 + 16;
+            const float b0 = A.b2[u0], b1 = A.b2[u1];
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) acc[q] = b;
-        const float4 *wrow = reinterpret_cast<const float4 *>(A.W2 + (long long)j * H);
-#pragma unroll 2
-        for (int i4 = 0; i4 < H / 4; ++i4) {
-            const float4 w4 = wrow[i4];
-            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float *hr = &h1t[4 * i4 + u][rh * RPT];
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) acc[q] = fmaf(wv[u], hr[q], acc[q]);
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * kk + q;
+                const float v0 = elu(acc0[q] + b0), v1 = elu(acc1[q] + b1);
+                h2r[r][u0] = v0;
+                h2r[r][u1] = v1;
+                if (r0 + r < A.R) {
+                    h2_out[(long long)(r0 + r) * H + u0] = v0;
+                    h2_out[(long long)(r0 + r) * H + u1] = v1;
+                }
             }
         }
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = rh * RPT + q;
-            const float v = elu(acc[q]);
-            h2t[j][r] = v;
-            if (r0 + r < A.R) h2_out[(long long)(r0 + r) * H + j] = v;
-        }
     }
     __syncthreads();
-    for (int p = t; p < TRF * M; p += 256) {          // layer 3
-        const int r = p / M, m = p - r * M;
-        float acc = A.b3[m];
-        const float *w = A.W3 + (long long)m * H;
-#pragma unroll 4
-        for (int i = 0; i < H; ++i) acc = fmaf(w[i], h2t[i][r], acc);
-        o_s[r][m] = acc;
+    STAMP(3);
+    for (int p = t; p < 2 * TRF * M; p += 256) {      // layer 3: two threads (adjacent lanes) per output, half the units each
+        const int pr = p >> 1, half = p & 1, r = pr / M, m = pr - r * M;
+        float acc = half ? 0.0f : A.b3[m];
+#pragma unroll 8
+        for (int i = half * (H / 2); i < (half + 1) * (H / 2); ++i) acc = fmaf(w3s[m][i], h2r[r][i], acc);
+        acc += __shfl_xor(acc, 1);
+        if (!half) o_s[r][m] = acc;
     }
     __syncthreads();
+    STAMP(4);
     for (int p = t; p < TRF * A.Dt; p += 256) {       // soft clamp + affine transform
         const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
         if (row >= A.R) continue;
@@ -120,6 +152,7 @@ __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, f
         y[(long long)row * ldy + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
     }
     __syncthreads();                  // the outputs are visible to the workgroup, and the LDS arrays are free again
+    STAMP(5);
 }
 
 // ---- the whole flow forward.  grid = ceil(R / TRF) workgroups of 256 threads, each takes its rows through every layer.
@@ -168,12 +201,15 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// ONE workgroup of 1024 threads walks the row tiles and keeps the weight gradients in registers (deterministic sums, no
-// atomics).  Thread t: unit j = t % 128, group g = t / 128 (0..7):
-//   dW2: row j, columns [16 g, 16 g + 16)                 16 registers
-//   dW1: row j, columns c with c % 8 == g                 <= 4
-//   dW3: column j of rows m with m % 8 == g               <= 2
-//   activations' gradients: unit j, rows [4 g, 4 g + 4) of the tile
+// ONE workgroup of 1024 threads (16 waves) walks the row tiles and keeps the weight gradients in registers (deterministic
+// sums, no atomics).  The two 32 x 128 x 128 products -- dW2 = d(a2)^T h1 and d(h1) = d(a2) W2 -- are f32 MFMAs (exact f32)
+// on operands read from LDS: as register-blocked FMAs their LDS reads were 12 of the half-layer's 33 microseconds.
+//   dW2: wave w owns the 32 x 32 tile (rows 32 (w / 4), columns 32 (w % 4)): 16 accumulator registers, v_mfma_f32_32x32x2_f32
+//   d(h1): wave w owns rows 16 (w / 8), units 16 (w % 8): v_mfma_f32_16x16x4_f32
+//   dW1: thread (unit j = t % 128, g = t / 128): columns c with c % 8 == g      <= 4 registers
+//   dW3: column j of rows m with m % 8 == g                                     <= 2
+// Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
+// are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of 33).
 struct BwdOut {
     float *gxh; int ldgh;      // [R, Dh]
     float *gcond;              // [R, C]
@@ -188,40 +224,50 @@ struct BwdIn {
     const float *gs;               // [R] gradient of the row's log|det| (= of every one of its log-scales)
 };
 constexpr int NTB = 1024;
-constexpr int TRP = TR + 4;      // (as TRFP: unpadded, the transposing stores and every per-unit read were 32-way bank conflicts)
+constexpr int LDW2 = H + 8;      // row stride of W2 in LDS: d(h1)'s B operand reads 4 rows x 16 columns per wave instruction
 
 __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I, const float *h1_in, const float *h2_in, const BwdOut &O)
 {
     __shared__ float in_s[TR][DI_MAX];
-    __shared__ __attribute__((aligned(16))) float h1t[H][TRP];
-    __shared__ __attribute__((aligned(16))) float h2t[H][TRP];         // later: d(pre-activation 1), transposed
-    __shared__ __attribute__((aligned(16))) float da2t[H][TRP];
+    __shared__ float h1r[TR][LDR];        // [row][unit]
+    __shared__ float h2r[TR][LDR];        // later: d(pre-activation 1)
+    __shared__ float da2r[TR][LDR];       // d(pre-activation 2)
     __shared__ float do_s[TR][M_MAX];
-    __shared__ float w2s[H][H];           // W2 staged once (64 KB of gfx950's 160 KB): its column reads below were the kernel's latency
-    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7;
-    for (int p = t; p < H * H; p += NTB) (&w2s[0][0])[p] = A.W2[p];     // (flat: one address register and immediates)
+    __shared__ float w2s[H][LDW2];
+    __shared__ float w1s[H][DI_MAX + 1];
+    __shared__ float w3s[M_MAX][H];
+    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6;
     const int DI = A.Dh + A.C, M = 2 * A.Dt;
-    float dW2[16], dW1[DI_MAX / 8], dW3[M_MAX / 8];
-    float db2 = 0.0f, db1 = 0.0f, db3 = 0.0f;
+    __syncthreads();                      // the previous half-layer's last phase read w1s and h2r
+    STAMP(10);
+#pragma unroll
+    for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = A.W2[t + NTB * k];
+    for (int p = t; p < H * DI; p += NTB) { const int jj = p / DI; w1s[jj][p - jj * DI] = A.W1[p]; }
+    for (int p = t; p < M * H; p += NTB) (&w3s[0][0])[p] = A.W3[p];
+    STAMP(101);
+    f32x16 dW2;
 #pragma unroll
     for (int q = 0; q < 16; ++q) dW2[q] = 0.0f;
+    float dW1[DI_MAX / 8], dW3[M_MAX / 8];
+    float db2 = 0.0f, db1 = 0.0f, db3 = 0.0f;
 #pragma unroll
     for (int q = 0; q < DI_MAX / 8; ++q) dW1[q] = 0.0f;
 #pragma unroll
     for (int q = 0; q < M_MAX / 8; ++q) dW3[q] = 0.0f;
 
     for (int r0 = 0; r0 < A.R; r0 += TR) {
-        __syncthreads();                  // the previous tile's readers are done
+        if (r0) __syncthreads();          // the previous tile's readers are done
         for (int p = t; p < TR * DI; p += NTB) {
             const int r = p / DI, c = p - r * DI, row = r0 + r;
             float v = 0.0f;
             if (row < A.R) v = c < A.Dh ? A.xh[(long long)row * A.ldh + c] : A.cond[(long long)row * A.C + (c - A.Dh)];
             in_s[r][c] = v;
         }
-        for (int p = t; p < TR * H; p += NTB) {          // saved activations, transposed into LDS (rows beyond R: zero)
-            const int r = p >> 7, i = p & (H - 1), row = r0 + r;
-            h1t[i][r] = row < A.R ? h1_in[(long long)row * H + i] : 0.0f;
-            h2t[i][r] = row < A.R ? h2_in[(long long)row * H + i] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < TR * H / NTB; ++k) {         // saved activations (rows beyond R: zero)
+            const int r = g + 8 * k, row = r0 + r;
+            h1r[r][j] = row < A.R ? h1_in[(long long)row * H + j] : 0.0f;
+            h2r[r][j] = row < A.R ? h2_in[(long long)row * H + j] : 0.0f;
         }
         for (int p = t; p < TR * A.Dt; p += NTB) {       // through the affine transform and the soft clamp
             const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
@@ -240,14 +286,15 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
             do_s[r][A.Dt + d] = d_t;
         }
         __syncthreads();
+        STAMP(11);
         // layer 3 weight gradient: thread (column j, rows m = g, g + 8)
 #pragma unroll
         for (int q = 0; q < M_MAX / 8; ++q) {
             const int m = 8 * q + g;
             if (m < M) {
                 float acc = dW3[q];
-#pragma unroll 4
-                for (int r = 0; r < TR; ++r) acc = fmaf(do_s[r][m], h2t[j][r], acc);
+#pragma unroll 8
+                for (int r = 0; r < TR; ++r) acc = fmaf(do_s[r][m], h2r[r][j], acc);
                 dW3[q] = acc;
             }
         }
@@ -260,80 +307,97 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 2
             for (int m = 0; m < M; ++m) {
-                const float w = A.W3[(long long)m * H + j];
+                const float w = w3s[m][j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, do_s[4 * g + q][m], acc[q]);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) da2t[j][4 * g + q] = acc[q] * elu_grad_from_out(h2t[j][4 * g + q]);
+            for (int q = 0; q < 4; ++q) da2r[4 * g + q][j] = acc[q] * elu_grad_from_out(h2r[4 * g + q][j]);
         }
         __syncthreads();
-        // layer 2 weight gradient: thread (row j of dW2, columns 16 g .. 16 g + 15); rows outside, columns unrolled (the
-        // accumulators are the only register array)
-#pragma unroll 2
-        for (int rr = 0; rr < TR / 4; ++rr) {          // four rows per 16-byte LDS read: a quarter of the LDS instructions
-            const float4 av = *reinterpret_cast<const float4 *>(&da2t[j][4 * rr]);
+        STAMP(12);
+        {   // layer 2 weight gradient, dW2[jo][i] += sum_r da2[r][jo] h1[r][i].  Lane l: A[jo = l & 31][k = l >> 5], B[k][i = l & 31];
+            // the sum's order is free, so step s takes rows r = 16 k + s (A and B alike)
+            const int m = lane & 31, kk = lane >> 5;
+            const float *ap = &da2r[16 * kk][32 * (wave >> 2) + m], *bp = &h1r[16 * kk][32 * (wave & 3) + m];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 hv = *reinterpret_cast<const float4 *>(&h1t[16 * g + q][4 * rr]);
-                dW2[q] = fmaf(av.w, hv.w, fmaf(av.z, hv.z, fmaf(av.y, hv.y, fmaf(av.x, hv.x, dW2[q]))));
-            }
-            if (g == 0) db2 += (av.x + av.y) + (av.z + av.w);
+            for (int s_ = 0; s_ < 16; ++s_) dW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s_ * LDR], bp[s_ * LDR], dW2, 0, 0, 0);
         }
-        // d h1 -> d(pre-activation 1): thread (unit i = j, rows 4 g .. 4 g + 3); W2 by columns, from LDS
-        float da1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-        for (int jj = 0; jj < H; ++jj) {
-            const float w = w2s[jj][j];
-            const float *ar = &da2t[jj][4 * g];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) da1[q] = fmaf(w, ar[q], da1[q]);
+        if (t < H) {
+#pragma unroll 8
+            for (int r = 0; r < TR; ++r) db2 += da2r[r][t];
         }
+        float da1[4];
+        {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k = l >> 4] = da2[row][4 s + k], B[k][i = l & 15] = W2[4 s + k][i]
+            const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float *ap = &da2r[16 * rb + n][kk], *bp = &w2s[kk][16 * ib + n];
+#pragma unroll 8
+            for (int s4 = 0; s4 < H; s4 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4], bp[s4 * LDW2], acc, 0, 0, 0);
+            // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register
 #pragma unroll
-        for (int q = 0; q < 4; ++q) da1[q] *= elu_grad_from_out(h1t[j][4 * g + q]);
-        __syncthreads();                  // h2t's readers (dW3, d h2) are done: it now holds d(pre-activation 1)
+            for (int q = 0; q < 4; ++q) da1[q] = acc[q] * elu_grad_from_out(h1r[16 * rb + 4 * kk + q][16 * ib + n]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h2t[j][4 * g + q] = da1[q];
+            for (int q = 0; q < 4; ++q) h2r[16 * rb + 4 * kk + q][16 * ib + n] = da1[q];     // (h2r's readers finished before the barrier above)
+        }
         __syncthreads();
+        STAMP(13);
         // layer 1 weight gradient: thread (row j, columns c = g, g + 8, ...)
 #pragma unroll
         for (int q = 0; q < DI_MAX / 8; ++q) {
             const int c = 8 * q + g;
             if (c < DI) {
                 float acc = dW1[q];
-#pragma unroll 4
-                for (int r = 0; r < TR; ++r) acc = fmaf(h2t[j][r], in_s[r][c], acc);
+#pragma unroll 8
+                for (int r = 0; r < TR; ++r) acc = fmaf(h2r[r][j], in_s[r][c], acc);
                 dW1[q] = acc;
             }
         }
+        STAMP(131);
         if (g == 0) {
-#pragma unroll 4
-            for (int r = 0; r < TR; ++r) db1 += h2t[j][r];
+#pragma unroll 8
+            for (int r = 0; r < TR; ++r) db1 += h2r[r][j];
         }
-        // d in: (row, column) pairs
-        for (int p = t; p < TR * DI; p += NTB) {
-            const int r = p / DI, c = p - r * DI, row = r0 + r;
-            if (row >= A.R) continue;
+        STAMP(132);
+        // d in: (row, column) pairs, `parts` adjacent lanes each (a power of two: every thread busy for 512 pairs or fewer)
+        {
+            const int npairs = TR * DI, parts = npairs <= NTB / 4 ? 4 : (npairs <= NTB / 2 ? 2 : 1), span = H / parts;
+            const int pr = t / parts, part = t - pr * parts;
+            const int r = pr / DI, c = pr - r * DI, row = r0 + r;
             float acc = 0.0f;
-#pragma unroll 4
-            for (int jj = 0; jj < H; ++jj) acc = fmaf(A.W1[jj * DI + c], h2t[jj][r], acc);
-            if (c < A.Dh) {
-                float *o = &O.gxh[(long long)row * O.ldgh + c];
-                *o = O.acc_gxh ? *o + acc : acc;
-            } else {
-                float *o = &O.gcond[(long long)row * A.C + (c - A.Dh)];
-                *o = O.acc_gcond ? *o + acc : acc;
+            if (pr < npairs) {
+#pragma unroll 8
+                for (int jj = part * span; jj < (part + 1) * span; ++jj) acc = fmaf(w1s[jj][c], h2r[r][jj], acc);
+            }
+            STAMP(133);
+            if (parts >= 2) acc += __shfl_xor(acc, 1);
+            if (parts >= 4) acc += __shfl_xor(acc, 2);
+            if (pr < npairs && part == 0 && row < A.R) {
+                if (c < A.Dh) {
+                    float *o = &O.gxh[(long long)row * O.ldgh + c];
+                    *o = O.acc_gxh ? *o + acc : acc;
+                } else {
+                    float *o = &O.gcond[(long long)row * A.C + (c - A.Dh)];
+                    *o = O.acc_gcond ? *o + acc : acc;
+                }
             }
         }
+        STAMP(14);
     }
+    {   // dW2's tile: register v of lane l is row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31
+        const int m = lane & 31, kk = lane >> 5;
+        float *o = O.gW2 + (long long)(32 * (wave >> 2) + 4 * kk) * H + 32 * (wave & 3) + m;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) O.gW2[(long long)j * H + 16 * g + q] = dW2[q];
+        for (int v = 0; v < 16; ++v) o[((v & 3) + 8 * (v >> 2)) * H] = dW2[v];
+    }
 #pragma unroll
     for (int q = 0; q < DI_MAX / 8; ++q) { const int c = 8 * q + g; if (c < DI) O.gW1[j * DI + c] = dW1[q]; }
 #pragma unroll
     for (int q = 0; q < M_MAX / 8; ++q) { const int m = 8 * q + g; if (m < M) O.gW3[(long long)m * H + j] = dW3[q]; }
-    if (g == 0) { O.gb2[j] = db2; O.gb1[j] = db1; }
+    if (t < H) O.gb2[t] = db2;
+    if (g == 0) O.gb1[j] = db1;
     if (t < M) O.gb3[t] = db3;
+    STAMP(15);
 }
 
 // ---- the whole flow backward: one workgroup of 1024 threads, half-layers last to first.  The host resolves every half-layer's
@@ -462,3 +526,18 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
 }
 
 }  // extern "C"
+
+#ifdef NDDM_TRAIN_STAMPS
+extern "C" int nddm_train_read_stamps(unsigned long long *out, int cap)
+{
+    int n = 0;
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(nddm_train::g_nstamps), sizeof(int));
+    if (n > cap) n = cap;
+    if (n > 4096) n = 4096;
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(nddm_train::g_stamps), sizeof(unsigned long long) * 2 * n);
+    int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(nddm_train::g_nstamps), &zero, sizeof(int));
+    return n;
+}
+#endif
