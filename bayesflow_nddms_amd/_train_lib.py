@@ -1,4 +1,5 @@
-"""ctypes binding of libnddm_train.so: the amortizer's flow as one kernel each way (csrc/train_kernels.hip).
+"""ctypes binding of libnddm_train.so: the amortizer's flow as one kernel each way (csrc/train_kernels.hip) and the summary
+network's per-trial MLPs (csrc/train_deepset.hip).
 Optional: `lib()` returns None when the library cannot be built or loaded, and the amortizer then runs its PyTorch path."""
 import ctypes
 import os
@@ -30,5 +31,16 @@ def lib():
     #                               ... params perm grads theta cond z_all out_all s_all h_all g_z g_ld gz gy2 gx gcond stream
     L.nddm_train_flow_bwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
     L.nddm_train_flow_bwd.restype = i32
+    L.nddm_deepset_supported.argtypes = [i32, i32]
+    L.nddm_deepset_supported.restype = i32
+    common = [fp, i32, i32, i32, i32, i32, fp, fp, f32, fp, i32, fp, i32, fp, fp, fp, fp, fp]   # x .. b3 (csrc/train_deepset.hip)
+    L.nddm_deepset_mlp_fwd.argtypes = common + [fp, fp, fp, fp, vp]
+    L.nddm_deepset_mlp_fwd.restype = i32
+    L.nddm_deepset_mlp_bwd.argtypes = common + [fp, fp, fp, fp, i32, fp, i32, fp, i32, fp, fp, i32, vp]
+    L.nddm_deepset_mlp_bwd.restype = i32
+    L.nddm_deepset_pool_finalize.argtypes = [fp, i32, i32, fp, f32, fp, vp]
+    L.nddm_deepset_pool_finalize.restype = i32
+    L.nddm_deepset_reduce.argtypes = [fp, i32, i32, fp, vp]
+    L.nddm_deepset_reduce.restype = i32
     _lib = L
     return _lib

@@ -12,8 +12,10 @@ amortized posterior, and a trainer with online and experience-replay loops that 
     post = amortizer.sample(configurator(generative_model(1)), n_samples=10000)
 
 BayesFlow/TensorFlow are not installable here, so parity with BayesFlow's networks is UNPINNED; what is pinned is
-the dictionary contract on both sides ('summary_conditions', 'direct_conditions', 'parameters').  This module is
-plain PyTorch (no custom kernels): the data-parallel hot path of the repository is the simulator that feeds it.
+the dictionary contract on both sides ('summary_conditions', 'direct_conditions', 'parameters').  The networks are plain
+PyTorch modules; on the GPU the flow and the summary network's per-trial MLPs run as hand-written kernels
+(csrc/train_kernels.hip, csrc/train_deepset.hip -- at batch 32 the PyTorch composition is ~600 launches of a few
+microseconds per training iteration), with the PyTorch composition as the definition they are tested against.
 """
 import os
 import pickle
@@ -97,16 +99,136 @@ class InvariantNetwork(nn.Module):
         self.pre_pool = _mlp(d, hidden, hidden)
         self.post_pool = _mlp(hidden, hidden, summary_dim)
         self.summary_dim = summary_dim
+        self.fused = True           # the hand-written kernels where they apply (False: always the PyTorch composition)
+
+    def _fused_lib(self, x):
+        """libnddm_train.so if its per-trial MLP kernels cover this network and this tensor, else None (the PyTorch composition)."""
+        if not (self.fused and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] >= 1):
+            return None
+        mlps = [m for blk in self.equiv for m in (blk.inv, blk.eq)] + [self.pre_pool]
+        if any(len(m) != 5 or not isinstance(m[1], nn.ReLU) or m[2].weight.shape != (64, 64) or m[4].weight.shape != (64, 64)
+               for m in mlps):
+            return None
+        from . import _train_lib
+        L = _train_lib.lib()
+        return L if L is not None and L.nddm_deepset_supported(64, x.shape[2]) else None
 
     def forward(self, x, mask=None, inv_n=None):
         """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors:
         the pooled means then run over the real trials only, so a batch padded to a fixed length (one hipGraph per length
         bucket, GraphTrainer) gives what the unpadded batch gives."""
+        L = self._fused_lib(x)
+        if L is not None:
+            params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+            params += [t for k in (0, 2, 4) for t in (self.pre_pool[k].weight, self.pre_pool[k].bias)]
+            m = None if mask is None else mask.reshape(-1).to(torch.float32)
+            inv = None if inv_n is None else (inv_n if torch.is_tensor(inv_n) else torch.full((1,), float(inv_n), device=x.device))
+            if inv is not None:
+                inv = inv.reshape(-1).to(torch.float32)
+            return self.post_pool(_FusedDeepSetFn.apply(L, len(self.equiv), x, m, inv, *params))
         for block in self.equiv:
             x = block(x, mask, inv_n)
         h = self.pre_pool(x)
         pooled = h.mean(dim=1) if mask is None else (h * mask).sum(dim=1) * inv_n
         return self.post_pool(pooled)
+
+
+class _FusedDeepSetFn(torch.autograd.Function):
+    """The per-trial part of the summary network -- every equivariant block (an MLP whose masked per-set mean is the context
+    of a second MLP) and the pre-pooling MLP with its masked mean -- as hand-written kernels (csrc/train_deepset.hip): one
+    launch per 3-layer MLP each way plus one reduction of the weight gradients, instead of ~150 PyTorch launches of 4-7
+    microseconds over [sets x trials, 64].  x [B, N, d] -> pooled [B, 64].  params: W1, b1, W2, b2, W3, b3 of the blocks'
+    (invariant, equivariant) MLPs in order, then of the pre-pooling MLP.  mask [N] / inv_n (device scalar) or None."""
+
+    ROWS_PER_WG = 128
+
+    @staticmethod
+    def _common(x_t, d, B, N, S, rpw, mask, inv_n, ctx_part, S_ctx, prm):
+        return (x_t.data_ptr(), d, B, N, S, rpw, None if mask is None else mask.data_ptr(),
+                None if inv_n is None else inv_n.data_ptr(), 1.0 / N, None if ctx_part is None else ctx_part.data_ptr(), S_ctx,
+                prm[0].data_ptr(), prm[0].shape[1], prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), prm[4].data_ptr(),
+                prm[5].data_ptr())
+
+    @staticmethod
+    def forward(ctx, L, nb, x, mask, inv_n, *params):
+        (B, N, d0), dev, rpw = x.shape, x.device, _FusedDeepSetFn.ROWS_PER_WG
+        T, S, Hd = B * N, -(-N // rpw), 64
+        x = x.contiguous()
+        acts = torch.empty((2 * nb + 1, 2, T, Hd), dtype=torch.float32, device=dev)
+        xs_next = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
+        pools = torch.empty((nb + 1, B, S, Hd), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        cm = _FusedDeepSetFn._common
+        cur, d, rc = x, d0, 0
+        for i in range(nb):
+            inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
+            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, inv), acts[2 * i, 0].data_ptr(),
+                                         acts[2 * i, 1].data_ptr(), None, pools[i].data_ptr(), st)
+            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), acts[2 * i + 1, 0].data_ptr(),
+                                         acts[2 * i + 1, 1].data_ptr(), xs_next[i].data_ptr(), None, st)
+            cur, d = xs_next[i], Hd
+        pre = params[12 * nb:]
+        rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pre), acts[2 * nb, 0].data_ptr(),
+                                     acts[2 * nb, 1].data_ptr(), None, pools[nb].data_ptr(), st)
+        rc |= L.nddm_deepset_pool_finalize(pools[nb].data_ptr(), B, S, None if inv_n is None else inv_n.data_ptr(), 1.0 / N,
+                                           pooled.data_ptr(), st)
+        if rc != 0:
+            raise RuntimeError(f"nddm_deepset_mlp_fwd failed ({rc})")
+        ctx.L, ctx.nb, ctx.has_mask, ctx.has_inv = L, nb, mask is not None, inv_n is not None
+        ctx.save_for_backward(x, acts, xs_next, pools, *([mask] if mask is not None else []), *([inv_n] if inv_n is not None else []),
+                              *params)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g_pooled):
+        L, nb, rpw = ctx.L, ctx.nb, _FusedDeepSetFn.ROWS_PER_WG
+        x, acts, xs_next, pools, *rest = ctx.saved_tensors
+        mask = rest.pop(0) if ctx.has_mask else None
+        inv_n = rest.pop(0) if ctx.has_inv else None
+        params = rest
+        (B, N, d0), dev, Hd = x.shape, x.device, 64
+        T, S = B * N, pools.shape[2]
+        G = B * S
+        sizes = [p.numel() for p in params]
+        per_mlp = [sum(sizes[6 * k:6 * k + 6]) for k in range(2 * nb + 1)]
+        offs = [sum(per_mlp[:k]) for k in range(2 * nb + 1)]
+        P = sum(per_mlp)
+        part = torch.empty((G, P), dtype=torch.float32, device=dev)
+        flat = torch.empty(P, dtype=torch.float32, device=dev)
+        gxbuf = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
+        dctx = torch.empty((max(nb, 1), B, S, Hd), dtype=torch.float32, device=dev)
+        g_pooled = g_pooled.contiguous()
+        st, F = torch.cuda.current_stream(dev).cuda_stream, 4
+        cm = _FusedDeepSetFn._common
+        pp = part.data_ptr()
+
+        def x_of(i):                                # input of block i (and of the pre-pooling MLP for i == nb)
+            return (xs_next[i - 1], Hd) if i else (x, d0)
+
+        xin, d = x_of(nb)
+        pre = params[12 * nb:]
+        rc = L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, pre), acts[2 * nb, 0].data_ptr(),
+                                    acts[2 * nb, 1].data_ptr(), None, g_pooled.data_ptr(), 0, None, 0,
+                                    gxbuf[nb - 1].data_ptr() if nb else None, 0, None, pp + offs[2 * nb] * F, P, st)
+        for i in reversed(range(nb)):
+            inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
+            xin, d = x_of(i)
+            gx = gxbuf[i - 1].data_ptr() if i else None
+            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), acts[2 * i + 1, 0].data_ptr(),
+                                         acts[2 * i + 1, 1].data_ptr(), gxbuf[i].data_ptr(), None, 0, None, 0, gx, 0,
+                                         dctx[i].data_ptr(), pp + offs[2 * i + 1] * F, P, st)
+            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, inv), acts[2 * i, 0].data_ptr(),
+                                         acts[2 * i, 1].data_ptr(), None, dctx[i].data_ptr(), S, eq[0].data_ptr() + d * F, d + Hd,
+                                         gx, 1, None, pp + offs[2 * i] * F, P, st)
+        rc |= L.nddm_deepset_reduce(pp, G, P, flat.data_ptr(), st)
+        if rc != 0:
+            raise RuntimeError(f"nddm_deepset_mlp_bwd failed ({rc})")
+        grads, o = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[o:o + n].view(p.shape))
+            o += n
+        return (None, None, None, None, None, *grads)
 
 
 class _FusedFlowFn(torch.autograd.Function):

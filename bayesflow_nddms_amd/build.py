@@ -83,19 +83,24 @@ def build_hip(force=False, verbose=False):
     return SO_PATH
 
 
-# ---- the amortizer's fused coupling kernels (csrc/train_kernels.hip -> libnddm_train.so): not part of the simulator's C ABI; the
-# PyTorch path is the fallback wherever this library is absent or the shape is not covered
+# ---- the amortizer's kernels (csrc/train_kernels.hip: the flow; csrc/train_deepset.hip: the summary network's per-trial MLPs
+# -> libnddm_train.so): not part of the simulator's C ABI; the PyTorch path is the fallback wherever this library is absent or the
+# shape is not covered
 TRAIN_SO_PATH = os.path.join(_HERE, "libnddm_train.so")
-TRAIN_SOURCE = os.path.join(_HERE, "csrc", "train_kernels.hip")
+TRAIN_SOURCES = [os.path.join(_HERE, "csrc", "train_kernels.hip"), os.path.join(_HERE, "csrc", "train_deepset.hip")]
+TRAIN_SOURCE = TRAIN_SOURCES[0]
 
 
 def train_source_hash():
-    with open(TRAIN_SOURCE, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()
+    for path in TRAIN_SOURCES:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build_train(force=False, verbose=False):
-    """Compile csrc/train_kernels.hip for gfx950; stale = other source content than the one recorded beside the library."""
+    """Compile the amortizer's kernels for gfx950; stale = other source content than the one recorded beside the library."""
     stamp = TRAIN_SO_PATH + ".srchash"
     fresh = os.path.exists(TRAIN_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == train_source_hash()
     if fresh and not force:
@@ -104,7 +109,7 @@ def build_train(force=False, verbose=False):
     with open(TRAIN_SO_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         tmp = f"{TRAIN_SO_PATH}.{os.getpid()}.tmp"
-        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", tmp, TRAIN_SOURCE]
+        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + TRAIN_SOURCES
         if verbose:
             print(" ".join(cmd))
         try:

@@ -1,0 +1,489 @@
+// train_deepset.hip -- the per-trial part of the amortizer's DeepSet summary network (bayesflow_nddms_amd/amortizer.py::
+// InvariantNetwork; the stand-in for bf.networks.InvariantNetwork, basic_ddm_dc.py:163) for the online-training loop
+// (basic_ddm_dc.py:199-202): every 3-layer MLP that runs on each trial of each set -- Linear, ReLU, Linear, ReLU, Linear, hidden
+// width 64 -- as ONE kernel forward and ONE backward, with what surrounds it fused in:
+//   * a per-set context vector (the masked mean over the set's trials of another MLP's output, taken through the context columns
+//     of W1) added before the first ReLU: the "equivariant" half of a DeepSet block;
+//   * the masked per-set sums of the output: the "invariant" half and the final pooling;
+//   * backward: the weight gradients as per-workgroup partial sums (deterministic; one reduction kernel sums them), the input
+//     gradient, the context's gradient, the pooled output's gradient spread back over the set's trials.
+// In PyTorch each Linear / ReLU / mask / sum / concat / expand is a launch of 4-7 microseconds over [32 sets x <= 300 trials, 64]:
+// ~150 launches per training iteration.  Here the [rows, 64] x [64, 64] products are v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered
+// fmaf chain) on LDS tiles of 64 rows; a workgroup owns up to `rows_per_wg` consecutive trials of ONE set, so pooling and context
+// never cross a workgroup inside a kernel -- they cross KERNELS as [set, workgroup-of-the-set, 64] partial sums.
+// gfx950 only.  tests/test_gpu_training.py compares with the PyTorch composition.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nddm_deepset {
+
+constexpr int HS = 64;        // hidden width
+constexpr int LD = HS + 4;    // LDS row stride: 16-byte aligned rows, and the operand reads of one wave instruction touch every bank twice
+constexpr int TM = 64;        // rows per tile
+constexpr int NT = 256;       // threads per workgroup: wave w owns the 32 x 32 tile (w >> 1, w & 1) of every 64 x 64 product
+constexpr int DS_MAX = 4;     // a "small" input (the raw trials: rt, choice) goes through layer 1 as plain FMAs
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Mlp { const float *W1; int ldw1; const float *b1, *W2, *b2, *W3, *b3; };
+// W1 [64, ldw1]: columns [0, d_in) act on the trial, columns [d_in, d_in + 64) on the set's pooled context (if there is one)
+
+struct Common {
+    const float *x; int d_in;               // [B * N, d_in]
+    int B, N, S, rows_per_wg;               // S workgroups per set
+    const float *mask;                      // [N]: 1 = a real trial, 0 = padding; null: all real
+    const float *inv_n; float inv_n_host;   // 1 / (number of real trials): device scalar, or (null) the host's value
+    const float *ctx_part; int S_ctx;       // [B, S_ctx, 64] partial sums of the pooled producer; null: no context
+    Mlp P;
+};
+
+// acc += A B over 64 k's.  Lane l holds A[i = l & 31][k] and B[k][j = l & 31] for the 32 k's of its half (l >> 5): the order of
+// the sum is free, so step s of the instruction stream takes k = 32 (l >> 5) + s from both.  SA / SB: distance in floats between
+// consecutive k's of this lane's operand (1: along a row of the LDS tile -- 16-byte reads; LD: down a column).
+template <int SA, int SB>
+__device__ __forceinline__ f32x16 mma64(const float *ap, const float *bp, f32x16 acc)
+{
+    float a[32], b[32];
+    if (SA == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(ap + 4 * q);
+            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) a[s] = ap[s * SA];
+    }
+    if (SB == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(bp + 4 * q);
+            b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = bp[s * SB];
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+// register v of lane l of a result tile: row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31
+__device__ __forceinline__ int drow(int v, int kk) { return (v & 3) + 8 * (v >> 2) + 4 * kk; }
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+    return z;
+}
+
+// 64 x 64 row-major weights -> LDS [64][LD], 16-byte loads (ldw: the source's row stride in floats, a multiple of 4)
+__device__ __forceinline__ void stage64(float (*dst)[LD], const float *src, int ldw, int t)
+{
+    for (int p = t; p < HS * HS / 4; p += NT) {
+        const int r = p >> 4, c4 = p & 15;
+        *reinterpret_cast<float4 *>(&dst[r][4 * c4]) = *reinterpret_cast<const float4 *>(src + (long long)r * ldw + 4 * c4);
+    }
+}
+
+// the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled
+__device__ __forceinline__ void context(const Common &C, int b, float *pooled, float *cs, int t)
+{
+    if (C.ctx_part) {
+        if (t < HS) {
+            float a = 0.0f;
+            for (int s = 0; s < C.S_ctx; ++s) a += C.ctx_part[((long long)b * C.S_ctx + s) * HS + t];
+            pooled[t] = a * (C.inv_n ? *C.inv_n : C.inv_n_host);
+        }
+        __syncthreads();
+        const int u = t >> 2, q = t & 3;
+        const float *w = C.P.W1 + (long long)u * C.P.ldw1 + C.d_in + 16 * q;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = fmaf(w[k], pooled[16 * q + k], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (q == 0) cs[u] = a + C.P.b1[u];
+    } else if (t < HS) {
+        cs[t] = C.P.b1[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct FwdOut {
+    float *h1, *h2;        // [B * N, 64] the two hidden activations (after their ReLU): saved for the backward
+    float *y;              // [B * N, 64] the output, or null (only its pooled sums are wanted)
+    float *pool_part;      // [B, S, 64] masked sums of the output over this workgroup's trials, or null
+};
+
+template <bool BIG>        // d_in == 64 (layer 1 is an MFMA product) or d_in <= DS_MAX
+__global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
+{
+    __shared__ __attribute__((aligned(16))) float w1s[BIG ? HS : 1][LD];
+    __shared__ __attribute__((aligned(16))) float w2s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w3s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float xs[BIG ? TM : 1][LD];
+    __shared__ __attribute__((aligned(16))) float h1s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h2s[TM][LD];
+    __shared__ float w1small[BIG ? 1 : HS][DS_MAX], xsmall[BIG ? 1 : TM][DS_MAX];
+    __shared__ float cs[HS], pooled[HS], red[4][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, kk = lane >> 5, rb = wave >> 1, ub = wave & 1;
+    const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
+    const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
+    const long long row0 = (long long)b * C.N;
+    stage64(w2s, C.P.W2, HS, t);
+    stage64(w3s, C.P.W3, HS, t);
+    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    else
+        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
+    context(C, b, pooled, cs, t);
+    __syncthreads();
+    const int u = 32 * ub + m;                       // this lane's column of every result tile
+    const float bias2 = C.P.b2[u], bias3 = C.P.b3[u], bias1 = cs[u];
+    float pacc = 0.0f;
+    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
+        if (BIG) {
+            for (int p = t; p < TM * HS / 4; p += NT) {
+                const int r = p >> 4, c4 = p & 15, n = n0 + r;
+                float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (n < n_end) v = *reinterpret_cast<const float4 *>(C.x + (row0 + n) * HS + 4 * c4);
+                *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = v;
+            }
+        } else {
+            for (int p = t; p < TM * C.d_in; p += NT) {
+                const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
+                xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (BIG) {                                   // layer 1
+            const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                const float val = fmaxf(acc[v] + bias1, 0.0f);
+                h1s[r][u] = val;
+                if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + u] = val;
+            }
+        } else {                                     // thread (unit t & 63, rows 16 (t >> 6) ...)
+            const int uu = t & 63, rg = t >> 6;
+            float w[DS_MAX];
+#pragma unroll
+            for (int c = 0; c < DS_MAX; ++c) w[c] = c < C.d_in ? w1small[uu][c] : 0.0f;
+            const float c0 = cs[uu];
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int r = 16 * rg + q;
+                float a = c0;
+#pragma unroll
+                for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) a = fmaf(w[c], xsmall[r][c], a);
+                const float val = fmaxf(a, 0.0f);
+                h1s[r][uu] = val;
+                if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
+            }
+        }
+        __syncthreads();
+        {                                            // layer 2
+            const f32x16 acc = mma64<1, 1>(&h1s[32 * rb + m][32 * kk], &w2s[u][32 * kk], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                const float val = fmaxf(acc[v] + bias2, 0.0f);
+                h2s[r][u] = val;
+                if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
+            }
+        }
+        __syncthreads();
+        {                                            // layer 3 (no activation), and the masked sums of its output
+            const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int n = n0 + 32 * rb + drow(v, kk);
+                if (n < n_end) {
+                    const float val = acc[v] + bias3;
+                    if (O.y) O.y[(row0 + n) * HS + u] = val;
+                    if (O.pool_part) pacc = fmaf(C.mask ? C.mask[n] : 1.0f, val, pacc);
+                }
+            }
+        }
+        // (the next tile's writes to xs / h1s / h2s are each behind a barrier every reader of this tile has passed)
+    }
+    if (O.pool_part) {                               // fixed-order sum of the four lanes that share a column
+        red[wave][lane] = pacc;
+        __syncthreads();
+        if (t < HS) {
+            const int cb = t >> 5, n = t & 31;
+            O.pool_part[((long long)b * C.S + sp) * HS + t] = (red[cb][n] + red[cb][n + 32]) + (red[2 + cb][n] + red[2 + cb][n + 32]);
+        }
+    }
+}
+
+// pooled [B, 64] = inv_n * sum over the set's workgroups
+__global__ void pool_finalize_kernel(const float *part, int B, int S, const float *inv_n, float inv_n_host, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * HS) return;
+    const int b = i / HS, u = i - b * HS;
+    float a = 0.0f;
+    for (int s = 0; s < S; ++s) a += part[((long long)b * S + s) * HS + u];
+    out[i] = a * (inv_n ? *inv_n : inv_n_host);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct BwdIO {
+    const float *h1, *h2;            // saved by the forward
+    const float *gy;                 // [B * N, 64] gradient of the output, or null
+    const float *gpool; int gp_S;    // gradient through the pooled output (null: none), one of two forms:
+    const float *gp_W; int gp_ldw;   //   gp_W != null: gpool [B, gp_S, 64] = the consumer's per-workgroup sums of d(pre-activation 1),
+                                     //     to be taken through the consumer's context columns gp_W [64, gp_ldw] and 1 / n;
+                                     //   gp_W == null: gpool [B, 64] = the gradient of the masked MEAN (1 / n is applied here)
+    float *gx; int gx_acc;           // [B * N, d_in] gradient of the input, or null; gx_acc: add to what it holds
+    float *dctx_part;                // [B, S, 64] this workgroup's sum of d(pre-activation 1) (the context's gradient), or null
+    float *wpart; int ld_part;       // row blockIdx.x (stride ld_part floats) takes this workgroup's weight gradients:
+                                     // W1 [64, ldw1], b1, W2, b2, W3, b3
+};
+
+template <bool BIG>
+__global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
+{
+    __shared__ __attribute__((aligned(16))) float w1s[BIG ? HS : 1][LD];
+    __shared__ __attribute__((aligned(16))) float w2s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w3s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float xs[BIG ? TM : 1][LD];
+    __shared__ __attribute__((aligned(16))) float h1s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h2s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float gs[TM][LD];        // gradient of the output; later d(pre-activation 1)
+    __shared__ __attribute__((aligned(16))) float d2s[TM][LD];       // d(pre-activation 2)
+    __shared__ float xsmall[BIG ? 1 : TM][DS_MAX];
+    __shared__ float pooled[HS], cs[HS], gp[HS], dsum[HS], red[4][3][HS], redw[BIG ? 1 : 4][HS][DS_MAX], db1s[HS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, kk = lane >> 5, rb = wave >> 1, ub = wave & 1;
+    const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
+    const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
+    const long long row0 = (long long)b * C.N;
+    const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
+    stage64(w2s, C.P.W2, HS, t);
+    stage64(w3s, C.P.W3, HS, t);
+    if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
+    if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
+        if (Q.gp_W) {
+            if (t < HS) {
+                float a = 0.0f;
+                for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
+                dsum[t] = a;
+            }
+            __syncthreads();
+            if (t < HS) {
+                float a = 0.0f;
+#pragma unroll 8
+                for (int uu = 0; uu < HS; ++uu) a = fmaf(Q.gp_W[(long long)uu * Q.gp_ldw + t], dsum[uu], a);
+                gp[t] = a * inv_n;
+            }
+        } else if (t < HS) {
+            gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
+        }
+    }
+    __syncthreads();
+    const int u = 32 * ub + m;
+    f32x16 aW1 = zero16(), aW2 = zero16(), aW3 = zero16();
+    float db[3] = {0.0f, 0.0f, 0.0f};                // thread (unit t & 63, rows 16 (t >> 6) ..): column sums of d(pre-activation 1..3)
+    float dw1[DS_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};    // (!BIG) row t & 63 of dW1 over the same rows
+    const int uu = t & 63, rg = t >> 6;
+    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
+        __syncthreads();                             // the previous tile's readers are done
+        for (int p = t; p < TM * HS / 4; p += NT) {
+            const int r = p >> 4, c4 = p & 15, n = n0 + r;
+            float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vg = v1, vx = v1;
+            if (n < n_end) {
+                const long long o = (row0 + n) * HS + 4 * c4;
+                v1 = *reinterpret_cast<const float4 *>(Q.h1 + o);
+                v2 = *reinterpret_cast<const float4 *>(Q.h2 + o);
+                if (Q.gy) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
+                if (BIG) vx = *reinterpret_cast<const float4 *>(C.x + o);
+                if (Q.gpool) {
+                    const float mk = C.mask ? C.mask[n] : 1.0f;
+                    vg.x = fmaf(mk, gp[4 * c4], vg.x); vg.y = fmaf(mk, gp[4 * c4 + 1], vg.y);
+                    vg.z = fmaf(mk, gp[4 * c4 + 2], vg.z); vg.w = fmaf(mk, gp[4 * c4 + 3], vg.w);
+                }
+            }
+            *reinterpret_cast<float4 *>(&h1s[r][4 * c4]) = v1;
+            *reinterpret_cast<float4 *>(&h2s[r][4 * c4]) = v2;
+            *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = vg;
+            if (BIG) *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = vx;
+        }
+        if (!BIG)
+            for (int p = t; p < TM * C.d_in; p += NT) {
+                const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
+                xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
+            }
+        __syncthreads();
+        // layer 3: dW3 [unit out, unit in] += g^T h2 (the k's are the tile's rows); d h2 = g W3 -> d(pre-activation 2)
+        aW3 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &h2s[32 * kk][u], aW3);
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[2] += gs[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w3s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                d2s[r][u] = h2s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // layer 2
+        aW2 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &h1s[32 * kk][u], aW2);
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[1] += d2s[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&d2s[32 * rb + m][32 * kk], &w2s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {           // (gs: its readers -- dW3, d h2 -- finished before the barrier above)
+                const int r = 32 * rb + drow(v, kk);
+                gs[r][u] = h1s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // layer 1
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[0] += gs[16 * rg + q][uu];
+        if (BIG) {
+            aW1 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &xs[32 * kk][u], aW1);
+            if (Q.gx) {
+                const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int n = n0 + 32 * rb + drow(v, kk);
+                    if (n < n_end) {
+                        float *o = Q.gx + (row0 + n) * HS + u;
+                        *o = Q.gx_acc ? *o + acc[v] : acc[v];
+                    }
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const float d = gs[16 * rg + q][uu];
+#pragma unroll
+                for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) dw1[c] = fmaf(d, xsmall[16 * rg + q][c], dw1[c]);
+            }
+        }
+    }
+    // ---- this workgroup's partial sums
+    float *wp = Q.wpart + (long long)blockIdx.x * Q.ld_part;
+    const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + HS * HS;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {                   // tile (rb, ub): row = unit out, column = unit in
+        const int r = 32 * rb + drow(v, kk);
+        wp[oW2 + r * HS + u] = aW2[v];
+        wp[oW3 + r * HS + u] = aW3[v];
+        if (BIG) wp[oW1 + r * ld1 + u] = aW1[v];
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) red[rg][l][uu] = db[l];
+    if (!BIG) {
+#pragma unroll
+        for (int c = 0; c < DS_MAX; ++c) redw[rg][uu][c] = dw1[c];
+    }
+    __syncthreads();
+    if (t < 3 * HS) {
+        const int l = t >> 6, c = t & 63;
+        const float v = (red[0][l][c] + red[1][l][c]) + (red[2][l][c] + red[3][l][c]);
+        wp[l == 0 ? ob1 + c : (l == 1 ? ob2 + c : ob3 + c)] = v;
+        if (l == 0) {
+            db1s[c] = v;
+            if (Q.dctx_part) Q.dctx_part[((long long)b * C.S + sp) * HS + c] = v;
+        }
+    }
+    if (!BIG && t < HS)
+        for (int c = 0; c < C.d_in; ++c) wp[oW1 + t * ld1 + c] = (redw[0][t][c] + redw[1][t][c]) + (redw[2][t][c] + redw[3][t][c]);
+    if (C.ctx_part) {                                // context columns of W1: (sum of d pre-activation 1) x pooled
+        __syncthreads();
+        for (int p = t; p < HS * HS; p += NT) {
+            const int r = p >> 6, k = p & 63;
+            wp[oW1 + r * ld1 + C.d_in + k] = db1s[r] * pooled[k];
+        }
+    }
+}
+
+// out[p] = sum over g of part[g][p], g in fixed order
+__global__ void reduce_partials_kernel(const float *part, int G, int P, float *out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        a0 += part[(long long)g * P + p];
+        a1 += part[(long long)(g + 1) * P + p];
+        a2 += part[(long long)(g + 2) * P + p];
+        a3 += part[(long long)(g + 3) * P + p];
+    }
+    for (; g < G; ++g) a0 += part[(long long)g * P + p];
+    out[p] = (a0 + a1) + (a2 + a3);
+}
+
+}  // namespace nddm_deepset
+
+using namespace nddm_deepset;
+
+extern "C" {
+
+int nddm_deepset_supported(int hidden, int d_in) { return (hidden == HS && (d_in == HS || (d_in >= 1 && d_in <= DS_MAX))) ? 1 : 0; }
+
+static bool common_ok(const Common &C)
+{
+    return nddm_deepset_supported(HS, C.d_in) && C.B > 0 && C.N > 0 && C.S > 0 && C.rows_per_wg > 0 && (long long)C.S * C.rows_per_wg >= C.N
+           && C.P.ldw1 == C.d_in + (C.ctx_part ? HS : 0) && (C.d_in != HS || C.P.ldw1 % 4 == 0);
+}
+
+/* One per-trial MLP forward.  x [B * N, d_in]; W1 [64, d_in (+ 64 with a context)], W2, W3 [64, 64]; mask [N] or NULL; inv_n: device
+ * scalar or NULL (then inv_n_host); ctx_part [B, S_ctx, 64] or NULL.  Writes h1, h2 [B * N, 64], and y [B * N, 64] and / or
+ * pool_part [B, S, 64] where not NULL.  S workgroups of up to rows_per_wg trials per set. */
+int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
+                         float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
+                         const float *b2, const float *W3, const float *b3, float *h1, float *h2, float *y, float *pool_part, void *stream)
+{
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}};
+    if (!common_ok(C) || !h1 || !h2) return 1;
+    const FwdOut O = {h1, h2, y, pool_part};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d_in == HS) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, O);
+    else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, O);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int nddm_deepset_pool_finalize(const float *part, int B, int S, const float *inv_n, float inv_n_host, float *out, void *stream)
+{
+    if (B <= 0 || S <= 0) return 1;
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3((B * HS + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, B, S,
+                       inv_n, inv_n_host, out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+/* The backward of nddm_deepset_mlp_fwd (same first arguments).  gy [B * N, 64] or NULL; gpool / gp_S / gp_W / gp_ldw: see BwdIO;
+ * gx [B * N, d_in] or NULL (d_in == 64 only), gx_acc: accumulate; dctx_part [B, S, 64] or NULL; wpart: B * S rows, ld_part floats
+ * apart, of 64 ldw1 + 64 + 2 (4096 + 64) weight-gradient partial sums each: reduce with nddm_deepset_reduce. */
+int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
+                         float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
+                         const float *b2, const float *W3, const float *b3, const float *h1, const float *h2, const float *gy,
+                         const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx, int gx_acc, float *dctx_part,
+                         float *wpart, int ld_part, void *stream)
+{
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}};
+    if (!common_ok(C) || !h1 || !h2 || !wpart || ld_part < HS * ldw1 + HS + 2 * (HS * HS + HS) || (gx && d_in != HS) || (!gy && !gpool)) return 1;
+    const BwdIO Q = {h1, h2, gy, gpool, gp_S, gp_W, gp_ldw, gx, gx_acc, dctx_part, wpart, ld_part};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d_in == HS) hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, Q);
+    else hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, Q);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int nddm_deepset_reduce(const float *part, int G, int P, float *out, void *stream)
+{
+    if (G <= 0 || P <= 0) return 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, G, P, out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // extern "C"

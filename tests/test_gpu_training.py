@@ -237,3 +237,48 @@ def test_fused_flow_equals_the_pytorch_path():
     small = InvertibleNetwork(num_params=5, hidden=32).cuda()          # hidden width 32: not covered -> the PyTorch path, silently
     z, ld = small(torch.randn(8, 5, device="cuda"), torch.randn(8, 11, device="cuda"))
     assert z.shape == (8, 5) and ld.shape == (8,)
+
+
+def test_fused_deepset_equals_the_pytorch_path():
+    """csrc/train_deepset.hip: every per-trial MLP of the summary network as one f32-MFMA kernel each way, with the masked
+    per-set pooling, the pooled context of the equivariant halves and the weight-gradient partial sums fused in.  The summary
+    and EVERY parameter gradient equal the PyTorch composition to float32 round-off: with and without padding mask, set sizes
+    that are not a multiple of the 64-row tile or of the 128 rows of a workgroup, 0 / 1 / 2 equivariant blocks; inputs the
+    kernels do not cover fall back."""
+    import torch
+    from bayesflow_nddms_amd import _train_lib
+    from bayesflow_nddms_amd.amortizer import InvariantNetwork
+    assert _train_lib.lib() is not None, "libnddm_train.so did not build / load"
+    torch.manual_seed(5)
+    for blocks, B, N, n_real in ((2, 32, 300, 237), (2, 3, 60, None), (1, 5, 131, 131), (2, 4, 129, 64), (0, 7, 200, 77), (2, 2, 1, None)):
+        net = InvariantNetwork(num_equiv=blocks).cuda()
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() == 1:
+                    p.copy_(0.1 * torch.randn_like(p))                  # non-zero biases
+        x = torch.stack([0.3 + torch.rand(B, N, device="cuda") * 2.0, (torch.rand(B, N, device="cuda") < 0.7).float()], dim=-1)
+        mask = inv_n = None
+        if n_real is not None:
+            mask = (torch.arange(N, device="cuda") < n_real).float().view(1, N, 1)
+            inv_n = torch.tensor(1.0 / n_real, device="cuda")
+        w = torch.randn(B, net.summary_dim, device="cuda")
+        res = {}
+        for fused in (True, False):
+            net.fused = fused
+            assert (net._fused_lib(x) is not None) == fused
+            out = net(x, mask, inv_n)
+            g = torch.autograd.grad((out * w).sum(), list(net.parameters()))
+            res[fused] = [out.detach()] + [t.detach() for t in g]
+        for k, (a, b) in enumerate(zip(res[True], res[False])):
+            mag = float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= 1e-4 * mag + 1e-6, (blocks, B, N, n_real, k, a.shape, float((a - b).abs().max()), mag)
+        if n_real is not None and n_real < N:                # padding is invisible: the unpadded batch gives the same summary
+            net.fused = True
+            assert torch.allclose(net(x[:, :n_real].contiguous()), res[True][0], rtol=1e-4, atol=1e-5)
+    wide = InvariantNetwork(hidden=32).cuda()                # hidden width 32: not covered -> the PyTorch path, silently
+    assert wide(torch.randn(4, 50, 2, device="cuda")).shape == (4, 10)
+    with torch.no_grad():                                    # inference (no autograd graph) runs the kernels too
+        net = InvariantNetwork().cuda()
+        a = net(x)
+        net.fused = False
+        assert torch.allclose(a, net(x), rtol=1e-4, atol=1e-5)
