@@ -1,5 +1,5 @@
 """ctypes binding of libnddm_train.so: the amortizer's flow as one kernel each way (csrc/train_kernels.hip) and the summary
-network's per-trial MLPs (csrc/train_deepset.hip).
+network's per-trial MLPs (csrc/train_deepset.hip), and the optimizer step on flat buffers (csrc/train_update.hip).
 Optional: `lib()` returns None when the library cannot be built or loaded, and the amortizer then runs its PyTorch path."""
 import ctypes
 import os
@@ -42,5 +42,8 @@ def lib():
     L.nddm_deepset_pool_finalize.restype = i32
     L.nddm_deepset_reduce.argtypes = [fp, i32, i32, fp, vp]
     L.nddm_deepset_reduce.restype = i32
+    i64 = c.c_longlong
+    L.nddm_train_adam_step.argtypes = [fp, fp, fp, fp, i64, fp, f32, f32, f32, f32, f32, f32, f32, fp, fp, fp, fp, i32, fp, vp]
+    L.nddm_train_adam_step.restype = i32
     _lib = L
     return _lib

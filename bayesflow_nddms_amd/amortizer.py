@@ -140,7 +140,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
     microseconds over [sets x trials, 64].  x [B, N, d] -> pooled [B, 64].  params: W1, b1, W2, b2, W3, b3 of the blocks'
     (invariant, equivariant) MLPs in order, then of the pre-pooling MLP.  mask [N] / inv_n (device scalar) or None."""
 
-    ROWS_PER_WG = 128
+    ROWS_PER_WG = 64     # one 64-row tile per workgroup: 160 workgroups at 32 sets x 300 trials (the chip has 256 CUs)
 
     @staticmethod
     def _common(x_t, d, B, N, S, rpw, mask, inv_n, ctx_part, S_ctx, prm):

@@ -83,11 +83,11 @@ def build_hip(force=False, verbose=False):
     return SO_PATH
 
 
-# ---- the amortizer's kernels (csrc/train_kernels.hip: the flow; csrc/train_deepset.hip: the summary network's per-trial MLPs
+# ---- the amortizer's kernels (csrc/train_kernels.hip: the flow; csrc/train_deepset.hip: the summary network's per-trial MLPs; csrc/train_update.hip: Adam
 # -> libnddm_train.so): not part of the simulator's C ABI; the PyTorch path is the fallback wherever this library is absent or the
 # shape is not covered
 TRAIN_SO_PATH = os.path.join(_HERE, "libnddm_train.so")
-TRAIN_SOURCES = [os.path.join(_HERE, "csrc", "train_kernels.hip"), os.path.join(_HERE, "csrc", "train_deepset.hip")]
+TRAIN_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("train_kernels.hip", "train_deepset.hip", "train_update.hip")]
 TRAIN_SOURCE = TRAIN_SOURCES[0]
 
 

@@ -24,6 +24,14 @@ constexpr int NT = 256;       // threads per workgroup: wave w owns the 32 x 32 
 constexpr int DS_MAX = 4;     // a "small" input (the raw trials: rt, choice) goes through layer 1 as plain FMAs
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of workgroup 0 (tools/_flow_stamps.py)
+__device__ unsigned long long g_stamps[8192];
+__device__ int g_nstamps;
+#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 struct Mlp { const float *W1; int ldw1; const float *b1, *W2, *b2, *W3, *b3; };
 // W1 [64, ldw1]: columns [0, d_in) act on the trial, columns [d_in, d_in + 64) on the set's pooled context (if there is one)
 
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
     const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
     const long long row0 = (long long)b * C.N;
+    STAMP(100);
     stage64(w2s, C.P.W2, HS, t);
     stage64(w3s, C.P.W3, HS, t);
     if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     const int u = 32 * ub + m;                       // this lane's column of every result tile
     const float bias2 = C.P.b2[u], bias3 = C.P.b3[u], bias1 = cs[u];
     float pacc = 0.0f;
+    STAMP(101);
     for (int n0 = n_begin; n0 < n_end; n0 += TM) {
         if (BIG) {
             for (int p = t; p < TM * HS / 4; p += NT) {
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             }
         }
         __syncthreads();
+        STAMP(102);
         if (BIG) {                                   // layer 1
             const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
 #pragma unroll
@@ -184,6 +195,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             }
         }
         __syncthreads();
+        STAMP(103);
         {                                            // layer 2
             const f32x16 acc = mma64<1, 1>(&h1s[32 * rb + m][32 * kk], &w2s[u][32 * kk], zero16());
 #pragma unroll
@@ -195,6 +207,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             }
         }
         __syncthreads();
+        STAMP(104);
         {                                            // layer 3 (no activation), and the masked sums of its output
             const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
 #pragma unroll
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 }
             }
         }
+        STAMP(105);
         // (the next tile's writes to xs / h1s / h2s are each behind a barrier every reader of this tile has passed)
     }
     if (O.pool_part) {                               // fixed-order sum of the four lanes that share a column
@@ -262,6 +276,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
     const long long row0 = (long long)b * C.N;
     const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
+    STAMP(200);
     stage64(w2s, C.P.W2, HS, t);
     stage64(w3s, C.P.W3, HS, t);
     if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
@@ -292,6 +307,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const int uu = t & 63, rg = t >> 6;
     for (int n0 = n_begin; n0 < n_end; n0 += TM) {
         __syncthreads();                             // the previous tile's readers are done
+        STAMP(201);
         for (int p = t; p < TM * HS / 4; p += NT) {
             const int r = p >> 4, c4 = p & 15, n = n0 + r;
             float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vg = v1, vx = v1;
@@ -318,6 +334,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
             }
         __syncthreads();
+        STAMP(202);
         // layer 3: dW3 [unit out, unit in] += g^T h2 (the k's are the tile's rows); d h2 = g W3 -> d(pre-activation 2)
         aW3 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &h2s[32 * kk][u], aW3);
 #pragma unroll 8
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
             }
         }
         __syncthreads();
+        STAMP(203);
         // layer 2
         aW2 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &h1s[32 * kk][u], aW2);
 #pragma unroll 8
@@ -344,6 +362,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
             }
         }
         __syncthreads();
+        STAMP(204);
         // layer 1
 #pragma unroll 8
         for (int q = 0; q < 16; ++q) db[0] += gs[16 * rg + q][uu];
@@ -369,6 +388,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
             }
         }
     }
+    STAMP(205);
     // ---- this workgroup's partial sums
     float *wp = Q.wpart + (long long)blockIdx.x * Q.ld_part;
     const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + HS * HS;
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
             wp[oW1 + r * ld1 + C.d_in + k] = db1s[r] * pooled[k];
         }
     }
+    STAMP(206);
 }
 
 // out[p] = sum over g of part[g][p], g in fixed order
@@ -487,3 +508,18 @@ int nddm_deepset_reduce(const float *part, int G, int P, float *out, void *strea
 }
 
 }  // extern "C"
+
+#ifdef NDDM_TRAIN_STAMPS
+extern "C" int nddm_deepset_read_stamps(unsigned long long *out, int cap)
+{
+    int n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(nddm_deepset::g_nstamps), sizeof(int));
+    if (n > cap) n = cap;
+    if (n > 4096) n = 4096;
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nddm_deepset::g_stamps), sizeof(unsigned long long) * 2 * n);
+    int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(nddm_deepset::g_nstamps), &zero, sizeof(int));
+    return n;
+}
+#endif

@@ -68,19 +68,39 @@ class GraphTrainer:
         self.split = (self.world > 1) if split is None else bool(split)
         self.iteration = 0
         with torch.cuda.device(self.dev):
-            # parameters' gradients are views of ONE flat buffer (+ 1 slot that carries the loss through the all-reduce)
+            # ONE flat buffer each for the parameters (the modules' tensors become views of it), the gradients (+ 1 slot that
+            # carries the loss through the all-reduce) and Adam's two moments: the optimizer step is then three launches of the
+            # library's (csrc/train_update.hip) instead of ~20 of PyTorch's.  Every tensor starts on a 16-byte boundary (the
+            # training kernels read weights with 16-byte loads): sizes are padded to multiples of four floats, the pads stay zero.
             self.params = [p for p in self.amortizer.parameters() if p.requires_grad]
-            n_el = sum(p.numel() for p in self.params)
-            self.flat = torch.zeros(n_el + 1, dtype=torch.float32, device=self.dev)
-            self.n_el, o = n_el, 0
+            self._offs, o = [], 0
             for p in self.params:
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
-                o += p.numel()
+                self._offs.append(o)
+                o += -(-p.numel() // 4) * 4
+            self.n_el = n_el = o
+            self.flat_p = torch.zeros(n_el, dtype=torch.float32, device=self.dev)
+            self.flat = torch.zeros(n_el + 1, dtype=torch.float32, device=self.dev)
+            self._pads = []
+            with torch.no_grad():
+                for p, o in zip(self.params, self._offs):
+                    view = self.flat_p[o:o + p.numel()].view_as(p)
+                    view.copy_(p.to(self.dev))
+                    p.data = view
+                    p.grad = None
+                    pad = -p.numel() % 4
+                    self._pads.append(torch.zeros(pad, dtype=torch.float32, device=self.dev) if pad else None)
             self.lr_t = torch.tensor(self.lr0, dtype=torch.float32, device=self.dev)
-            # fused: ONE multi-tensor kernel per step.  (The capturable foreach form computes its bias corrections as per-parameter
-            # 0-dim tensors: ~400 four-microsecond kernels for this model's 110 parameter tensors, a third of the iteration.)
-            self.optimizer = torch.optim.Adam(self.params, lr=self.lr_t, capturable=True, fused=True)
-            self.grad_views = [p.grad for p in self.params]
+            from . import _train_lib
+            self._lib = _train_lib.lib()
+            if self._lib is not None:
+                self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+                self._partial = torch.zeros(256, dtype=torch.float32, device=self.dev)
+                self.optimizer = None
+            else:
+                # without the library: PyTorch's fused multi-tensor Adam on the same flat layout (one tensor)
+                self._flat_param = torch.nn.Parameter(self.flat_p)
+                self._flat_param.grad = self.flat[:n_el]
+                self.optimizer = torch.optim.Adam([self._flat_param], lr=self.lr_t, capturable=True, fused=True)
             # device-side counters and scalars
             self.offset = torch.tensor([self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
             self.step_i = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -88,10 +108,11 @@ class GraphTrainer:
             self.n_f = torch.full((1,), float(self.n_max), dtype=torch.float32, device=self.dev)
             self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
             self.arange = torch.arange(self.n_max, dtype=torch.float32, device=self.dev)
-            # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
-            self.optimizer.step()
-            for st in self.optimizer.state.values():
-                st["step"].zero_()
+            if self.optimizer is not None:
+                # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
+                self.optimizer.step()
+                for st in self.optimizer.state.values():
+                    st["step"].zero_()
         self._buckets = {}
         self._replay = None
         # everything the trainer enqueues -- warm-up passes, captures, replays -- goes to ONE stream of its own: autograd's
@@ -125,11 +146,26 @@ class GraphTrainer:
         # gradients straight into the flat buffer with ONE concatenation (accumulating into pre-set .grad views costs one add
         # kernel per parameter tensor plus the zero fill; torch._foreach_copy_ runs as one copy per tensor here: ~90 launches)
         grads = torch.autograd.grad(loss, self.params)
-        torch.cat([g.reshape(-1) for g in grads], out=self.flat[:self.n_el])
+        pieces = []
+        for g, pad in zip(grads, self._pads):
+            pieces.append(g.reshape(-1))
+            if pad is not None:
+                pieces.append(pad)
+        torch.cat(pieces, out=self.flat[:self.n_el])
         self.flat[self.n_el:].copy_(loss.detach().view(1))
 
     def _update(self, scale):
-        """cosine schedule, clip_grad_norm_(5.0) on the flat gradient, Adam, loss into the history buffer."""
+        """cosine schedule, clip_grad_norm_(5.0) on the flat gradient, Adam, loss into the history buffer, counters."""
+        if self._lib is not None:
+            rc = self._lib.nddm_train_adam_step(self.flat_p.data_ptr(), self.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.n_el, self._partial.data_ptr(), float(scale), self.clip,
+                                                self.lr0, float(max(1, self.T)), 0.9, 0.999, 1e-8, self.step_i.data_ptr(),
+                                                self.step_f.data_ptr(), self.lr_t.data_ptr(), self.loss_buf.data_ptr(),
+                                                self.loss_buf.numel(), self.flat[self.n_el:].data_ptr(),
+                                                torch.cuda.current_stream(self.dev).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"nddm_train_adam_step failed ({rc})")
+            return
         g = self.flat[:self.n_el]
         if scale != 1.0:
             self.flat.mul_(scale)                                     # mean over ranks (gradients and the loss slot)
@@ -169,7 +205,9 @@ class GraphTrainer:
     # ------------------------------------------------------------------------------------------------ graphs
     def _mutable(self):
         # (the flat gradient buffer too: a stretch that starts with the update clips it in place)
-        ts = list(self.params) + [self.offset, self.step_i, self.step_f, self.lr_t, self.n_f, self.flat]
+        ts = [self.flat_p, self.offset, self.step_i, self.step_f, self.lr_t, self.n_f, self.flat, self.loss_buf]
+        if self.optimizer is None:
+            return ts + [self.exp_avg, self.exp_avg_sq]
         for st in self.optimizer.state.values():
             ts += [st["step"], st["exp_avg"], st["exp_avg_sq"]]
         return ts
@@ -312,7 +350,7 @@ class GraphTrainer:
     # so that a resumed run continues the random stream and reproduces the uninterrupted one
     def state_dict(self):
         self._stream.synchronize()
-        st = {"model": self.amortizer.state_dict(), "optimizer": self.optimizer.state_dict(), "iteration": self.iteration,
+        st = {"model": self.amortizer.state_dict(), "optimizer": self._optimizer_state(), "iteration": self.iteration,
               "offset": self.offset.cpu(), "step_i": self.step_i.cpu(), "step_f": self.step_f.cpu(), "lr": self.lr_t.cpu(),
               "loss_buf": self.loss_buf.cpu(), "replay": None}
         if self._replay is not None:
@@ -320,16 +358,27 @@ class GraphTrainer:
             st["replay"] = {"ring": [(p.cpu(), t.cpu(), n) for p, t, n in ring], "rng": rng.bit_generator.state, "capacity": cap}
         return st
 
+    def _moments(self):
+        if self.optimizer is None:
+            return self.exp_avg, self.exp_avg_sq
+        state = self.optimizer.state[self._flat_param]
+        return state["exp_avg"], state["exp_avg_sq"]
+
+    def _optimizer_state(self):
+        m, v = self._moments()
+        return {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "layout": "flat, every parameter tensor padded to a multiple of 4 floats"}
+
     def load_state_dict(self, st):
         import numpy as np
         self._stream.synchronize()
         with torch.no_grad():
             self.amortizer.load_state_dict(st["model"])
-            # Adam's state tensors are the ones the captured graphs hold: copy INTO them
-            src = st["optimizer"]["state"]
-            for i, p in enumerate(self.params):
-                for k in ("step", "exp_avg", "exp_avg_sq"):
-                    self.optimizer.state[p][k].copy_(src[i][k])
+            # Adam's state tensors are the ones the captured graphs hold: copy INTO them (Adam's step count is step_i)
+            m, v = self._moments()
+            m.copy_(st["optimizer"]["exp_avg"])
+            v.copy_(st["optimizer"]["exp_avg_sq"])
+            if self.optimizer is not None:
+                self.optimizer.state[self._flat_param]["step"].copy_(st["step_i"].to(torch.float32).view(()))
             self.offset.copy_(st["offset"]); self.step_i.copy_(st["step_i"]); self.step_f.copy_(st["step_f"])
             self.lr_t.copy_(st["lr"])
             n = min(self.loss_buf.numel(), st["loss_buf"].numel())

@@ -282,3 +282,44 @@ def test_fused_deepset_equals_the_pytorch_path():
         a = net(x)
         net.fused = False
         assert torch.allclose(a, net(x), rtol=1e-4, atol=1e-5)
+
+
+def test_flat_adam_step_equals_pytorch():
+    """csrc/train_update.hip: global-norm clipping + cosine learning rate + Adam on flat buffers (three launches) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam + the same schedule, over several steps with gradients large enough to be
+    clipped at first; the loss history, the reported rate and both counters move as the PyTorch form moves them."""
+    import math
+    import torch
+    from bayesflow_nddms_amd import _train_lib
+    L = _train_lib.lib()
+    assert L is not None
+    torch.manual_seed(11)
+    n, T, lr0, clip, scale = 4096 + 8, 50, 2e-3, 5.0, 0.5
+    p0 = torch.randn(n, device="cuda")
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=lr0)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    g = torch.zeros(n + 1, device="cuda")
+    partial = torch.zeros(256, device="cuda")
+    step_i, step_f = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, device="cuda")
+    lr_out, loss_buf = torch.zeros((), device="cuda"), torch.zeros(4, device="cuda")
+    for it in range(6):
+        grad = torch.randn(n, device="cuda") * (3.0 if it < 3 else 0.01)
+        g[:n].copy_(grad)
+        g[n] = float(it + 1)
+        lr = 0.5 * lr0 * (1.0 + math.cos(it * math.pi / T))
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = grad * scale
+        torch.nn.utils.clip_grad_norm_([ref], clip)
+        opt.step()
+        rc = L.nddm_train_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, partial.data_ptr(), scale, clip, lr0, float(T),
+                                    0.9, 0.999, 1e-8, step_i.data_ptr(), step_f.data_ptr(), lr_out.data_ptr(), loss_buf.data_ptr(), 4,
+                                    g[n:].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6), (it, float((p - ref.detach()).abs().max()))
+        assert abs(float(lr_out) - lr) < 1e-9 and int(step_i) == it + 1 and float(step_f) == it + 1
+    assert loss_buf.tolist() == [0.5, 1.0, 1.5, 3.0]          # scaled losses; steps beyond the capacity land in the last slot
+    assert L.nddm_train_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n + 1, partial.data_ptr(), 1.0, clip, lr0, 1.0,
+                                  0.9, 0.999, 1e-8, step_i.data_ptr(), step_f.data_ptr(), lr_out.data_ptr(), loss_buf.data_ptr(), 4,
+                                  g[n:].data_ptr(), None) == 1       # a length that is not a multiple of 4 is refused
