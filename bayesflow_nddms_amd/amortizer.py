@@ -105,9 +105,9 @@ class InvariantNetwork(nn.Module):
         """libnddm_train.so if its per-trial MLP kernels cover this network and this tensor, else None (the PyTorch composition)."""
         if not (self.fused and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] >= 1):
             return None
-        mlps = [m for blk in self.equiv for m in (blk.inv, blk.eq)] + [self.pre_pool]
-        if any(len(m) != 5 or not isinstance(m[1], nn.ReLU) or m[2].weight.shape != (64, 64) or m[4].weight.shape != (64, 64)
-               for m in mlps):
+        mlps = [m for blk in self.equiv for m in (blk.inv, blk.eq)] + [self.pre_pool, self.post_pool]
+        if any(len(m) != 5 or not isinstance(m[1], nn.ReLU) or m[2].weight.shape != (64, 64) or m[4].weight.shape[1] != 64
+               for m in mlps) or any(m[4].weight.shape[0] != 64 for m in mlps[:-1]) or not 1 <= self.summary_dim <= 64:
             return None
         from . import _train_lib
         L = _train_lib.lib()
@@ -120,12 +120,12 @@ class InvariantNetwork(nn.Module):
         L = self._fused_lib(x)
         if L is not None:
             params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
-            params += [t for k in (0, 2, 4) for t in (self.pre_pool[k].weight, self.pre_pool[k].bias)]
+            params += [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
             m = None if mask is None else mask.reshape(-1).to(torch.float32)
             inv = None if inv_n is None else (inv_n if torch.is_tensor(inv_n) else torch.full((1,), float(inv_n), device=x.device))
             if inv is not None:
                 inv = inv.reshape(-1).to(torch.float32)
-            return self.post_pool(_FusedDeepSetFn.apply(L, len(self.equiv), x, m, inv, *params))
+            return _FusedDeepSetFn.apply(L, len(self.equiv), x, m, inv, *params)
         for block in self.equiv:
             x = block(x, mask, inv_n)
         h = self.pre_pool(x)
@@ -134,71 +134,82 @@ class InvariantNetwork(nn.Module):
 
 
 class _FusedDeepSetFn(torch.autograd.Function):
-    """The per-trial part of the summary network -- every equivariant block (an MLP whose masked per-set mean is the context
-    of a second MLP) and the pre-pooling MLP with its masked mean -- as hand-written kernels (csrc/train_deepset.hip): one
-    launch per 3-layer MLP each way plus one reduction of the weight gradients, instead of ~150 PyTorch launches of 4-7
-    microseconds over [sets x trials, 64].  x [B, N, d] -> pooled [B, 64].  params: W1, b1, W2, b2, W3, b3 of the blocks'
-    (invariant, equivariant) MLPs in order, then of the pre-pooling MLP.  mask [N] / inv_n (device scalar) or None."""
+    """The summary network -- every equivariant block (an MLP whose masked per-set mean is the context of a second MLP), the
+    pre-pooling MLP with its masked mean, and the MLP after the pooling -- as hand-written kernels (csrc/train_deepset.hip): one
+    launch per 3-layer MLP each way plus one reduction of the weight gradients, instead of ~170 PyTorch launches of 4-7
+    microseconds over [sets x trials, 64].  x [B, N, d] -> summary [B, summary_dim].  params: W1, b1, W2, b2, W3, b3 of the
+    blocks' (invariant, equivariant) MLPs in order, then of the pre-pooling MLP, then of the post-pooling MLP.
+    mask [N] / inv_n (device scalar) or None."""
 
     ROWS_PER_WG = 64     # one 64-row tile per workgroup: 160 workgroups at 32 sets x 300 trials (the chip has 256 CUs)
 
     @staticmethod
-    def _common(x_t, d, B, N, S, rpw, mask, inv_n, ctx_part, S_ctx, prm):
-        return (x_t.data_ptr(), d, B, N, S, rpw, None if mask is None else mask.data_ptr(),
+    def _common(x_t, d, B, N, S, rpw, mask, inv_n, ctx_part, S_ctx, prm, x_part=None, S_x=0):
+        return (None if x_t is None else x_t.data_ptr(), d, B, N, S, rpw, None if mask is None else mask.data_ptr(),
                 None if inv_n is None else inv_n.data_ptr(), 1.0 / N, None if ctx_part is None else ctx_part.data_ptr(), S_ctx,
                 prm[0].data_ptr(), prm[0].shape[1], prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), prm[4].data_ptr(),
-                prm[5].data_ptr())
+                prm[5].data_ptr(), prm[4].shape[0], None if x_part is None else x_part.data_ptr(), S_x)
 
     @staticmethod
     def forward(ctx, L, nb, x, mask, inv_n, *params):
         (B, N, d0), dev, rpw = x.shape, x.device, _FusedDeepSetFn.ROWS_PER_WG
         T, S, Hd = B * N, -(-N // rpw), 64
+        Sp = -(-B // rpw)                           # the post-pooling MLP runs on one row per set: B rows in all
         x = x.contiguous()
-        acts = torch.empty((2 * nb + 1, 2, T, Hd), dtype=torch.float32, device=dev)
+        acts = torch.empty(((2 * nb + 1) * 2 * T + 2 * B, Hd), dtype=torch.float32, device=dev)   # h1, h2 of every MLP
+        act = lambda k, j: acts[(2 * k + j) * T:(2 * k + j + 1) * T]
+        act_post = lambda j: acts[(2 * nb + 1) * 2 * T + j * B:(2 * nb + 1) * 2 * T + (j + 1) * B]
         xs_next = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
         pools = torch.empty((nb + 1, B, S, Hd), dtype=torch.float32, device=dev)
-        pooled = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+        post = params[12 * nb + 6:]
+        summary = torch.empty((B, post[4].shape[0]), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         cm = _FusedDeepSetFn._common
+        inv_post = inv_n if inv_n is not None else None
         cur, d, rc = x, d0, 0
         for i in range(nb):
             inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
-            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, inv), acts[2 * i, 0].data_ptr(),
-                                         acts[2 * i, 1].data_ptr(), None, pools[i].data_ptr(), st)
-            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), acts[2 * i + 1, 0].data_ptr(),
-                                         acts[2 * i + 1, 1].data_ptr(), xs_next[i].data_ptr(), None, st)
+            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, inv), act(2 * i, 0).data_ptr(),
+                                         act(2 * i, 1).data_ptr(), None, pools[i].data_ptr(), st)
+            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
+                                         act(2 * i + 1, 1).data_ptr(), xs_next[i].data_ptr(), None, st)
             cur, d = xs_next[i], Hd
-        pre = params[12 * nb:]
-        rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pre), acts[2 * nb, 0].data_ptr(),
-                                     acts[2 * nb, 1].data_ptr(), None, pools[nb].data_ptr(), st)
-        rc |= L.nddm_deepset_pool_finalize(pools[nb].data_ptr(), B, S, None if inv_n is None else inv_n.data_ptr(), 1.0 / N,
-                                           pooled.data_ptr(), st)
+        pre = params[12 * nb:12 * nb + 6]
+        rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pre), act(2 * nb, 0).data_ptr(),
+                                     act(2 * nb, 1).data_ptr(), None, pools[nb].data_ptr(), st)
+        # (1 / N as the host's value must be THIS launch's N, not the B rows the post-pooling MLP is launched over)
+        cp = list(cm(None, Hd, 1, B, Sp, rpw, None, inv_post, None, 0, post, pools[nb], S))
+        cp[8] = 1.0 / N
+        rc |= L.nddm_deepset_mlp_fwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), summary.data_ptr(), None, st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_fwd failed ({rc})")
         ctx.L, ctx.nb, ctx.has_mask, ctx.has_inv = L, nb, mask is not None, inv_n is not None
         ctx.save_for_backward(x, acts, xs_next, pools, *([mask] if mask is not None else []), *([inv_n] if inv_n is not None else []),
                               *params)
-        return pooled
+        return summary
 
     @staticmethod
-    def backward(ctx, g_pooled):
+    def backward(ctx, g_summary):
         L, nb, rpw = ctx.L, ctx.nb, _FusedDeepSetFn.ROWS_PER_WG
         x, acts, xs_next, pools, *rest = ctx.saved_tensors
         mask = rest.pop(0) if ctx.has_mask else None
         inv_n = rest.pop(0) if ctx.has_inv else None
         params = rest
         (B, N, d0), dev, Hd = x.shape, x.device, 64
-        T, S = B * N, pools.shape[2]
+        T, S, Sp = B * N, pools.shape[2], -(-B // rpw)
         G = B * S
+        act = lambda k, j: acts[(2 * k + j) * T:(2 * k + j + 1) * T]
+        act_post = lambda j: acts[(2 * nb + 1) * 2 * T + j * B:(2 * nb + 1) * 2 * T + (j + 1) * B]
         sizes = [p.numel() for p in params]
-        per_mlp = [sum(sizes[6 * k:6 * k + 6]) for k in range(2 * nb + 1)]
-        offs = [sum(per_mlp[:k]) for k in range(2 * nb + 1)]
+        per_mlp = [sum(sizes[6 * k:6 * k + 6]) for k in range(2 * nb + 2)]
+        offs = [sum(per_mlp[:k]) for k in range(2 * nb + 2)]
         P = sum(per_mlp)
         part = torch.empty((G, P), dtype=torch.float32, device=dev)
         flat = torch.empty(P, dtype=torch.float32, device=dev)
         gxbuf = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
         dctx = torch.empty((max(nb, 1), B, S, Hd), dtype=torch.float32, device=dev)
-        g_pooled = g_pooled.contiguous()
+        g_pooled = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+        g_summary = g_summary.contiguous()
         st, F = torch.cuda.current_stream(dev).cuda_stream, 4
         cm = _FusedDeepSetFn._common
         pp = part.data_ptr()
@@ -206,22 +217,27 @@ class _FusedDeepSetFn(torch.autograd.Function):
         def x_of(i):                                # input of block i (and of the pre-pooling MLP for i == nb)
             return (xs_next[i - 1], Hd) if i else (x, d0)
 
+        post = params[12 * nb + 6:]
+        cp = list(cm(None, Hd, 1, B, Sp, rpw, None, inv_n, None, 0, post, pools[nb], S))
+        cp[8] = 1.0 / N
+        rc = L.nddm_deepset_mlp_bwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), g_summary.data_ptr(), None, 0, None, 0,
+                                    g_pooled.data_ptr(), 0, None, pp + offs[2 * nb + 1] * F, P, st)
         xin, d = x_of(nb)
-        pre = params[12 * nb:]
-        rc = L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, pre), acts[2 * nb, 0].data_ptr(),
-                                    acts[2 * nb, 1].data_ptr(), None, g_pooled.data_ptr(), 0, None, 0,
-                                    gxbuf[nb - 1].data_ptr() if nb else None, 0, None, pp + offs[2 * nb] * F, P, st)
+        pre = params[12 * nb:12 * nb + 6]
+        rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, pre), act(2 * nb, 0).data_ptr(),
+                                     act(2 * nb, 1).data_ptr(), None, g_pooled.data_ptr(), 0, None, 0,
+                                     gxbuf[nb - 1].data_ptr() if nb else None, 0, None, pp + offs[2 * nb] * F, P, st)
         for i in reversed(range(nb)):
             inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
             xin, d = x_of(i)
             gx = gxbuf[i - 1].data_ptr() if i else None
-            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), acts[2 * i + 1, 0].data_ptr(),
-                                         acts[2 * i + 1, 1].data_ptr(), gxbuf[i].data_ptr(), None, 0, None, 0, gx, 0,
+            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
+                                         act(2 * i + 1, 1).data_ptr(), gxbuf[i].data_ptr(), None, 0, None, 0, gx, 0,
                                          dctx[i].data_ptr(), pp + offs[2 * i + 1] * F, P, st)
-            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, inv), acts[2 * i, 0].data_ptr(),
-                                         acts[2 * i, 1].data_ptr(), None, dctx[i].data_ptr(), S, eq[0].data_ptr() + d * F, d + Hd,
+            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, inv), act(2 * i, 0).data_ptr(),
+                                         act(2 * i, 1).data_ptr(), None, dctx[i].data_ptr(), S, eq[0].data_ptr() + d * F, d + Hd,
                                          gx, 1, None, pp + offs[2 * i] * F, P, st)
-        rc |= L.nddm_deepset_reduce(pp, G, P, flat.data_ptr(), st)
+        rc |= L.nddm_deepset_reduce(pp, G, P, offs[2 * nb + 1], Sp, flat.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_bwd failed ({rc})")
         grads, o = [], 0

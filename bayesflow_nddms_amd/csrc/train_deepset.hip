@@ -42,7 +42,9 @@ struct Common {
     const float *inv_n; float inv_n_host;   // 1 / (number of real trials): device scalar, or (null) the host's value
     const float *ctx_part; int S_ctx;       // [B, S_ctx, 64] partial sums of the pooled producer; null: no context
     Mlp P;
-};
+    int d_out;                              // rows of W3 / b3 (<= 64): 64 for the per-trial MLPs, the summary width for the last MLP
+    const float *x_part; int S_x;           // not null (d_in == 64): row r of x IS inv_n * sum over s of x_part[r][s][.] -- the MLP
+};                                          // after the pooling runs on the pooled means, one row per set (launched as ONE "set" of B rows)
 
 // acc += A B over 64 k's.  Lane l holds A[i = l & 31][k] and B[k][j = l & 31] for the 32 k's of its half (l >> 5): the order of
 // the sum is free, so step s of the instruction stream takes k = 32 (l >> 5) + s from both.  SA / SB: distance in floats between
@@ -86,13 +88,29 @@ __device__ __forceinline__ f32x16 zero16()
     return z;
 }
 
-// 64 x 64 row-major weights -> LDS [64][LD], 16-byte loads (ldw: the source's row stride in floats, a multiple of 4)
-__device__ __forceinline__ void stage64(float (*dst)[LD], const float *src, int ldw, int t)
+// [rows <= 64] x 64 row-major weights -> LDS [64][LD] (rows beyond: zero), 16-byte loads (ldw: the source's row stride in floats,
+// a multiple of 4)
+__device__ __forceinline__ void stage64(float (*dst)[LD], const float *src, int ldw, int t, int rows = HS)
 {
     for (int p = t; p < HS * HS / 4; p += NT) {
         const int r = p >> 4, c4 = p & 15;
-        *reinterpret_cast<float4 *>(&dst[r][4 * c4]) = *reinterpret_cast<const float4 *>(src + (long long)r * ldw + 4 * c4);
+        float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < rows) v = *reinterpret_cast<const float4 *>(src + (long long)r * ldw + 4 * c4);
+        *reinterpret_cast<float4 *>(&dst[r][4 * c4]) = v;
     }
+}
+
+// four columns of row `row` of the input of a 64-wide MLP: loaded, or (x_part) the mean of the pooled partial sums
+__device__ __forceinline__ float4 x_row4(const Common &C, long long row, int c4, float inv_n)
+{
+    if (!C.x_part) return *reinterpret_cast<const float4 *>(C.x + row * HS + 4 * c4);
+    float4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < C.S_x; ++s) {
+        const float4 v = *reinterpret_cast<const float4 *>(C.x_part + (row * C.S_x + s) * HS + 4 * c4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    a.x *= inv_n; a.y *= inv_n; a.z *= inv_n; a.w *= inv_n;
+    return a;
 }
 
 // the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled
@@ -142,14 +160,15 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     const long long row0 = (long long)b * C.N;
     STAMP(100);
     stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t);
+    stage64(w3s, C.P.W3, HS, t, C.d_out);
     if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
     else
         for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
     context(C, b, pooled, cs, t);
     __syncthreads();
     const int u = 32 * ub + m;                       // this lane's column of every result tile
-    const float bias2 = C.P.b2[u], bias3 = C.P.b3[u], bias1 = cs[u];
+    const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
+    const float bias2 = C.P.b2[u], bias3 = u < C.d_out ? C.P.b3[u] : 0.0f, bias1 = cs[u];
     float pacc = 0.0f;
     STAMP(101);
     for (int n0 = n_begin; n0 < n_end; n0 += TM) {
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             for (int p = t; p < TM * HS / 4; p += NT) {
                 const int r = p >> 4, c4 = p & 15, n = n0 + r;
                 float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (n < n_end) v = *reinterpret_cast<const float4 *>(C.x + (row0 + n) * HS + 4 * c4);
+                if (n < n_end) v = x_row4(C, row0 + n, c4, inv_n);
                 *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = v;
             }
         } else {
@@ -213,9 +232,9 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int n = n0 + 32 * rb + drow(v, kk);
-                if (n < n_end) {
+                if (n < n_end && u < C.d_out) {
                     const float val = acc[v] + bias3;
-                    if (O.y) O.y[(row0 + n) * HS + u] = val;
+                    if (O.y) O.y[(row0 + n) * C.d_out + u] = val;
                     if (O.pool_part) pacc = fmaf(C.mask ? C.mask[n] : 1.0f, val, pacc);
                 }
             }
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
     STAMP(200);
     stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t);
+    stage64(w3s, C.P.W3, HS, t, C.d_out);
     if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
     context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
     if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
@@ -315,8 +334,17 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 const long long o = (row0 + n) * HS + 4 * c4;
                 v1 = *reinterpret_cast<const float4 *>(Q.h1 + o);
                 v2 = *reinterpret_cast<const float4 *>(Q.h2 + o);
-                if (Q.gy) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
-                if (BIG) vx = *reinterpret_cast<const float4 *>(C.x + o);
+                if (Q.gy) {
+                    if (C.d_out == HS) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
+                    else {
+                        const float *gr = Q.gy + (row0 + n) * C.d_out;
+                        vg.x = 4 * c4 < C.d_out ? gr[4 * c4] : 0.0f;
+                        vg.y = 4 * c4 + 1 < C.d_out ? gr[4 * c4 + 1] : 0.0f;
+                        vg.z = 4 * c4 + 2 < C.d_out ? gr[4 * c4 + 2] : 0.0f;
+                        vg.w = 4 * c4 + 3 < C.d_out ? gr[4 * c4 + 3] : 0.0f;
+                    }
+                }
+                if (BIG) vx = x_row4(C, row0 + n, c4, inv_n);
                 if (Q.gpool) {
                     const float mk = C.mask ? C.mask[n] : 1.0f;
                     vg.x = fmaf(mk, gp[4 * c4], vg.x); vg.y = fmaf(mk, gp[4 * c4 + 1], vg.y);
@@ -391,12 +419,12 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     STAMP(205);
     // ---- this workgroup's partial sums
     float *wp = Q.wpart + (long long)blockIdx.x * Q.ld_part;
-    const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + HS * HS;
+    const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + C.d_out * HS;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {                   // tile (rb, ub): row = unit out, column = unit in
         const int r = 32 * rb + drow(v, kk);
         wp[oW2 + r * HS + u] = aW2[v];
-        wp[oW3 + r * HS + u] = aW3[v];
+        if (r < C.d_out) wp[oW3 + r * HS + u] = aW3[v];
         if (BIG) wp[oW1 + r * ld1 + u] = aW1[v];
     }
 #pragma unroll
@@ -409,7 +437,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     if (t < 3 * HS) {
         const int l = t >> 6, c = t & 63;
         const float v = (red[0][l][c] + red[1][l][c]) + (red[2][l][c] + red[3][l][c]);
-        wp[l == 0 ? ob1 + c : (l == 1 ? ob2 + c : ob3 + c)] = v;
+        if (l < 2 || c < C.d_out) wp[l == 0 ? ob1 + c : (l == 1 ? ob2 + c : ob3 + c)] = v;
         if (l == 0) {
             db1s[c] = v;
             if (Q.dctx_part) Q.dctx_part[((long long)b * C.S + sp) * HS + c] = v;
@@ -427,11 +455,12 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     STAMP(206);
 }
 
-// out[p] = sum over g of part[g][p], g in fixed order
-__global__ void reduce_partials_kernel(const float *part, int G, int P, float *out)
+// out[p] = sum over g of part[g][p], g in fixed order; entries p >= P_main were written by the first G_tail rows only
+__global__ void reduce_partials_kernel(const float *part, int G, int P, int P_main, int G_tail, float *out)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    if (p >= P_main) G = G_tail;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     int g = 0;
     for (; g + 4 <= G; g += 4) {
@@ -455,18 +484,21 @@ int nddm_deepset_supported(int hidden, int d_in) { return (hidden == HS && (d_in
 static bool common_ok(const Common &C)
 {
     return nddm_deepset_supported(HS, C.d_in) && C.B > 0 && C.N > 0 && C.S > 0 && C.rows_per_wg > 0 && (long long)C.S * C.rows_per_wg >= C.N
-           && C.P.ldw1 == C.d_in + (C.ctx_part ? HS : 0) && (C.d_in != HS || C.P.ldw1 % 4 == 0);
+           && C.P.ldw1 == C.d_in + (C.ctx_part ? HS : 0) && (C.d_in != HS || C.P.ldw1 % 4 == 0) && C.d_out >= 1 && C.d_out <= HS
+           && (C.x_part ? (C.d_in == HS && C.S_x >= 1) : C.x != nullptr);
 }
 
 /* One per-trial MLP forward.  x [B * N, d_in]; W1 [64, d_in (+ 64 with a context)], W2, W3 [64, 64]; mask [N] or NULL; inv_n: device
  * scalar or NULL (then inv_n_host); ctx_part [B, S_ctx, 64] or NULL.  Writes h1, h2 [B * N, 64], and y [B * N, 64] and / or
- * pool_part [B, S, 64] where not NULL.  S workgroups of up to rows_per_wg trials per set. */
+ * pool_part [B, S, 64] where not NULL.  S workgroups of up to rows_per_wg trials per set.  d_out: rows of W3 / b3 and width of y
+ * (64 but for the last MLP of the network); x_part / S_x: see Common (NULL / 0: x is read). */
 int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
-                         const float *b2, const float *W3, const float *b3, float *h1, float *h2, float *y, float *pool_part, void *stream)
+                         const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, float *h1, float *h2,
+                         float *y, float *pool_part, void *stream)
 {
-    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}};
-    if (!common_ok(C) || !h1 || !h2) return 1;
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    if (!common_ok(C) || !h1 || !h2 || (pool_part && d_out != HS)) return 1;
     const FwdOut O = {h1, h2, y, pool_part};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, O);
@@ -487,12 +519,14 @@ int nddm_deepset_pool_finalize(const float *part, int B, int S, const float *inv
  * apart, of 64 ldw1 + 64 + 2 (4096 + 64) weight-gradient partial sums each: reduce with nddm_deepset_reduce. */
 int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
-                         const float *b2, const float *W3, const float *b3, const float *h1, const float *h2, const float *gy,
-                         const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx, int gx_acc, float *dctx_part,
-                         float *wpart, int ld_part, void *stream)
+                         const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, const float *h1,
+                         const float *h2, const float *gy, const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx,
+                         int gx_acc, float *dctx_part, float *wpart, int ld_part, void *stream)
 {
-    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}};
-    if (!common_ok(C) || !h1 || !h2 || !wpart || ld_part < HS * ldw1 + HS + 2 * (HS * HS + HS) || (gx && d_in != HS) || (!gy && !gpool)) return 1;
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    if (!common_ok(C) || !h1 || !h2 || !wpart || ld_part < HS * ldw1 + HS + HS * HS + HS + d_out * HS + d_out || (gx && d_in != HS)
+        || (!gy && !gpool) || (gpool && d_out != HS))
+        return 1;
     const BwdIO Q = {h1, h2, gy, gpool, gp_S, gp_W, gp_ldw, gx, gx_acc, dctx_part, wpart, ld_part};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, Q);
@@ -500,10 +534,11 @@ int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int nddm_deepset_reduce(const float *part, int G, int P, float *out, void *stream)
+int nddm_deepset_reduce(const float *part, int G, int P, int P_main, int G_tail, float *out, void *stream)
 {
-    if (G <= 0 || P <= 0) return 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, G, P, out);
+    if (G <= 0 || P <= 0 || P_main < 0 || P_main > P || G_tail < 0 || G_tail > G) return 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, G, P, P_main,
+                       G_tail, out);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
