@@ -252,10 +252,12 @@ class _FusedFlowFn(torch.autograd.Function):
     (concatenate, three Linear layers with two ELUs, soft clamp, exp, multiply-add) -- as ONE hand-written kernel forward and ONE
     backward (csrc/train_kernels.hip) and one autograd node: at batch 32 the PyTorch composition is ~400 launches of a few
     microseconds each way, with a slice / concatenate / select bookkeeping kernel between any two.
-    -> (z [R, D], log|det| [R]).  params: per layer ActNorm log-scale and bias, then weight, bias x 3 of both sub-networks."""
+    -> (z [R, D], log|det| [R]); with nll=True -> the maximum-likelihood loss mean(|z|^2 / 2 - log|det|) itself (the backward
+    then derives the gradients of z and log|det| inside the kernel: ~12 more PyTorch launches gone).
+    params: per layer ActNorm log-scale and bias, then weight, bias x 3 of both sub-networks."""
 
     @staticmethod
-    def forward(ctx, L, clamp, d1, perms, theta, cond, *params):
+    def forward(ctx, L, clamp, d1, perms, nll, theta, cond, *params):
         import ctypes
         nl, (R, D), C = len(perms), theta.shape, cond.shape[1]
         Hd, dev = params[4].shape[0], theta.device
@@ -263,45 +265,49 @@ class _FusedFlowFn(torch.autograd.Function):
         saved = torch.empty(3 * nl * R * D + 4 * nl * R * Hd, dtype=torch.float32, device=dev)
         z_all, out_all, s_all = (saved[i * nl * R * D:(i + 1) * nl * R * D].view(nl, R, D) for i in range(3))
         h_all = saved[3 * nl * R * D:]
-        ld = torch.empty(R, dtype=torch.float32, device=dev)
+        ld = torch.empty(R + 1, dtype=torch.float32, device=dev)           # (+ the loss)
         ptrs = (ctypes.c_void_p * (14 * nl))(*[p.data_ptr() for p in params])
         perm = (ctypes.c_int * (nl * D))(*[int(v) for p in perms for v in p])
         rc = L.nddm_train_flow_fwd(nl, R, D, d1, C, float(clamp), ptrs, perm, theta.data_ptr(), cond.data_ptr(), z_all.data_ptr(),
                                    out_all.data_ptr(), s_all.data_ptr(), h_all.data_ptr(), ld.data_ptr(),
-                                   torch.cuda.current_stream(dev).cuda_stream)
+                                   ld[R:].data_ptr() if nll else None, torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"nddm_train_flow_fwd failed ({rc})")
-        ctx.L, ctx.clamp, ctx.d1, ctx.perm, ctx.ptrs, ctx.nl = L, float(clamp), d1, perm, ptrs, nl
+        ctx.L, ctx.clamp, ctx.d1, ctx.perm, ctx.ptrs, ctx.nl, ctx.nll = L, float(clamp), d1, perm, ptrs, nl, bool(nll)
         ctx.save_for_backward(theta, cond, saved, *params)
-        return out_all[nl - 1], ld
+        return ld[R] if nll else (out_all[nl - 1], ld[:R])
 
     @staticmethod
-    def backward(ctx, g_z, g_ld):
+    def backward(ctx, *gs):
         import ctypes
         theta, cond, saved, *params = ctx.saved_tensors
         L, nl, d1 = ctx.L, ctx.nl, ctx.d1
         (R, D), C, dev = theta.shape, cond.shape[1], theta.device
-        Hd = params[4].shape[0]
         n_rd = nl * R * D
-        g_z = g_z.contiguous() if g_z is not None else torch.zeros_like(theta)
-        g_ld = g_ld.contiguous() if g_ld is not None else torch.zeros(R, dtype=torch.float32, device=dev)
         sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes) + 2 * R * D + R * (D - d1) + R * C, dtype=torch.float32, device=dev)
+        flat = torch.empty(sum(sizes) + 3 * R * D + R * (D - d1) + R * C + R, dtype=torch.float32, device=dev)
         grads, o = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[o:o + n].view(p.shape))
             o += n
-        gz, gx, gy2, gcond = flat[o:o + R * D], flat[o + R * D:o + 2 * R * D], flat[o + 2 * R * D:o + 2 * R * D + R * (D - d1)], \
-            flat[o + 2 * R * D + R * (D - d1):]
+        gz, gx, w_gz = flat[o:o + R * D], flat[o + R * D:o + 2 * R * D], flat[o + 2 * R * D:o + 3 * R * D]
+        o += 3 * R * D
+        gy2, gcond, w_gld = flat[o:o + R * (D - d1)], flat[o + R * (D - d1):o + R * (D - d1) + R * C], flat[o + R * (D - d1) + R * C:]
+        if ctx.nll:
+            g_nll, g_z, g_ld = gs[0].contiguous(), w_gz, w_gld
+        else:
+            g_nll = None
+            g_z = gs[0].contiguous() if gs[0] is not None else torch.zeros_like(theta)
+            g_ld = gs[1].contiguous() if gs[1] is not None else torch.zeros(R, dtype=torch.float32, device=dev)
         gptr = (ctypes.c_void_p * (14 * nl))(*[g.data_ptr() for g in grads])
         sp, F = saved.data_ptr(), 4
         rc = L.nddm_train_flow_bwd(nl, R, D, d1, C, ctx.clamp, ctx.ptrs, ctx.perm, gptr, theta.data_ptr(), cond.data_ptr(),
                                    sp, sp + n_rd * F, sp + 2 * n_rd * F, sp + 3 * n_rd * F, g_z.data_ptr(), g_ld.data_ptr(),
-                                   gz.data_ptr(), gy2.data_ptr(), gx.data_ptr(), gcond.data_ptr(),
-                                   torch.cuda.current_stream(dev).cuda_stream)
+                                   None if g_nll is None else g_nll.data_ptr(), gz.data_ptr(), gy2.data_ptr(), gx.data_ptr(),
+                                   gcond.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"nddm_train_flow_bwd failed ({rc})")
-        return (None, None, None, None, gx.view(R, D), gcond.view(R, C), *grads)
+        return (None, None, None, None, None, gx.view(R, D), gcond.view(R, C), *grads)
 
 
 class _AffineCoupling(nn.Module):
@@ -361,7 +367,8 @@ class InvertibleNetwork(nn.Module):
 
     def _fused_lib(self, theta, cond):
         """libnddm_train.so if the fused flow covers this network and these tensors, else None (the PyTorch composition)."""
-        if not (self.fused and len(self.layers) and theta.is_cuda and theta.dtype == torch.float32 and cond.dtype == torch.float32):
+        if not (self.fused and len(self.layers) and theta.is_cuda and theta.dtype == torch.float32 and cond.dtype == torch.float32
+                and theta.shape[0] <= self.FUSED_MAX_ROWS):
             return None
         l0 = self.layers[0]
         if any(len(n) != 5 or not isinstance(n[1], nn.ELU) for l in self.layers for n in (l.net1, l.net2)):
@@ -372,17 +379,32 @@ class InvertibleNetwork(nn.Module):
                                                            cond.shape[1])
         return L if ok else None
 
+    # the fused backward is ONE workgroup walking 32-row tiles (the weight gradients are plain register sums): made for the
+    # training loop's batch of 32 per rank; beyond ~128 rows PyTorch's many small launches, which do spread, are as fast
+    FUSED_MAX_ROWS = 128
+
+    def _flow_params(self):
+        params = []
+        for i, l in enumerate(self.layers):
+            params += [self.an_scale[i], self.an_bias[i]]
+            params += [t for n in (l.net1, l.net2) for k in (0, 2, 4) for t in (n[k].weight, n[k].bias)]
+        return params
+
+    def nll(self, theta, cond):
+        """mean(|z|^2 / 2 - log|det|): the maximum-likelihood loss of bf.amortizers.AmortizedPosterior."""
+        L = self._fused_lib(theta, cond)
+        if L is not None:
+            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, True, theta, cond, *self._flow_params())
+        z, log_det = self(theta, cond)
+        return (0.5 * (z ** 2).sum(-1) - log_det).mean()
+
     def _refresh_host_perms(self, *_):
         self._perm_host = [getattr(self, f"perm{i}").tolist() for i in range(len(self.layers))]
 
     def forward(self, theta, cond):
         L = self._fused_lib(theta, cond)
         if L is not None:
-            params = []
-            for i, l in enumerate(self.layers):
-                params += [self.an_scale[i], self.an_bias[i]]
-                params += [t for n in (l.net1, l.net2) for k in (0, 2, 4) for t in (n[k].weight, n[k].bias)]
-            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, theta, cond, *params)
+            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, False, theta, cond, *self._flow_params())
         z, scales = theta, []
         for i, layer in enumerate(self.layers):
             z = torch.addcmul(self.an_bias[i], z, torch.exp(self.an_scale[i]))
@@ -422,7 +444,10 @@ class AmortizedPosterior(nn.Module):
         return self.inference_net(self._t(input_dict["parameters"]), self._conditions(input_dict))
 
     def compute_loss(self, input_dict):
-        z, log_det = self(input_dict)
+        theta, cond = self._t(input_dict["parameters"]), self._conditions(input_dict)
+        if hasattr(self.inference_net, "nll"):
+            return self.inference_net.nll(theta, cond)
+        z, log_det = self.inference_net(theta, cond)
         return (0.5 * (z ** 2).sum(-1) - log_det).mean()
 
     @torch.no_grad()

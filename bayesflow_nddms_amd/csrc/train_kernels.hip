@@ -400,6 +400,25 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
     STAMP(15);
 }
 
+// mean over the rows of |z|^2 / 2 - log|det| (fixed summation order)
+__global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *ld, int R, int D, float *out)
+{
+    __shared__ float red[256];
+    float a = 0.0f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        float q = 0.0f;
+        for (int c = 0; c < D; ++c) q = fmaf(z[(long long)r * D + c], z[(long long)r * D + c], q);
+        a += 0.5f * q - ld[r];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0] / (float)R;
+}
+
 // ---- the whole flow backward: one workgroup of 1024 threads, half-layers last to first.  The host resolves every half-layer's
 // pointers into a table in the kernel arguments (the loop body then reads its operands like a one-half-layer kernel would).
 struct HalfB {
@@ -414,10 +433,18 @@ struct FlowBwdBuf {
     const float *gz;               // [R, D] scratch the half-layers write: gradient of a layer's permuted ActNorm output
     float *gx;                     // [R, D]: gradient of a layer's input; after layer 0, of theta
     float *gcond;                  // [R, C]
+    const float *g_nll;            // not null: the gradient of the mean negative log-likelihood (a scalar); the kernel then WRITES
+    float *w_gz, *w_gld;           // the gradients of z and log|det| it reads -- z g / R and -g / R -- from the forward's z
+    const float *z_last;
 };
 __global__ __launch_bounds__(NTB) void flow_bwd_kernel(FlowDims Q, FlowB T, const float *cond, FlowBwdBuf U)
 {
     const int t = threadIdx.x, D = Q.D;
+    if (U.g_nll) {                                           // (the first half-layer starts with a barrier)
+        const float sc = *U.g_nll / (float)Q.R;
+        for (int i = t; i < Q.R * D; i += NTB) U.w_gz[i] = U.z_last[i] * sc;
+        for (int r = t; r < Q.R; r += NTB) U.w_gld[r] = -sc;
+    }
     for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
         const HalfB &X = T.half[hl];
         const Args A = {X.xh, D, X.Dh, cond, Q.C, X.xtr, D, X.Dt, X.W1, nullptr, X.W2, nullptr, X.W3, nullptr, Q.clamp, Q.R};
@@ -477,10 +504,10 @@ static void fill(FlowP &P, int L, int D, const void *const *params, const int *p
 }
 
 /* -> z = out_all[L - 1] and ld [R] (log|det|, ActNorm terms included); z_all / out_all / s_all [L, R, D] and h_all [L, 4, R, H]
- * are what the backward needs. */
+ * are what the backward needs.  nll (may be NULL): the maximum-likelihood loss, mean over the rows of |z|^2 / 2 - log|det|. */
 int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         const float *theta, const float *cond, float *z_all, float *out_all, float *s_all, float *h_all, float *ld,
-                        void *stream)
+                        float *nll, void *stream)
 {
     if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
     for (int i = 0; i < L * D; ++i) if (perm[i] < 0 || perm[i] >= D) return 1;
@@ -490,14 +517,19 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowSaved S = {z_all, out_all, s_all, h_all};
     hipLaunchKernelGGL(flow_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta,
                        cond, S, ld);
+    if (nll)
+        hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out_all + (long long)(L - 1) * R * D,
+                           ld, R, D, nll);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-/* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results.
+/* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results -- or, with
+ * g_nll (the gradient of the forward's nll, a device scalar) not NULL, scratch of those sizes that the kernel fills itself.
  * gz [R, D] and gy2 [R, D - d1] are scratch; gx [R, D] ends as the gradient of theta, gcond [R, C] as that of the condition. */
 int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         void *const *grads, const float *theta, const float *cond, float *z_all, float *out_all, float *s_all,
-                        float *h_all, const float *g_z, const float *g_ld, float *gz, float *gy2, float *gx, float *gcond, void *stream)
+                        float *h_all, float *g_z, float *g_ld, const float *g_nll, float *gz, float *gy2, float *gx, float *gcond,
+                        void *stream)
 {
     if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
     for (int i = 0; i < L * D; ++i) if (perm[i] < 0 || perm[i] >= D) return 1;
@@ -520,7 +552,7 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
         for (int d = 0; d < D; ++d) T.norm[l].perm[d] = (unsigned char)perm[l * D + d];
     }
     const FlowDims Q = {L, R, D, d1, C, clamp};
-    const FlowBwdBuf U = {g_ld, gz, gx, gcond};
+    const FlowBwdBuf U = {g_ld, gz, gx, gcond, g_nll, g_z, g_ld, out_all + (long long)(L - 1) * RD};
     hipLaunchKernelGGL(flow_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), Q, T, cond, U);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
