@@ -251,7 +251,8 @@ class _FusedFlowFn(torch.autograd.Function):
     """The whole conditional flow -- per layer an ActNorm, a fixed permutation and two conditional affine-coupling half-layers
     (concatenate, three Linear layers with two ELUs, soft clamp, exp, multiply-add) -- as ONE hand-written kernel forward and ONE
     backward (csrc/train_kernels.hip) and one autograd node: at batch 32 the PyTorch composition is ~400 launches of a few
-    microseconds each way, with a slice / concatenate / select bookkeeping kernel between any two.
+    microseconds each way, with a slice / concatenate / select bookkeeping kernel between any two.  (The backward is two
+    kernels: the chain of activation gradients, and the weight gradients of all half-layers side by side.)
     -> (z [R, D], log|det| [R]); with nll=True -> the maximum-likelihood loss mean(|z|^2 / 2 - log|det|) itself (the backward
     then derives the gradients of z and log|det| inside the kernel: ~12 more PyTorch launches gone).
     params: per layer ActNorm log-scale and bias, then weight, bias x 3 of both sub-networks."""
@@ -285,14 +286,18 @@ class _FusedFlowFn(torch.autograd.Function):
         (R, D), C, dev = theta.shape, cond.shape[1], theta.device
         n_rd = nl * R * D
         sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes) + 3 * R * D + R * (D - d1) + R * C + R, dtype=torch.float32, device=dev)
+        Hd = params[4].shape[0]
+        n_scratch = [nl * R * D, R * D, R * D, R * (D - d1), R * C, R, 2 * nl * R * (2 * Hd + 16)]
+        flat = torch.empty(sum(sizes) + sum(n_scratch), dtype=torch.float32, device=dev)
         grads, o = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[o:o + n].view(p.shape))
             o += n
-        gz, gx, w_gz = flat[o:o + R * D], flat[o + R * D:o + 2 * R * D], flat[o + 2 * R * D:o + 3 * R * D]
-        o += 3 * R * D
-        gy2, gcond, w_gld = flat[o:o + R * (D - d1)], flat[o + R * (D - d1):o + R * (D - d1) + R * C], flat[o + R * (D - d1) + R * C:]
+        scratch = []
+        for n in n_scratch:
+            scratch.append(flat[o:o + n])
+            o += n
+        gz_all, gx, w_gz, gy2, gcond, w_gld, work = scratch
         if ctx.nll:
             g_nll, g_z, g_ld = gs[0].contiguous(), w_gz, w_gld
         else:
@@ -303,8 +308,8 @@ class _FusedFlowFn(torch.autograd.Function):
         sp, F = saved.data_ptr(), 4
         rc = L.nddm_train_flow_bwd(nl, R, D, d1, C, ctx.clamp, ctx.ptrs, ctx.perm, gptr, theta.data_ptr(), cond.data_ptr(),
                                    sp, sp + n_rd * F, sp + 2 * n_rd * F, sp + 3 * n_rd * F, g_z.data_ptr(), g_ld.data_ptr(),
-                                   None if g_nll is None else g_nll.data_ptr(), gz.data_ptr(), gy2.data_ptr(), gx.data_ptr(),
-                                   gcond.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                   None if g_nll is None else g_nll.data_ptr(), gz_all.data_ptr(), gy2.data_ptr(), gx.data_ptr(),
+                                   gcond.data_ptr(), work.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"nddm_train_flow_bwd failed ({rc})")
         return (None, None, None, None, None, gx.view(R, D), gcond.view(R, C), *grads)
@@ -379,9 +384,9 @@ class InvertibleNetwork(nn.Module):
                                                            cond.shape[1])
         return L if ok else None
 
-    # the fused backward is ONE workgroup walking 32-row tiles (the weight gradients are plain register sums): made for the
-    # training loop's batch of 32 per rank; beyond ~128 rows PyTorch's many small launches, which do spread, are as fast
-    FUSED_MAX_ROWS = 128
+    # (the fused kernels take 8 / 32 rows per workgroup, and one workgroup per half-layer sums the weight gradients over all rows:
+    # made for the training loop's batches of 32 ... a few hundred rows)
+    FUSED_MAX_ROWS = 4096
 
     def _flow_params(self):
         params = []

@@ -201,34 +201,34 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// ONE workgroup of 1024 threads (16 waves) walks the row tiles and keeps the weight gradients in registers (deterministic
-// sums, no atomics).  The two 32 x 128 x 128 products -- dW2 = d(a2)^T h1 and d(h1) = d(a2) W2 -- are f32 MFMAs (exact f32)
-// on operands read from LDS: as register-blocked FMAs their LDS reads were 12 of the half-layer's 33 microseconds.
-//   dW2: wave w owns the 32 x 32 tile (rows 32 (w / 4), columns 32 (w % 4)): 16 accumulator registers, v_mfma_f32_32x32x2_f32
-//   d(h1): wave w owns rows 16 (w / 8), units 16 (w % 8): v_mfma_f32_16x16x4_f32
-//   dW1: thread (unit j = t % 128, g = t / 128): columns c with c % 8 == g      <= 4 registers
-//   dW3: column j of rows m with m % 8 == g                                     <= 2
+// Two kernels.  (1) The chain of ACTIVATION gradients, half-layers last to first -- the critical path: every row is independent,
+// so workgroup w takes rows [32 w, 32 w + 32) through all of it (1024 threads; d(h1) = d(a2) W2 is v_mfma_f32_16x16x4_f32 on LDS
+// operands) and leaves d(pre-activation 1, 2) and d(output) of every half-layer in global memory.  (2) The WEIGHT gradients of all
+// half-layers at once, one workgroup per half-layer (dW2 = d(a2)^T h1 as v_mfma_f32_32x32x2_f32, a 32 x 32 tile per wave): they
+// are off the critical path, and as one kernel with (1) they were 60 % of a half-layer's 19 microseconds.
 // Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
-// are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of 33).
-struct BwdOut {
-    float *gxh; int ldgh;      // [R, Dh]
-    float *gcond;              // [R, C]
-    float *gxtr; int ldgt;     // [R, Dt]
-    float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
-    int acc_gxh, acc_gcond;    // add to what gxh / gcond hold instead of overwriting (the second half-layer of a coupling layer)
-};
-struct BwdIn {
-    const float *s; int lds;       // [R, Dt] clamped log-scales saved by the forward
-    const float *gy; int ldgy;     // [R, Dt] gradient of the transformed half
-    const float *gy2; int ldgy2;   // optional second contribution to it (null: none)
-    const float *gs;               // [R] gradient of the row's log|det| (= of every one of its log-scales)
-};
+// are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of the original 33).
 constexpr int NTB = 1024;
 constexpr int LDW2 = H + 8;      // row stride of W2 in LDS: d(h1)'s B operand reads 4 rows x 16 columns per wave instruction
 
-__device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I, const float *h1_in, const float *h2_in, const BwdOut &O)
+struct HalfD {                   // one half-layer of kernel (1), resolved by the host
+    const float *xtr, *W1, *W2, *W3, *s, *h1, *h2, *gy, *gy2;
+    float *gxh, *gxtr, *da2, *da1, *dos;     // da2, da1 [R, H], dos [R, M_MAX]: for kernel (2)
+    int Dh, Dt, ldgh, acc_gxh, acc_gcond, norm;          // norm: the layer's ActNorm / permutation backward follows (-1: no)
+};
+struct NormD { const float *scale; const float *gz; unsigned char perm[D_MAX]; };
+struct FlowD { HalfD half[2 * L_MAX]; NormD norm[L_MAX]; };
+struct FlowBwdBuf {
+    const float *g_ld;             // [R] gradient of the flow's log|det|
+    float *gx;                     // [R, D]: gradient of a layer's input; after layer 0, of theta
+    float *gcond;                  // [R, C]
+    const float *g_nll;            // not null: the gradient of the mean negative log-likelihood (a scalar); the kernel then WRITES
+    float *w_gz, *w_gld;           // the gradients of z and log|det| it reads -- z g / R and -g / R -- from the forward's z
+    const float *z_last;
+};
+
+__global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, FlowBwdBuf U)
 {
-    __shared__ float in_s[TR][DI_MAX];
     __shared__ float h1r[TR][LDR];        // [row][unit]
     __shared__ float h2r[TR][LDR];        // later: d(pre-activation 1)
     __shared__ float da2r[TR][LDR];       // d(pre-activation 2)
@@ -236,15 +236,142 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
     __shared__ float w2s[H][LDW2];
     __shared__ float w1s[H][DI_MAX + 1];
     __shared__ float w3s[M_MAX][H];
-    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6;
-    const int DI = A.Dh + A.C, M = 2 * A.Dt;
-    __syncthreads();                      // the previous half-layer's last phase read w1s and h2r
-    STAMP(10);
+    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D;
+    const int r0 = blockIdx.x * TR, rows = min(TR, Q.R - r0);
+    if (U.g_nll) {                                           // (this workgroup's rows; the first half-layer starts with a barrier)
+        const float sc = *U.g_nll / (float)Q.R;
+        for (int i = t; i < rows * D; i += NTB) U.w_gz[(long long)r0 * D + i] = U.z_last[(long long)r0 * D + i] * sc;
+        for (int r = t; r < rows; r += NTB) U.w_gld[r0 + r] = -sc;
+    }
+    for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
+        const HalfD &X = T.half[hl];
+        const int DI = X.Dh + Q.C, M = 2 * X.Dt;
+        __syncthreads();                  // the previous half-layer's last phase read w1s and h2r; its global writes are visible
+        STAMP(10);
 #pragma unroll
-    for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = A.W2[t + NTB * k];
-    for (int p = t; p < H * DI; p += NTB) { const int jj = p / DI; w1s[jj][p - jj * DI] = A.W1[p]; }
-    for (int p = t; p < M * H; p += NTB) (&w3s[0][0])[p] = A.W3[p];
-    STAMP(101);
+        for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = X.W2[t + NTB * k];
+        for (int p = t; p < H * DI; p += NTB) { const int jj = p / DI; w1s[jj][p - jj * DI] = X.W1[p]; }
+        for (int p = t; p < M * H; p += NTB) (&w3s[0][0])[p] = X.W3[p];
+#pragma unroll
+        for (int k = 0; k < TR * H / NTB; ++k) {         // saved activations (rows beyond R: zero)
+            const int r = g + 8 * k, row = r0 + r;
+            h1r[r][j] = row < Q.R ? X.h1[(long long)row * H + j] : 0.0f;
+            h2r[r][j] = row < Q.R ? X.h2[(long long)row * H + j] : 0.0f;
+        }
+        for (int p = t; p < TR * X.Dt; p += NTB) {       // through the affine transform and the soft clamp
+            const int r = p / X.Dt, d = p - r * X.Dt, row = r0 + r;
+            float d_os = 0.0f, d_t = 0.0f;
+            if (row < Q.R) {
+                const float s = X.s[(long long)row * D + d], es = expf(s);
+                float gg = X.gy[(long long)row * D + d];
+                if (X.gy2) gg += X.gy2[(long long)row * (D - Q.d1) + d];
+                const float d_sc = fmaf(gg * X.xtr[(long long)row * D + d], es, U.g_ld[row]);
+                const float u = s / Q.clamp;
+                d_os = d_sc * (1.0f - u * u);
+                d_t = gg;
+                X.gxtr[(long long)row * D + d] = gg * es;
+                X.dos[(long long)row * M_MAX + d] = d_os;
+                X.dos[(long long)row * M_MAX + X.Dt + d] = d_t;
+            }
+            do_s[r][d] = d_os;
+            do_s[r][X.Dt + d] = d_t;
+        }
+        __syncthreads();
+        STAMP(11);
+        {   // d h2 -> d(pre-activation 2): thread (unit j, rows 4 g .. 4 g + 3)
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+            for (int m = 0; m < M; ++m) {
+                const float w = w3s[m][j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, do_s[4 * g + q][m], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                const float v = acc[q] * elu_grad_from_out(h2r[r][j]);
+                da2r[r][j] = v;
+                if (r0 + r < Q.R) X.da2[(long long)(r0 + r) * H + j] = v;
+            }
+        }
+        __syncthreads();
+        STAMP(12);
+        {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k = l >> 4] = da2[row][4 s + k], B[k][i = l & 15] = W2[4 s + k][i]
+            const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float *ap = &da2r[16 * rb + n][kk], *bp = &w2s[kk][16 * ib + n];
+#pragma unroll 8
+            for (int s4 = 0; s4 < H; s4 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4], bp[s4 * LDW2], acc, 0, 0, 0);
+            // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register  (h2r: its readers finished before the barrier above)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
+                const float v = acc[q] * elu_grad_from_out(h1r[r][i]);
+                h2r[r][i] = v;
+                if (r0 + r < Q.R) X.da1[(long long)(r0 + r) * H + i] = v;
+            }
+        }
+        __syncthreads();
+        STAMP(13);
+        // d in: (row, column) pairs, `parts` adjacent lanes each (a power of two: every thread busy for 512 pairs or fewer)
+        {
+            const int npairs = TR * DI, parts = npairs <= NTB / 4 ? 4 : (npairs <= NTB / 2 ? 2 : 1), span = H / parts;
+            const int pr = t / parts, part = t - pr * parts;
+            const int r = pr / DI, c = pr - r * DI, row = r0 + r;
+            float acc = 0.0f;
+            if (pr < npairs) {
+#pragma unroll 8
+                for (int jj = part * span; jj < (part + 1) * span; ++jj) acc = fmaf(w1s[jj][c], h2r[r][jj], acc);
+            }
+            if (parts >= 2) acc += __shfl_xor(acc, 1);
+            if (parts >= 4) acc += __shfl_xor(acc, 2);
+            if (pr < npairs && part == 0 && row < Q.R) {
+                if (c < X.Dh) {
+                    float *o = &X.gxh[(long long)row * X.ldgh + c];
+                    *o = X.acc_gxh ? *o + acc : acc;
+                } else {
+                    float *o = &U.gcond[(long long)row * Q.C + (c - X.Dh)];
+                    *o = X.acc_gcond ? *o + acc : acc;
+                }
+            }
+        }
+        STAMP(14);
+        if (X.norm < 0) continue;
+        __syncthreads();
+        // back through the permutation and the ActNorm (the parameters' gradients: kernel (2))
+        const NormD &N = T.norm[X.norm];
+        if (t < TR * D) {
+            const int r = t / D, c = t - r * D, row = r0 + r;
+            if (row < Q.R) {
+                const int p = N.perm[c];
+                U.gx[(long long)row * D + p] = N.gz[(long long)row * D + c] * expf(N.scale[p]);
+            }
+        }
+    }
+}
+
+struct HalfW {                   // one half-layer of kernel (2)
+    const float *xh, *h1, *h2, *da2, *da1, *dos;
+    float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
+    int Dh, Dt, norm, pad_;
+};
+struct NormW { const float *x, *scale, *gz; float *gscale, *gbias; unsigned char perm[D_MAX]; };
+struct FlowW { HalfW half[2 * L_MAX]; NormW norm[L_MAX]; };
+
+//   dW2: wave w owns the 32 x 32 tile (rows 32 (w / 4), columns 32 (w % 4)): 16 accumulator registers
+//   dW1: thread (unit j = t % 128, g = t / 128): columns c with c % 8 == g      <= 4 registers
+//   dW3: column j of rows m with m % 8 == g                                     <= 2
+__global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, const float *cond, const float *g_ld)
+{
+    __shared__ float in_s[TR][DI_MAX];
+    __shared__ float h1r[TR][LDR];
+    __shared__ float h2r[TR][LDR];
+    __shared__ float da2r[TR][LDR];
+    __shared__ float da1r[TR][LDR];
+    __shared__ float do_s[TR][M_MAX];
+    const HalfW &X = T.half[blockIdx.x];
+    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D;
+    const int DI = X.Dh + Q.C, M = 2 * X.Dt;
     f32x16 dW2;
 #pragma unroll
     for (int q = 0; q < 16; ++q) dW2[q] = 0.0f;
@@ -254,40 +381,30 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
     for (int q = 0; q < DI_MAX / 8; ++q) dW1[q] = 0.0f;
 #pragma unroll
     for (int q = 0; q < M_MAX / 8; ++q) dW3[q] = 0.0f;
-
-    for (int r0 = 0; r0 < A.R; r0 += TR) {
+    for (int r0 = 0; r0 < Q.R; r0 += TR) {
         if (r0) __syncthreads();          // the previous tile's readers are done
         for (int p = t; p < TR * DI; p += NTB) {
             const int r = p / DI, c = p - r * DI, row = r0 + r;
             float v = 0.0f;
-            if (row < A.R) v = c < A.Dh ? A.xh[(long long)row * A.ldh + c] : A.cond[(long long)row * A.C + (c - A.Dh)];
+            if (row < Q.R) v = c < X.Dh ? X.xh[(long long)row * D + c] : cond[(long long)row * Q.C + (c - X.Dh)];
             in_s[r][c] = v;
         }
 #pragma unroll
-        for (int k = 0; k < TR * H / NTB; ++k) {         // saved activations (rows beyond R: zero)
+        for (int k = 0; k < TR * H / NTB; ++k) {         // (rows beyond R: zero)
             const int r = g + 8 * k, row = r0 + r;
-            h1r[r][j] = row < A.R ? h1_in[(long long)row * H + j] : 0.0f;
-            h2r[r][j] = row < A.R ? h2_in[(long long)row * H + j] : 0.0f;
+            const bool ok = row < Q.R;
+            const long long o = (long long)row * H + j;
+            h1r[r][j] = ok ? X.h1[o] : 0.0f;
+            h2r[r][j] = ok ? X.h2[o] : 0.0f;
+            da2r[r][j] = ok ? X.da2[o] : 0.0f;
+            da1r[r][j] = ok ? X.da1[o] : 0.0f;
         }
-        for (int p = t; p < TR * A.Dt; p += NTB) {       // through the affine transform and the soft clamp
-            const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
-            float d_os = 0.0f, d_t = 0.0f;
-            if (row < A.R) {
-                const float s = I.s[(long long)row * I.lds + d], es = expf(s);
-                float gg = I.gy[(long long)row * I.ldgy + d];
-                if (I.gy2) gg += I.gy2[(long long)row * I.ldgy2 + d];
-                const float d_sc = fmaf(gg * A.xtr[(long long)row * A.ldt + d], es, I.gs[row]);
-                const float u = s / A.clamp;
-                d_os = d_sc * (1.0f - u * u);
-                d_t = gg;
-                O.gxtr[(long long)row * O.ldgt + d] = gg * es;
-            }
-            do_s[r][d] = d_os;
-            do_s[r][A.Dt + d] = d_t;
+        for (int p = t; p < TR * M_MAX; p += NTB) {
+            const int r = p / M_MAX, m = p - r * M_MAX, row = r0 + r;
+            do_s[r][m] = (row < Q.R && m < M) ? X.dos[(long long)row * M_MAX + m] : 0.0f;
         }
         __syncthreads();
-        STAMP(11);
-        // layer 3 weight gradient: thread (column j, rows m = g, g + 8)
+        // layer 3: thread (column j, rows m = g, g + 8)
 #pragma unroll
         for (int q = 0; q < M_MAX / 8; ++q) {
             const int m = 8 * q + g;
@@ -302,21 +419,7 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
 #pragma unroll 4
             for (int r = 0; r < TR; ++r) db3 += do_s[r][t];
         }
-        // d h2 -> d(pre-activation 2): thread (unit j, rows 4 g .. 4 g + 3)
-        {
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
-            for (int m = 0; m < M; ++m) {
-                const float w = w3s[m][j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, do_s[4 * g + q][m], acc[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) da2r[4 * g + q][j] = acc[q] * elu_grad_from_out(h2r[4 * g + q][j]);
-        }
-        __syncthreads();
-        STAMP(12);
-        {   // layer 2 weight gradient, dW2[jo][i] += sum_r da2[r][jo] h1[r][i].  Lane l: A[jo = l & 31][k = l >> 5], B[k][i = l & 31];
+        {   // layer 2, dW2[jo][i] += sum_r da2[r][jo] h1[r][i].  Lane l: A[jo = l & 31][k = l >> 5], B[k][i = l & 31];
             // the sum's order is free, so step s takes rows r = 16 k + s (A and B alike)
             const int m = lane & 31, kk = lane >> 5;
             const float *ap = &da2r[16 * kk][32 * (wave >> 2) + m], *bp = &h1r[16 * kk][32 * (wave & 3) + m];
@@ -327,77 +430,56 @@ __device__ __forceinline__ void coupling_bwd_body(const Args &A, const BwdIn &I,
 #pragma unroll 8
             for (int r = 0; r < TR; ++r) db2 += da2r[r][t];
         }
-        float da1[4];
-        {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k = l >> 4] = da2[row][4 s + k], B[k][i = l & 15] = W2[4 s + k][i]
-            const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float *ap = &da2r[16 * rb + n][kk], *bp = &w2s[kk][16 * ib + n];
-#pragma unroll 8
-            for (int s4 = 0; s4 < H; s4 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4], bp[s4 * LDW2], acc, 0, 0, 0);
-            // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register
-#pragma unroll
-            for (int q = 0; q < 4; ++q) da1[q] = acc[q] * elu_grad_from_out(h1r[16 * rb + 4 * kk + q][16 * ib + n]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) h2r[16 * rb + 4 * kk + q][16 * ib + n] = da1[q];     // (h2r's readers finished before the barrier above)
-        }
-        __syncthreads();
-        STAMP(13);
-        // layer 1 weight gradient: thread (row j, columns c = g, g + 8, ...)
+        // layer 1: thread (row j, columns c = g, g + 8, ...)
 #pragma unroll
         for (int q = 0; q < DI_MAX / 8; ++q) {
             const int c = 8 * q + g;
             if (c < DI) {
                 float acc = dW1[q];
 #pragma unroll 8
-                for (int r = 0; r < TR; ++r) acc = fmaf(h2r[r][j], in_s[r][c], acc);
+                for (int r = 0; r < TR; ++r) acc = fmaf(da1r[r][j], in_s[r][c], acc);
                 dW1[q] = acc;
             }
         }
-        STAMP(131);
         if (g == 0) {
 #pragma unroll 8
-            for (int r = 0; r < TR; ++r) db1 += h2r[r][j];
+            for (int r = 0; r < TR; ++r) db1 += da1r[r][j];
         }
-        STAMP(132);
-        // d in: (row, column) pairs, `parts` adjacent lanes each (a power of two: every thread busy for 512 pairs or fewer)
-        {
-            const int npairs = TR * DI, parts = npairs <= NTB / 4 ? 4 : (npairs <= NTB / 2 ? 2 : 1), span = H / parts;
-            const int pr = t / parts, part = t - pr * parts;
-            const int r = pr / DI, c = pr - r * DI, row = r0 + r;
-            float acc = 0.0f;
-            if (pr < npairs) {
-#pragma unroll 8
-                for (int jj = part * span; jj < (part + 1) * span; ++jj) acc = fmaf(w1s[jj][c], h2r[r][jj], acc);
-            }
-            STAMP(133);
-            if (parts >= 2) acc += __shfl_xor(acc, 1);
-            if (parts >= 4) acc += __shfl_xor(acc, 2);
-            if (pr < npairs && part == 0 && row < A.R) {
-                if (c < A.Dh) {
-                    float *o = &O.gxh[(long long)row * O.ldgh + c];
-                    *o = O.acc_gxh ? *o + acc : acc;
-                } else {
-                    float *o = &O.gcond[(long long)row * A.C + (c - A.Dh)];
-                    *o = O.acc_gcond ? *o + acc : acc;
-                }
-            }
-        }
-        STAMP(14);
     }
     {   // dW2's tile: register v of lane l is row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31
         const int m = lane & 31, kk = lane >> 5;
-        float *o = O.gW2 + (long long)(32 * (wave >> 2) + 4 * kk) * H + 32 * (wave & 3) + m;
+        float *o = X.gW2 + (long long)(32 * (wave >> 2) + 4 * kk) * H + 32 * (wave & 3) + m;
 #pragma unroll
         for (int v = 0; v < 16; ++v) o[((v & 3) + 8 * (v >> 2)) * H] = dW2[v];
     }
 #pragma unroll
-    for (int q = 0; q < DI_MAX / 8; ++q) { const int c = 8 * q + g; if (c < DI) O.gW1[j * DI + c] = dW1[q]; }
+    for (int q = 0; q < DI_MAX / 8; ++q) { const int c = 8 * q + g; if (c < DI) X.gW1[j * DI + c] = dW1[q]; }
 #pragma unroll
-    for (int q = 0; q < M_MAX / 8; ++q) { const int m = 8 * q + g; if (m < M) O.gW3[(long long)m * H + j] = dW3[q]; }
-    if (t < H) O.gb2[t] = db2;
-    if (g == 0) O.gb1[j] = db1;
-    if (t < M) O.gb3[t] = db3;
-    STAMP(15);
+    for (int q = 0; q < M_MAX / 8; ++q) { const int m = 8 * q + g; if (m < M) X.gW3[(long long)m * H + j] = dW3[q]; }
+    if (t < H) X.gb2[t] = db2;
+    if (g == 0) X.gb1[j] = db1;
+    if (t < M) X.gb3[t] = db3;
+    if (X.norm < 0) return;
+    // the ActNorm's parameters: 32 threads per column, fixed order
+    const NormW &N = T.norm[X.norm];
+    if (t < 32 * D) {
+        const int c = t >> 5, i = t & 31, p = N.perm[c];
+        const float ex = expf(N.scale[p]);
+        float sb = 0.0f, ss = 0.0f, sd = 0.0f;
+        for (int row = i; row < Q.R; row += 32) {
+            const float gv = N.gz[(long long)row * D + c];
+            sb += gv;
+            ss = fmaf(gv * ex, N.x[(long long)row * D + p], ss);
+            sd += g_ld[row];
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+            sb += __shfl_xor(sb, m, 32);
+            ss += __shfl_xor(ss, m, 32);
+            sd += __shfl_xor(sd, m, 32);
+        }
+        if (i == 0) { N.gbias[p] = sb; N.gscale[p] = ss + sd; }
+    }
 }
 
 // mean over the rows of |z|^2 / 2 - log|det| (fixed summation order)
@@ -417,65 +499,6 @@ __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *l
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = red[0] / (float)R;
-}
-
-// ---- the whole flow backward: one workgroup of 1024 threads, half-layers last to first.  The host resolves every half-layer's
-// pointers into a table in the kernel arguments (the loop body then reads its operands like a one-half-layer kernel would).
-struct HalfB {
-    const float *xh, *xtr, *W1, *W2, *W3, *s, *h1, *h2, *gy, *gy2;
-    float *gxh, *gxtr, *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;
-    int Dh, Dt, ldgh, acc_gxh, acc_gcond, norm;          // norm: the layer's ActNorm / permutation backward follows (-1: no)
-};
-struct NormB { const float *x, *scale; float *gscale, *gbias; unsigned char perm[D_MAX]; };
-struct FlowB { HalfB half[2 * L_MAX]; NormB norm[L_MAX]; };
-struct FlowBwdBuf {
-    const float *g_ld;             // [R] gradient of the flow's log|det|
-    const float *gz;               // [R, D] scratch the half-layers write: gradient of a layer's permuted ActNorm output
-    float *gx;                     // [R, D]: gradient of a layer's input; after layer 0, of theta
-    float *gcond;                  // [R, C]
-    const float *g_nll;            // not null: the gradient of the mean negative log-likelihood (a scalar); the kernel then WRITES
-    float *w_gz, *w_gld;           // the gradients of z and log|det| it reads -- z g / R and -g / R -- from the forward's z
-    const float *z_last;
-};
-__global__ __launch_bounds__(NTB) void flow_bwd_kernel(FlowDims Q, FlowB T, const float *cond, FlowBwdBuf U)
-{
-    const int t = threadIdx.x, D = Q.D;
-    if (U.g_nll) {                                           // (the first half-layer starts with a barrier)
-        const float sc = *U.g_nll / (float)Q.R;
-        for (int i = t; i < Q.R * D; i += NTB) U.w_gz[i] = U.z_last[i] * sc;
-        for (int r = t; r < Q.R; r += NTB) U.w_gld[r] = -sc;
-    }
-    for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
-        const HalfB &X = T.half[hl];
-        const Args A = {X.xh, D, X.Dh, cond, Q.C, X.xtr, D, X.Dt, X.W1, nullptr, X.W2, nullptr, X.W3, nullptr, Q.clamp, Q.R};
-        const BwdIn I = {X.s, D, X.gy, D, X.gy2, D - Q.d1, U.g_ld};
-        const BwdOut O = {X.gxh, X.ldgh, U.gcond, X.gxtr, D, X.gW1, X.gb1, X.gW2, X.gb2, X.gW3, X.gb3, X.acc_gxh, X.acc_gcond};
-        coupling_bwd_body(A, I, X.h1, X.h2, O);
-        if (X.norm < 0) continue;
-        __syncthreads();
-        // back through the permutation and the ActNorm: 32 threads per column
-        const NormB &N = T.norm[X.norm];
-        if (t < 32 * D) {
-            const int c = t >> 5, i = t & 31, p = N.perm[c];
-            const float ex = expf(N.scale[p]);
-            float sb = 0.0f, ss = 0.0f, sd = 0.0f;
-            for (int row = i; row < Q.R; row += 32) {
-                const float g = U.gz[(long long)row * D + c], gxv = g * ex;
-                U.gx[(long long)row * D + p] = gxv;
-                sb += g;
-                ss = fmaf(gxv, N.x[(long long)row * D + p], ss);
-                sd += U.g_ld[row];
-            }
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) {
-                sb += __shfl_xor(sb, m, 32);
-                ss += __shfl_xor(ss, m, 32);
-                sd += __shfl_xor(sd, m, 32);
-            }
-            if (i == 0) { N.gbias[p] = sb; N.gscale[p] = ss + sd; }
-        }
-        // (the next half-layer's first tile starts with a barrier: U.gx is visible by then)
-    }
 }
 
 }  // namespace nddm_train
@@ -525,35 +548,43 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
 
 /* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results -- or, with
  * g_nll (the gradient of the forward's nll, a device scalar) not NULL, scratch of those sizes that the kernel fills itself.
- * gz [R, D] and gy2 [R, D - d1] are scratch; gx [R, D] ends as the gradient of theta, gcond [R, C] as that of the condition. */
+ * Scratch: gz_all [L, R, D], gy2 [R, D - d1], work [2 L, R, 2 * 128 + 16].  gx [R, D] ends as the gradient of theta, gcond [R, C]
+ * as that of the condition. */
 int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         void *const *grads, const float *theta, const float *cond, float *z_all, float *out_all, float *s_all,
-                        float *h_all, float *g_z, float *g_ld, const float *g_nll, float *gz, float *gy2, float *gx, float *gcond,
-                        void *stream)
+                        float *h_all, float *g_z, float *g_ld, const float *g_nll, float *gz_all, float *gy2, float *gx, float *gcond,
+                        float *work, void *stream)
 {
     if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
     for (int i = 0; i < L * D; ++i) if (perm[i] < 0 || perm[i] >= D) return 1;
     const int d2 = D - d1;
-    const long long RD = (long long)R * D, RH = (long long)R * H;
-    FlowB T = {};
+    const long long RD = (long long)R * D, RH = (long long)R * H, RW = (long long)R * (2 * H + M_MAX);
+    FlowD TD = {};
+    FlowW TW = {};
     for (int l = 0; l < L; ++l) {
         const float *const *q = reinterpret_cast<const float *const *>(params) + 14 * l;
         float *const *g = reinterpret_cast<float *const *>(grads) + 14 * l;
         const float *x = l ? out_all + (l - 1) * RD : theta;
         const float *z = z_all + l * RD, *out = out_all + l * RD, *sl = s_all + l * RD, *h = h_all + 4 * l * RH;
         const float *g_out = l == L - 1 ? g_z : gx;
+        float *gz = gz_all + l * RD, *wa = work + (2 * l) * RW, *wb = work + (2 * l + 1) * RW;
         // sub-network 2 (runs first): d out[:, :d1] -> d z[:, :d1] (written), d out[:, d1:] through its input (gy2), d cond
-        T.half[2 * l + 1] = {out + d1, z, q[8], q[10], q[12], sl + d2, h + 2 * RH, h + 3 * RH, g_out, nullptr,
-                             gy2, gz, g[8], g[9], g[10], g[11], g[12], g[13], d2, d1, d2, 0, l != L - 1, -1};
+        TD.half[2 * l + 1] = {z, q[8], q[10], q[12], sl + d2, h + 2 * RH, h + 3 * RH, g_out, nullptr,
+                              gy2, gz, wb, wb + RH, wb + 2 * RH, d2, d1, d2, 0, l != L - 1, -1};
+        TW.half[2 * l + 1] = {out + d1, h + 2 * RH, h + 3 * RH, wb, wb + RH, wb + 2 * RH, g[8], g[9], g[10], g[11], g[12], g[13], d2, d1, -1, 0};
         // sub-network 1: d out[:, d1:] + gy2 -> d z[:, d1:] (written), d z[:, :d1] and d cond (accumulated)
-        T.half[2 * l] = {z, z + d1, q[2], q[4], q[6], sl, h, h + RH, g_out + d1, gy2,
-                         gz, gz + d1, g[2], g[3], g[4], g[5], g[6], g[7], d1, d2, D, 1, 1, l};
-        T.norm[l] = {x, q[0], g[0], g[1], {}};
-        for (int d = 0; d < D; ++d) T.norm[l].perm[d] = (unsigned char)perm[l * D + d];
+        TD.half[2 * l] = {z + d1, q[2], q[4], q[6], sl, h, h + RH, g_out + d1, gy2,
+                          gz, gz + d1, wa, wa + RH, wa + 2 * RH, d1, d2, D, 1, 1, l};
+        TW.half[2 * l] = {z, h, h + RH, wa, wa + RH, wa + 2 * RH, g[2], g[3], g[4], g[5], g[6], g[7], d1, d2, l, 0};
+        TD.norm[l] = {q[0], gz, {}};
+        TW.norm[l] = {x, q[0], gz, g[0], g[1], {}};
+        for (int d = 0; d < D; ++d) TD.norm[l].perm[d] = TW.norm[l].perm[d] = (unsigned char)perm[l * D + d];
     }
     const FlowDims Q = {L, R, D, d1, C, clamp};
-    const FlowBwdBuf U = {g_ld, gz, gx, gcond, g_nll, g_z, g_ld, out_all + (long long)(L - 1) * RD};
-    hipLaunchKernelGGL(flow_bwd_kernel, dim3(1), dim3(NTB), 0, reinterpret_cast<hipStream_t>(stream), Q, T, cond, U);
+    const FlowBwdBuf U = {g_ld, gx, gcond, g_nll, g_z, g_ld, out_all + (long long)(L - 1) * RD};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(flow_dgrad_kernel, dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
+    hipLaunchKernelGGL(flow_wgrad_kernel, dim3(2 * L), dim3(NTB), 0, st, Q, TW, cond, static_cast<const float *>(g_ld));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

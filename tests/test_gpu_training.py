@@ -212,7 +212,7 @@ def test_fused_flow_equals_the_pytorch_path():
     from bayesflow_nddms_amd.amortizer import InvertibleNetwork
     assert _train_lib.lib() is not None, "libnddm_train.so did not build / load"
     torch.manual_seed(3)
-    for layers, R, D in ((1, 32, 5), (1, 5, 5), (2, 77, 5), (6, 128, 5), (6, 32, 8), (3, 40, 2)):
+    for layers, R, D in ((1, 32, 5), (1, 5, 5), (2, 77, 5), (6, 256, 5), (6, 32, 8), (3, 40, 2)):
         net = InvertibleNetwork(num_params=D, num_coupling_layers=layers, seed=layers).cuda()
         with torch.no_grad():
             for p in net.parameters():                   # larger weights than the initialisation, ActNorms away from identity
@@ -242,8 +242,6 @@ def test_fused_flow_equals_the_pytorch_path():
             assert float((a - b).abs().max()) <= 5e-5 * mag + 1e-6, ("nll", layers, R, D, k, float((a - b).abs().max()), mag)
         x = net.inverse(res[True][0], cond.detach())     # and the (PyTorch) inverse undoes the fused forward
         assert torch.allclose(x, theta.detach(), atol=2e-3), float((x - theta).abs().max())
-    net = InvertibleNetwork(num_params=5).cuda()                      # more rows than the one-workgroup backward is meant for
-    assert net._fused_lib(torch.randn(129, 5, device="cuda"), torch.randn(129, 11, device="cuda")) is None
     small = InvertibleNetwork(num_params=5, hidden=32).cuda()          # hidden width 32: not covered -> the PyTorch path, silently
     z, ld = small(torch.randn(8, 5, device="cuda"), torch.randn(8, 11, device="cuda"))
     assert z.shape == (8, 5) and ld.shape == (8,)
