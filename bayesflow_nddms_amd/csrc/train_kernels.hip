@@ -26,7 +26,10 @@ constexpr int M_MAX = 16;     // outputs (2 * transformed columns)
 #ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of workgroup 0 (tools/_flow_stamps.py)
 __device__ unsigned long long g_stamps[8192];
 __device__ int g_nstamps;
-#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
+#ifndef NDDM_STAMP_BLOCK
+#define NDDM_STAMP_BLOCK 0
+#endif
+#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == NDDM_STAMP_BLOCK) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
 #else
 #define STAMP(id) do { } while (0)
 #endif
@@ -55,7 +58,7 @@ constexpr int TRF = 8, RPT = TRF / 2;
 constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2 in LDS: the MFMA operand reads (16 lanes down
                                 // a column, 4 lanes along it) then touch every bank exactly twice per wave
 __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, float *y, int ldy, float *s_out, int lds, float *h1_out,
-                                               float *h2_out)
+                                               float *h2_out, float (*s_tile)[M_MAX])
 {
     __shared__ float in_s[TRF][DI_MAX];
     __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TRF..15 stay zero (the MFMA tile has 16 rows)
@@ -148,6 +151,7 @@ __device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, f
         const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
         if (row >= A.R) continue;
         const float s = A.clamp * tanhf(o_s[r][d] / A.clamp);
+        s_tile[r][d] = s;
         s_out[(long long)row * lds + d] = s;
         y[(long long)row * ldy + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
     }
@@ -165,8 +169,11 @@ struct FlowSaved { float *z_all, *out_all, *s_all, *h_all; };    // [L, R, D] pe
                                                                   // log-scales; [L, 4, R, H] activations of the sub-networks
 __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
 {
+    __shared__ float s_tile[TRF][M_MAX];                    // the current half-layer's log-scales (rows beyond R: stale, unused)
+    float ld_acc = 0.0f;                                     // threads t < TRF: log|det| of row r0 + t, summed as the layers go
     const int t = threadIdx.x, r0 = blockIdx.x * TRF, D = Q.D, d1 = Q.d1, d2 = D - d1;
     const long long RD = (long long)Q.R * D, RH = (long long)Q.R * H;
+    STAMP(0);
     for (int hl = 0; hl < 2 * Q.L; ++hl) {                  // half-layers: ONE copy of the tile function's code
         const int l = hl >> 1;
         const bool second = hl & 1;
@@ -181,6 +188,10 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
                     z[(long long)row * D + c] = fmaf(x[(long long)row * D + p], expf(Y.scale[p]), Y.bias[p]);
                 }
             }
+            if (t < TRF) {
+#pragma unroll
+                for (int d = 0; d < D_MAX; ++d) if (d < D) ld_acc += Y.scale[d];
+            }
             __syncthreads();
         }
         // first:  conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s[:, :d2]
@@ -189,15 +200,15 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
         const Args A = {second ? out + d1 : z, D, second ? d2 : d1, cond, Q.C, second ? z : z + d1, D, second ? d1 : d2,
                         W.W1, W.b1, W.W2, W.b2, W.W3, W.b3, Q.clamp, Q.R};
         coupling_fwd_tile(A, r0, second ? out : out + d1, D, second ? sl + d2 : sl, D, h + (second ? 2 : 0) * RH,
-                          h + (second ? 3 : 1) * RH);
+                          h + (second ? 3 : 1) * RH, s_tile);
+        if (t < TRF) {                                       // (the tile function ends with a barrier; the next one's writes to
+            const int Dt = second ? d1 : d2;                 // s_tile come after three more)
+#pragma unroll
+            for (int d = 0; d < M_MAX / 2; ++d) if (d < Dt) ld_acc += s_tile[t][d];
+        }
     }
-    if (t < TRF && r0 + t < Q.R) {                           // log|det| of the row: every log-scale, and the ActNorms'
-        const int row = r0 + t;
-        float acc = 0.0f;
-        for (int l = 0; l < Q.L; ++l)
-            for (int d = 0; d < D; ++d) acc += S.s_all[l * RD + (long long)row * D + d] + P.layer[l].scale[d];
-        ld[row] = acc;
-    }
+    if (t < TRF && r0 + t < Q.R) ld[r0 + t] = ld_acc;
+    STAMP(6);        // log|det| of the row: every log-scale, and the ActNorms'
 }
 
 // ------------------------------------------------------------------------------------------------ backward

@@ -4,6 +4,8 @@ generative model feeding `trainer.train_*(batch_size=32)`) with every iteration 
     device prior -> simulate (HIP kernels, C ABI) -> configurator -> DeepSet + coupling flow forward -> backward
     -> gradient clipping -> Adam (+ cosine learning-rate schedule, + the loss stored into a device buffer)
 
+(at one rank as two graphs on two streams: the simulation of batch i + 1 runs beside the training step on batch i)
+
 The eager loop (amortizer.Trainer) spends ~10 ms of host time per iteration launching ~1000 small kernels and reads the
 loss back every step; the MI355X is busy for a few per cent of it.  Here the host's share of an iteration is: draw the
 batch-shared N (a pure function of (seed, iteration), distributed.shared_prior_N), write it to the device, replay a graph.
@@ -47,10 +49,11 @@ class _Bucket:
 class GraphTrainer:
     def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=16, dt=0.01,
                  max_steps=400.0, seed=2023, learning_rate=5e-4, clip=5.0, device=None, use_graph=True,
-                 world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic"):
+                 world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic", overlap=True):
         """total_steps: length of the cosine schedule and capacity of the loss buffer.  use_graph=False runs the SAME
         iteration eagerly (the comparator of the parity test).  split: force the two-graph form (the one used with a
-        collective in the middle) at world 1."""
+        collective in the middle) at world 1.  overlap (one rank, graphs): batch i + 1 is simulated on a stream of its own
+        while batch i is trained on -- same batches, same order, same result."""
         if parallel not in ("gather", "ddp"):
             raise ValueError("parallel must be 'gather' or 'ddp'")
         torch_ = engine.require_device()
@@ -66,6 +69,7 @@ class GraphTrainer:
         self.use_graph = bool(use_graph)
         self.world, self.rank, self.parallel, self.backend = int(world), int(rank), parallel, backend
         self.split = (self.world > 1) if split is None else bool(split)
+        self.overlap = bool(overlap) and self.use_graph and self.world == 1 and not self.split
         self.iteration = 0
         with torch.cuda.device(self.dev):
             # ONE flat buffer each for the parameters (the modules' tensors become views of it), the gradients (+ 1 slot that
@@ -119,6 +123,7 @@ class GraphTrainer:
         # gradient-accumulation nodes remember the stream they were first used on, and capture needs a non-default one
         self._stream = torch.cuda.Stream(device=self.dev)
         self._comm = torch.cuda.Stream(device=self.dev)
+        self._sim_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
         self._closed = False
 
@@ -229,6 +234,8 @@ class GraphTrainer:
                 bk.g_params = torch.empty((self.world, self.B, self.P), dtype=torch.float32, device=self.dev)
                 bk.g_trials = torch.empty((self.world, self.B, n_top, 2), dtype=torch.float32, device=self.dev)
                 bk.t_params, bk.t_trials = bk.g_params.view(-1, self.P), bk.g_trials.view(-1, n_top, 2)
+            elif self.overlap:                      # the simulator refills params / trials while these are trained on
+                bk.t_params, bk.t_trials = torch.empty_like(bk.params), torch.empty_like(bk.trials)
             else:
                 bk.t_params, bk.t_trials = bk.params, bk.trials
             bk.r_params = bk.r_trials = None          # staging of a replayed batch: allocated by the first replay iteration
@@ -236,15 +243,18 @@ class GraphTrainer:
         self._buckets[n_top] = bk
         return bk
 
-    def _run(self, bk, key, fn):
+    def _run(self, bk, key, fn, stream=None):
         """One graph-able stretch of the iteration on one bucket: captured at its first use -- after one eager pass at this
         shape (GEMM heuristics, workspaces, autograd buffers) whose every effect on the trainer's state is rolled back, so
         that capturing does not cost an iteration -- and replayed from then on."""
         if not self.use_graph:
             fn()
             return
+        stream = stream or self._stream             # (the caller has made it the current stream)
         g = bk.graphs.get(key)
         if g is None:
+            if self.overlap:
+                torch.cuda.synchronize(self.dev)    # the other stream's work in flight must not see the warm-up pass's state
             with torch.no_grad():
                 snap = [t.clone() for t in self._mutable()]
             fn()
@@ -255,7 +265,7 @@ class GraphTrainer:
             g = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
             # default (global) capture mode turns into an error that kills the process
-            with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self._pool, stream=stream, capture_error_mode="thread_local"):
                 fn()
             bk.graphs[key] = g
         g.replay()
@@ -290,7 +300,65 @@ class GraphTrainer:
         self._run(bk, "sim", sim)
         if gather:
             self._on_comm_stream(lambda: self._gather(bk))
-        entry = (bk.t_params.clone(), bk.t_trials.clone(), n)
+        bt = self._replay_stage((bk.t_params.clone(), bk.t_trials.clone(), n), replay)
+        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
+        up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
+        if coll and ddp:
+            self._run(bt, "r:fb", fb)
+            self._on_comm_stream(self._all_reduce_gradients)
+            self._run(bt, "up", up)
+        else:
+            self._run(bt, "r:fb+up", lambda: (fb(), up()))
+
+    def _train_overlapped(self, iterations, replay):
+        """One rank, graphs: the simulator runs one batch AHEAD on its own stream -- `sim` graph of batch i + 1 | training graph
+        of batch i side by side (the simulate launch is a few dozen waves for 30-200 microseconds: alone on the chip it is
+        pure latency) -- within this call only: nothing is simulated beyond the last iteration, so the random stream's
+        position after the call is what the sequential loop leaves."""
+        T, S = self._stream, self._sim_stream
+        cur = torch.cuda.current_stream(self.dev)
+        T.wait_stream(cur)
+        S.wait_stream(T)
+        ns = [shared_prior_N(self.seed, self.iteration + k, self.n_min, self.n_max) for k in range(int(iterations))]
+        up = lambda: self._update(1.0)
+
+        def simulate(n):
+            bk = self._bucket(self.bucket_top(n))
+            with torch.cuda.stream(S):
+                self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
+                ev = torch.cuda.Event()
+                ev.record(S)
+            return ev
+
+        with torch.cuda.device(self.dev):
+            ev = simulate(ns[0]) if ns else None
+            for k, n in enumerate(ns):
+                bk = self._bucket(self.bucket_top(n))
+                with torch.cuda.stream(T):
+                    T.wait_event(ev)
+                    if replay is None:
+                        bk.t_params.copy_(bk.params); bk.t_trials.copy_(bk.trials)
+                    else:
+                        entry = (bk.params.clone(), bk.trials.clone(), n)
+                    taken = torch.cuda.Event()
+                    taken.record(T)
+                if k + 1 < len(ns):
+                    S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers
+                    ev = simulate(ns[k + 1])
+                with torch.cuda.stream(T):
+                    if replay is None:
+                        self.n_f.fill_(float(n))
+                        self._run(bk, "fb+up", lambda: (self._forward_backward(bk.t_params, bk.t_trials), up()))
+                    else:
+                        bt = self._replay_stage(entry, replay)
+                        self._run(bt, "r:fb+up", lambda: (self._forward_backward(bt.r_params, bt.r_trials), up()))
+                self.iteration += 1
+        cur.wait_stream(T)
+        cur.wait_stream(S)
+
+    def _replay_stage(self, entry, replay):
+        """Experience replay's host side: the fresh batch into the buffer (overwriting a random slot once it is full), a stored
+        batch drawn at random into ITS bucket's staging tensors, with ITS N (-> that bucket)."""
         ring, rng, cap = replay
         if len(ring) < cap:
             ring.append(entry)
@@ -302,17 +370,12 @@ class GraphTrainer:
             bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
         bt.r_params.copy_(p_s); bt.r_trials.copy_(t_s)
         self.n_f.fill_(float(n_s))
-        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
-        up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
-        if coll and ddp:
-            self._run(bt, "r:fb", fb)
-            self._on_comm_stream(self._all_reduce_gradients)
-            self._run(bt, "up", up)
-        else:
-            self._run(bt, "r:fb+up", lambda: (fb(), up()))
+        return bt
 
     def train_online(self, iterations):
         """`iterations` training steps, every batch fresh; returns nothing -- losses stay on the device until loss_history()."""
+        if self.overlap:
+            return self._train_overlapped(iterations, None)
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
             for _ in range(int(iterations)):
@@ -327,6 +390,8 @@ class GraphTrainer:
         import numpy as np
         if self._replay is None:
             self._replay = ([], np.random.default_rng(replay_seed), int(capacity_in_batches))
+        if self.overlap:
+            return self._train_overlapped(iterations, self._replay)
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
             for _ in range(int(iterations)):

@@ -61,7 +61,8 @@ def test_prefetched_online_training_sees_the_same_batches():
 
 def test_graph_trainer_equals_the_eager_iteration_and_tracks_the_classic_loop():
     """graph_trainer.GraphTrainer: every iteration one hipGraph replay (device prior -> simulate -> forward -> backward ->
-    clip -> Adam; one graph per n_trials bucket).  For fixed seeds its loss history equals (1e-4) the SAME iteration run
+    clip -> Adam; one graph per n_trials bucket) -- or, the default at one rank, two on two streams (the next batch is simulated
+    beside the training step).  For fixed seeds its loss history equals (1e-4) the SAME iteration run
     eagerly, in the single-graph form and in the two-graph form used with a collective in between; the classic eager
     Trainer fed the same batches unpadded (exact N instead of bucket top + mask) gives the same curve to 2e-3; the losses
     go down; and the library memory behind the captured launches is released when the trainer closes."""
@@ -80,12 +81,14 @@ def test_graph_trainer_equals_the_eager_iteration_and_tracks_the_classic_loop():
             gt.train_online(iters)
             return gt.loss_history(), gt.n_graphs
 
-    h_graph, n_graphs = run(use_graph=True)
+    h_graph, n_graphs = run(use_graph=True, overlap=False)
     h_split, n_split = run(use_graph=True, split=True)
+    h_ahead, n_ahead = run(use_graph=True)             # the default: simulate graph of batch i + 1 beside the training graph of i
     h_eager, _ = run(use_graph=False)
-    assert len(h_graph) == iters and n_graphs >= 5 and n_split == 2 * n_graphs      # several N buckets were hit
+    assert len(h_graph) == iters and n_graphs >= 5 and n_split == 2 * n_graphs == n_ahead      # several N buckets were hit
     assert np.allclose(h_graph, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h_graph) - np.array(h_eager)).max()
     assert np.allclose(h_split, h_eager, rtol=1e-4, atol=1e-4)
+    assert np.allclose(h_ahead, h_eager, rtol=1e-4, atol=1e-4)
     assert np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
     # the classic loop on the same batches: same prior rows, same simulator stream, exact N
     prior, step = DevicePrior("basic", seed=2023), {"i": 0}
