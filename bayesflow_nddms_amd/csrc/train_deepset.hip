@@ -24,10 +24,13 @@ constexpr int NT = 256;       // threads per workgroup: wave w owns the 32 x 32 
 constexpr int DS_MAX = 4;     // a "small" input (the raw trials: rt, choice) goes through layer 1 as plain FMAs
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of workgroup 0 (tools/_flow_stamps.py)
+#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of one workgroup (tools/train_stamps.py)
 __device__ unsigned long long g_stamps[8192];
 __device__ int g_nstamps;
-#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
+#ifndef NDDM_STAMP_BLOCK
+#define NDDM_STAMP_BLOCK 0
+#endif
+#define STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == NDDM_STAMP_BLOCK) { int k_ = g_nstamps++; if (k_ < 4096) { g_stamps[2 * k_] = (id); g_stamps[2 * k_ + 1] = wall_clock64(); } } } while (0)
 #else
 #define STAMP(id) do { } while (0)
 #endif

@@ -1,18 +1,20 @@
 // train_kernels.hip -- the amortizer's conditional normalising flow (bayesflow_nddms_amd/amortizer.py::InvertibleNetwork; the
-// stand-in for bf.networks.InvertibleNetwork, basic_ddm_dc.py:163-165) as ONE kernel forward and ONE backward, for the batch
+// stand-in for bf.networks.InvertibleNetwork, basic_ddm_dc.py:163-165) as ONE kernel forward and TWO backward, for the batch
 // sizes of the online-training loop (32 sets per rank: basic_ddm_dc.py:199-202): per layer an ActNorm, a fixed permutation and
-// two conditional affine-coupling half-layers.
+// two conditional affine-coupling half-layers, and (optionally) the maximum-likelihood loss on top.
 //
-// At batch 32 the flow is ~400 of the ~650 kernels of a graph-replayed training iteration, each a 3-5 microsecond launch that
+// At batch 32 the flow was ~400 of the ~650 kernels of a graph-replayed training iteration, each a 3-5 microsecond launch that
 // touches a few kilobytes: concatenate, three GEMMs of 32 rows, two ELUs, the soft clamp, exp, multiply-add, and twice that
-// backward -- 33 launches per half-layer, twelve half-layers.  Here a half-layer is one device function each way, and the
-// kernels walk the layers (rows are independent forward; backward one workgroup owns every row, so the weight gradients are
-// plain register sums); everything between the layers (slices, concatenations, ActNorm, permutation) is index arithmetic:
+// backward -- 33 launches per half-layer, twelve half-layers.  Here a half-layer is a loop body, the kernels walk the layers
+// (every row is independent but for the weight gradients), and everything between the layers (slices, concatenations,
+// ActNorm, permutation) is index arithmetic:
 //     in = [x_h | cond]  ->  h1 = elu(W1 in + b1)  ->  h2 = elu(W2 h1 + b2)  ->  (o_s | o_t) = W3 h2 + b3
 //     s = clamp * tanh(o_s / clamp),   y = x_tr * exp(s) + o_t                      (returns y and s; log|det| = sum of s)
-// Not MFMA work: 32 x 128 x 128 multiply-adds per GEMM is a microsecond of plain FMAs; what is bought is launches.
+// What is bought is launches and latency, not arithmetic: the kernels are chains of small dependent phases on one or a few
+// CUs, so weights are staged in LDS with coalesced loads once per half-layer and the 32 x 128 x 128 products are f32 MFMAs
+// (v_mfma_f32_16x16x4_f32 / 32x32x2: exact f32) on LDS operands -- as register-blocked FMAs their LDS reads were the time.
 // Hidden width 128 (the networks' default), at most 32 inputs and 8 transformed columns; everything else takes the PyTorch path.
-// gfx950 only.  Test infrastructure compares both paths (tests/test_gpu_training.py).
+// gfx950 only.  tests/test_gpu_training.py compares with the PyTorch composition.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,7 +25,7 @@ constexpr int TR = 32;        // rows per tile
 constexpr int DI_MAX = 32;    // inputs of the sub-network (x_h columns + condition columns)
 constexpr int M_MAX = 16;     // outputs (2 * transformed columns)
 
-#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of workgroup 0 (tools/_flow_stamps.py)
+#ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of one workgroup (tools/train_stamps.py)
 __device__ unsigned long long g_stamps[8192];
 __device__ int g_nstamps;
 #ifndef NDDM_STAMP_BLOCK

@@ -298,3 +298,21 @@ def test_graph_trainer_buckets_and_masked_pooling_equal_the_unpadded_batch():
     x_pad = x.clone()
     x_pad[:, n:] = 1e3 * torch.randn(5, 91 - n, 2)                      # whatever the padding holds
     assert torch.allclose(net(x_pad, mask, torch.tensor(1.0 / n)), net(x[:, :n]), atol=2e-5)
+
+
+def test_training_library_builds_and_exports_its_entry_points():
+    """libnddm_train.so (the amortizer's flow, summary-network and optimizer kernels: csrc/train_*.hip) cross-compiles for
+    gfx950 without a GPU, loads, and exports what _train_lib binds; the shape predicates answer on the host."""
+    import ctypes
+    from bayesflow_nddms_amd import build
+    L = ctypes.CDLL(build.build_train())
+    for name in ("nddm_train_flow_supported", "nddm_train_flow_fwd", "nddm_train_flow_bwd", "nddm_deepset_supported",
+                 "nddm_deepset_mlp_fwd", "nddm_deepset_mlp_bwd", "nddm_deepset_pool_finalize", "nddm_deepset_reduce",
+                 "nddm_train_adam_step"):
+        assert hasattr(L, name), name
+    L.nddm_train_flow_supported.argtypes = [ctypes.c_int] * 5
+    assert L.nddm_train_flow_supported(128, 6, 5, 2, 11) == 1          # the reference's network: 6 layers, 5 parameters, 10 + 1 conditions
+    assert L.nddm_train_flow_supported(64, 6, 5, 2, 11) == 0 and L.nddm_train_flow_supported(128, 9, 5, 2, 11) == 0
+    L.nddm_deepset_supported.argtypes = [ctypes.c_int] * 2
+    assert L.nddm_deepset_supported(64, 2) == 1 and L.nddm_deepset_supported(64, 64) == 1 and L.nddm_deepset_supported(64, 7) == 0
+    assert build.train_source_hash() == open(build.TRAIN_SO_PATH + ".srchash").read().strip()
