@@ -338,7 +338,21 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed,
             "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
 
 
+_JSON_OUT = None      # the process's real standard output, kept for the ONE JSON line
+
+
+def emit(obj):
+    print(json.dumps(obj), file=_JSON_OUT or sys.stdout, flush=True)
+
+
 def worker(a):
+    # libraries write to file descriptor 1 too (RCCL prints a five-line version banner there when its first communicator
+    # comes up): everything but the JSON line goes to standard error, so standard output carries exactly one line
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -615,7 +629,7 @@ def simulate_bench(a, ctx):
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, p_host, a.model, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
-    print(json.dumps(res), flush=True)
+    emit(res)
 
 
 # --------------------------------------------------------------------------------------------------- config 5
@@ -794,7 +808,7 @@ def train_bench(a, ctx):
                    f"(each trains the same {Bl * world} sets)")
         else:
             par = f"dp{world}: simulation AND training sharded ({Bl} sets per rank), flat gradient all-reduce"
-        print(json.dumps({
+        emit({
             "metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE config 5)",
             "value": ref["iterations_per_s"], "unit": "iterations/s", "n_gpus": world, "steps": a.train_iters, "warmup": warm,
             "ms_per_step": ref["ms_per_iteration"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -805,7 +819,7 @@ def train_bench(a, ctx):
                        "arithmetic": ARITHMETIC, "parallelism": par, "backend": a.backend,
                        "train_mode": a.train_mode},
             "loss_first10": ref["loss_first10"], "loss_last10": ref["loss_last10"],
-            "train": results}), flush=True)
+            "train": results})
 
 
 def main():

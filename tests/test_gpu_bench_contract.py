@@ -68,9 +68,11 @@ def test_bench_gpus_2_starts_two_ranks(gather):
 
 
 def _one_line(r):
+    """Standard output is EXACTLY the JSON line: what libraries print to file descriptor 1 (RCCL's version banner) is sent to
+    standard error by bench.py."""
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:500]
     return json.loads(lines[0])
 
 

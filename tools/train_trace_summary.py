@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Is the graph-replayed training iteration GPU-bound?  From a rocprofv3 kernel trace of `bench.py --train --train-mode graph`:
-takes the steady-state replays (the last `--iters` iterations' worth of kernels on the trainer's stream before the first
-isolated simulate launches) and reports kernels per iteration, the GPU time they sum to, the wall span they cover and the busy
+takes the steady-state replays (the longest run of regularly spaced optimizer updates, at most `--iters` iterations of it) and reports kernels per iteration, the GPU time they sum to, the wall span they cover and the busy
 fraction; plus the ten kernel names with the largest share.
 
 usage: python tools/train_trace_summary.py <dir with *_kernel_trace.csv> [--iters 150]"""
@@ -21,11 +20,12 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]))
     rows.sort()
-    sims = [i for i, r in enumerate(rows) if "sim_kernel" in r[2]]
-    # iterations = simulator launches; the steady-state block is the longest run of simulator launches with a regular spacing
+    # one marker kernel per training iteration: the optimizer's update (older builds: the simulator launch); the steady-state block
+    # is the longest run of markers with a regular spacing (captures, warm-up passes and the bench's other legs break the rhythm)
+    marker = "adam_kernel" if any("adam_kernel" in r[2] for r in rows) else "sim_kernel"
+    sims = [i for i, r in enumerate(rows) if marker in r[2]]
     gaps = [rows[sims[j + 1]][0] - rows[sims[j]][0] for j in range(len(sims) - 1)]
-    # (training iterations are milliseconds apart; the bench's isolated simulate launches, tens of microseconds)
-    train_gaps = [g for g in gaps if g > 1_000_000]
+    train_gaps = [g for g in gaps if g > 200_000]
     med = sorted(train_gaps)[len(train_gaps) // 2]
     best, cur, start = (0, 0), 0, 0
     for j, g in enumerate(gaps):
