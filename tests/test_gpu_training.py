@@ -334,3 +334,37 @@ def test_flat_adam_step_equals_pytorch():
     assert L.nddm_train_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n + 1, partial.data_ptr(), 1.0, clip, lr0, 1.0,
                                   0.9, 0.999, 1e-8, step_i.data_ptr(), step_f.data_ptr(), lr_out.data_ptr(), loss_buf.data_ptr(), 4,
                                   g[n:].data_ptr(), None) == 1       # a length that is not a multiple of 4 is refused
+
+
+def test_graph_trainer_without_the_training_library_follows_the_same_curve():
+    """NDDM_NO_FUSED_COUPLING=1: the trainer runs on the pure-PyTorch networks and PyTorch's fused Adam (on the same flat
+    parameter layout) -- the fallback where libnddm_train.so cannot be built -- and its loss curve follows the kernels' curve:
+    an end-to-end cross-check of every hand-written training kernel against PyTorch over 12 optimizer steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = """
+import json, torch
+from bayesflow_nddms_amd import _train_lib
+from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+torch.manual_seed(0)
+am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+with GraphTrainer(am, batch_size=32, total_steps=12, seed=2023, learning_rate=1e-3) as gt:
+    gt.train_online(12)
+    print(json.dumps({"lib": _train_lib.lib() is not None, "loss": gt.loss_history()}))
+"""
+    out = {}
+    for off in (False, True):
+        env = dict(os.environ)
+        env.pop("NDDM_NO_FUSED_COUPLING", None)
+        if off:
+            env["NDDM_NO_FUSED_COUPLING"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[off] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out[False]["lib"] and not out[True]["lib"]
+    a, b = np.array(out[False]["loss"]), np.array(out[True]["loss"])
+    assert len(a) == len(b) == 12 and np.all(np.isfinite(a)) and np.abs(a - b)[:6].max() < 2e-3 and np.abs(a - b).max() < 5e-2, (a, b)
