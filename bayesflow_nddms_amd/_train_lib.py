@@ -33,13 +33,11 @@ def lib():
     L.nddm_train_flow_bwd.restype = i32
     L.nddm_deepset_supported.argtypes = [i32, i32]
     L.nddm_deepset_supported.restype = i32
-    common = [fp, i32, i32, i32, i32, i32, fp, fp, f32, fp, i32, fp, i32, fp, fp, fp, fp, fp, i32, fp, i32]   # x .. S_x (csrc/train_deepset.hip)
+    common = [fp, i32, i32, i32, i32, i32, fp, i32, fp, f32, fp, i32, fp, i32, fp, fp, fp, fp, fp, i32, fp, i32]   # x .. S_x (csrc/train_deepset.hip)
     L.nddm_deepset_mlp_fwd.argtypes = common + [fp, fp, fp, fp, vp]
     L.nddm_deepset_mlp_fwd.restype = i32
     L.nddm_deepset_mlp_bwd.argtypes = common + [fp, fp, fp, fp, i32, fp, i32, fp, i32, fp, fp, i32, vp]
     L.nddm_deepset_mlp_bwd.restype = i32
-    L.nddm_deepset_pool_finalize.argtypes = [fp, i32, i32, fp, f32, fp, vp]
-    L.nddm_deepset_pool_finalize.restype = i32
     L.nddm_deepset_reduce.argtypes = [fp, i32, i32, i32, i32, fp, vp]
     L.nddm_deepset_reduce.restype = i32
     i64 = c.c_longlong

@@ -113,11 +113,20 @@ class InvariantNetwork(nn.Module):
         L = _train_lib.lib()
         return L if L is not None and L.nddm_deepset_supported(64, x.shape[2]) else None
 
-    def forward(self, x, mask=None, inv_n=None):
-        """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors:
-        the pooled means then run over the real trials only, so a batch padded to a fixed length (one hipGraph per length
-        bucket, GraphTrainer) gives what the unpadded batch gives."""
+    def forward(self, x, mask=None, inv_n=None, n_valid=None):
+        """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors -- or
+        n_valid, the number of real trials as a device scalar (the first n_valid trials are the real ones): the pooled means
+        then run over the real trials only, so a batch padded to a fixed length (one hipGraph per length bucket,
+        GraphTrainer) gives what the unpadded batch gives."""
         L = self._fused_lib(x)
+        if n_valid is not None and mask is None:
+            n_valid = n_valid.reshape(-1).to(torch.float32)
+            if L is not None:
+                params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+                params += [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+                return _FusedDeepSetFn.apply(L, len(self.equiv), x, n_valid, None, *params)
+            mask = (torch.arange(x.shape[1], device=x.device, dtype=torch.float32) < n_valid).to(torch.float32).view(1, -1, 1)
+            inv_n = 1.0 / n_valid
         if L is not None:
             params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
             params += [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
@@ -139,13 +148,14 @@ class _FusedDeepSetFn(torch.autograd.Function):
     launch per 3-layer MLP each way plus one reduction of the weight gradients, instead of ~170 PyTorch launches of 4-7
     microseconds over [sets x trials, 64].  x [B, N, d] -> summary [B, summary_dim].  params: W1, b1, W2, b2, W3, b3 of the
     blocks' (invariant, equivariant) MLPs in order, then of the pre-pooling MLP, then of the post-pooling MLP.
-    mask [N] / inv_n (device scalar) or None."""
+    mask [N] and inv_n (device scalar), or mask = ONE float, the number of real trials, and inv_n None; or both None."""
 
     ROWS_PER_WG = 64     # one 64-row tile per workgroup: 160 workgroups at 32 sets x 300 trials (the chip has 256 CUs)
 
     @staticmethod
     def _common(x_t, d, B, N, S, rpw, mask, inv_n, ctx_part, S_ctx, prm, x_part=None, S_x=0):
-        return (None if x_t is None else x_t.data_ptr(), d, B, N, S, rpw, None if mask is None else mask.data_ptr(),
+        count = mask is not None and mask.numel() == 1 and inv_n is None       # the number of real trials instead of a 0/1 mask
+        return (None if x_t is None else x_t.data_ptr(), d, B, N, S, rpw, None if mask is None else mask.data_ptr(), int(count),
                 None if inv_n is None else inv_n.data_ptr(), 1.0 / N, None if ctx_part is None else ctx_part.data_ptr(), S_ctx,
                 prm[0].data_ptr(), prm[0].shape[1], prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), prm[4].data_ptr(),
                 prm[5].data_ptr(), prm[4].shape[0], None if x_part is None else x_part.data_ptr(), S_x)
@@ -165,7 +175,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
         summary = torch.empty((B, post[4].shape[0]), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         cm = _FusedDeepSetFn._common
-        inv_post = inv_n if inv_n is not None else None
+        count = mask is not None and mask.numel() == 1 and inv_n is None
         cur, d, rc = x, d0, 0
         for i in range(nb):
             inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
@@ -178,8 +188,8 @@ class _FusedDeepSetFn(torch.autograd.Function):
         rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pre), act(2 * nb, 0).data_ptr(),
                                      act(2 * nb, 1).data_ptr(), None, pools[nb].data_ptr(), st)
         # (1 / N as the host's value must be THIS launch's N, not the B rows the post-pooling MLP is launched over)
-        cp = list(cm(None, Hd, 1, B, Sp, rpw, None, inv_post, None, 0, post, pools[nb], S))
-        cp[8] = 1.0 / N
+        cp = list(cm(None, Hd, 1, B, Sp, rpw, mask if count else None, inv_n, None, 0, post, pools[nb], S))
+        cp[9] = 1.0 / N
         rc |= L.nddm_deepset_mlp_fwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), summary.data_ptr(), None, st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_fwd failed ({rc})")
@@ -212,14 +222,15 @@ class _FusedDeepSetFn(torch.autograd.Function):
         g_summary = g_summary.contiguous()
         st, F = torch.cuda.current_stream(dev).cuda_stream, 4
         cm = _FusedDeepSetFn._common
+        count = mask is not None and mask.numel() == 1 and inv_n is None
         pp = part.data_ptr()
 
         def x_of(i):                                # input of block i (and of the pre-pooling MLP for i == nb)
             return (xs_next[i - 1], Hd) if i else (x, d0)
 
         post = params[12 * nb + 6:]
-        cp = list(cm(None, Hd, 1, B, Sp, rpw, None, inv_n, None, 0, post, pools[nb], S))
-        cp[8] = 1.0 / N
+        cp = list(cm(None, Hd, 1, B, Sp, rpw, mask if count else None, inv_n, None, 0, post, pools[nb], S))
+        cp[9] = 1.0 / N
         rc = L.nddm_deepset_mlp_bwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), g_summary.data_ptr(), None, 0, None, 0,
                                     g_pooled.data_ptr(), 0, None, pp + offs[2 * nb + 1] * F, P, st)
         xin, d = x_of(nb)
@@ -439,9 +450,13 @@ class AmortizedPosterior(nn.Module):
         return v.to(dev, torch.float32) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev)
 
     def _conditions(self, input_dict):
-        pad = input_dict.get("summary_mask", None)        # (mask, inv_n) of a batch padded to a bucket length (additive key)
+        pad = input_dict.get("summary_mask", None)        # (mask, inv_n) of a batch padded to a bucket length (additive keys), or
+        nv = input_dict.get("summary_n", None)            # the number of real trials, a device scalar
         x = self._t(input_dict["summary_conditions"])
-        summ = self.summary_net(x) if pad is None else self.summary_net(x, pad[0], pad[1])
+        if nv is not None:
+            summ = self.summary_net(x, n_valid=nv)
+        else:
+            summ = self.summary_net(x) if pad is None else self.summary_net(x, pad[0], pad[1])
         direct = input_dict.get("direct_conditions", None)
         return summ if direct is None else torch.cat([summ, self._t(direct)], dim=-1)
 

@@ -41,7 +41,8 @@ struct Mlp { const float *W1; int ldw1; const float *b1, *W2, *b2, *W3, *b3; };
 struct Common {
     const float *x; int d_in;               // [B * N, d_in]
     int B, N, S, rows_per_wg;               // S workgroups per set
-    const float *mask;                      // [N]: 1 = a real trial, 0 = padding; null: all real
+    const float *mask; int mask_is_count;   // [N]: 1 = a real trial, 0 = padding; null: all real.  mask_is_count: ONE float, the number
+                                            // of real trials n (device scalar): trial i is real iff i < n, and 1 / n is taken from it
     const float *inv_n; float inv_n_host;   // 1 / (number of real trials): device scalar, or (null) the host's value
     const float *ctx_part; int S_ctx;       // [B, S_ctx, 64] partial sums of the pooled producer; null: no context
     Mlp P;
@@ -116,6 +117,15 @@ __device__ __forceinline__ float4 x_row4(const Common &C, long long row, int c4,
     return a;
 }
 
+__device__ __forceinline__ float inv_count(const Common &C)
+{
+    return C.mask_is_count ? 1.0f / *C.mask : (C.inv_n ? *C.inv_n : C.inv_n_host);
+}
+__device__ __forceinline__ float mask_of(const Common &C, int n)
+{
+    return !C.mask ? 1.0f : (C.mask_is_count ? (n < *C.mask ? 1.0f : 0.0f) : C.mask[n]);
+}
+
 // the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled
 __device__ __forceinline__ void context(const Common &C, int b, float *pooled, float *cs, int t)
 {
@@ -123,7 +133,7 @@ __device__ __forceinline__ void context(const Common &C, int b, float *pooled, f
         if (t < HS) {
             float a = 0.0f;
             for (int s = 0; s < C.S_ctx; ++s) a += C.ctx_part[((long long)b * C.S_ctx + s) * HS + t];
-            pooled[t] = a * (C.inv_n ? *C.inv_n : C.inv_n_host);
+            pooled[t] = a * inv_count(C);
         }
         __syncthreads();
         const int u = t >> 2, q = t & 3;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     context(C, b, pooled, cs, t);
     __syncthreads();
     const int u = 32 * ub + m;                       // this lane's column of every result tile
-    const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
+    const float inv_n = inv_count(C);
     const float bias2 = C.P.b2[u], bias3 = u < C.d_out ? C.P.b3[u] : 0.0f, bias1 = cs[u];
     float pacc = 0.0f;
     STAMP(101);
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 if (n < n_end && u < C.d_out) {
                     const float val = acc[v] + bias3;
                     if (O.y) O.y[(row0 + n) * C.d_out + u] = val;
-                    if (O.pool_part) pacc = fmaf(C.mask ? C.mask[n] : 1.0f, val, pacc);
+                    if (O.pool_part) pacc = fmaf(mask_of(C, n), val, pacc);
                 }
             }
         }
@@ -253,17 +263,6 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             O.pool_part[((long long)b * C.S + sp) * HS + t] = (red[cb][n] + red[cb][n + 32]) + (red[2 + cb][n] + red[2 + cb][n + 32]);
         }
     }
-}
-
-// pooled [B, 64] = inv_n * sum over the set's workgroups
-__global__ void pool_finalize_kernel(const float *part, int B, int S, const float *inv_n, float inv_n_host, float *out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * HS) return;
-    const int b = i / HS, u = i - b * HS;
-    float a = 0.0f;
-    for (int s = 0; s < S; ++s) a += part[((long long)b * S + s) * HS + u];
-    out[i] = a * (inv_n ? *inv_n : inv_n_host);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
     const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
     const long long row0 = (long long)b * C.N;
-    const float inv_n = C.inv_n ? *C.inv_n : C.inv_n_host;
+    const float inv_n = inv_count(C);
     STAMP(200);
     stage64(w2s, C.P.W2, HS, t);
     stage64(w3s, C.P.W3, HS, t, C.d_out);
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 }
                 if (BIG) vx = x_row4(C, row0 + n, c4, inv_n);
                 if (Q.gpool) {
-                    const float mk = C.mask ? C.mask[n] : 1.0f;
+                    const float mk = mask_of(C, n);
                     vg.x = fmaf(mk, gp[4 * c4], vg.x); vg.y = fmaf(mk, gp[4 * c4 + 1], vg.y);
                     vg.z = fmaf(mk, gp[4 * c4 + 2], vg.z); vg.w = fmaf(mk, gp[4 * c4 + 3], vg.w);
                 }
@@ -495,12 +494,12 @@ static bool common_ok(const Common &C)
  * scalar or NULL (then inv_n_host); ctx_part [B, S_ctx, 64] or NULL.  Writes h1, h2 [B * N, 64], and y [B * N, 64] and / or
  * pool_part [B, S, 64] where not NULL.  S workgroups of up to rows_per_wg trials per set.  d_out: rows of W3 / b3 and width of y
  * (64 but for the last MLP of the network); x_part / S_x: see Common (NULL / 0: x is read). */
-int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
+int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, float *h1, float *h2,
                          float *y, float *pool_part, void *stream)
 {
-    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
     if (!common_ok(C) || !h1 || !h2 || (pool_part && d_out != HS)) return 1;
     const FwdOut O = {h1, h2, y, pool_part};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -509,24 +508,16 @@ int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int nddm_deepset_pool_finalize(const float *part, int B, int S, const float *inv_n, float inv_n_host, float *out, void *stream)
-{
-    if (B <= 0 || S <= 0) return 1;
-    hipLaunchKernelGGL(pool_finalize_kernel, dim3((B * HS + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, B, S,
-                       inv_n, inv_n_host, out);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
-}
-
 /* The backward of nddm_deepset_mlp_fwd (same first arguments).  gy [B * N, 64] or NULL; gpool / gp_S / gp_W / gp_ldw: see BwdIO;
  * gx [B * N, d_in] or NULL (d_in == 64 only), gx_acc: accumulate; dctx_part [B, S, 64] or NULL; wpart: B * S rows, ld_part floats
  * apart, of 64 ldw1 + 64 + 2 (4096 + 64) weight-gradient partial sums each: reduce with nddm_deepset_reduce. */
-int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, const float *inv_n,
+int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, const float *h1,
                          const float *h2, const float *gy, const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx,
                          int gx_acc, float *dctx_part, float *wpart, int ld_part, void *stream)
 {
-    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
     if (!common_ok(C) || !h1 || !h2 || !wpart || ld_part < HS * ldw1 + HS + HS * HS + HS + d_out * HS + d_out || (gx && d_in != HS)
         || (!gy && !gpool) || (gpool && d_out != HS))
         return 1;

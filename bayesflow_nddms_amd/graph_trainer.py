@@ -111,7 +111,6 @@ class GraphTrainer:
             self.step_f = torch.zeros(1, dtype=torch.float32, device=self.dev)
             self.n_f = torch.full((1,), float(self.n_max), dtype=torch.float32, device=self.dev)
             self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
-            self.arange = torch.arange(self.n_max, dtype=torch.float32, device=self.dev)
             if self.optimizer is not None:
                 # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
                 self.optimizer.step()
@@ -142,9 +141,7 @@ class GraphTrainer:
 
     def _forward_backward(self, params, trials):
         """configurator (basic_ddm_dc.py:139-160) on device scalars + maximum-likelihood loss + backward into the flat buffer."""
-        n_top = trials.shape[1]
-        mask = (self.arange[:n_top] < self.n_f).to(torch.float32).view(1, n_top, 1)
-        conf = {"summary_conditions": trials, "summary_mask": (mask, 1.0 / self.n_f),
+        conf = {"summary_conditions": trials, "summary_n": self.n_f,
                 "direct_conditions": torch.log(self.n_f).view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
                 "parameters": params if self.P_net == self.P else params[:, :self.P_net]}
         loss = self.amortizer.compute_loss(conf)

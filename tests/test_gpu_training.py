@@ -283,6 +283,14 @@ def test_fused_deepset_equals_the_pytorch_path():
         for k, (a, b) in enumerate(zip(res[True], res[False])):
             mag = float(b.abs().max()) + 1e-6
             assert float((a - b).abs().max()) <= 1e-4 * mag + 1e-6, (blocks, B, N, n_real, k, a.shape, float((a - b).abs().max()), mag)
+        if n_real is not None:                               # the count form of the mask (a device scalar: what the graph trainer passes)
+            nv = torch.tensor([float(n_real)], device="cuda")
+            for fused in (True, False):
+                net.fused = fused
+                out = net(x, n_valid=nv)
+                g = torch.autograd.grad((out * w).sum(), list(net.parameters()))
+                for a, b in zip([out.detach()] + list(g), res[fused]):
+                    assert torch.equal(a, b) if fused else torch.allclose(a, b, rtol=1e-5, atol=1e-6)
         if n_real is not None and n_real < N:                # padding is invisible: the unpadded batch gives the same summary
             net.fused = True
             assert torch.allclose(net(x[:, :n_real].contiguous()), res[True][0], rtol=1e-4, atol=1e-5)

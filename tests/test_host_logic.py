@@ -307,7 +307,7 @@ def test_training_library_builds_and_exports_its_entry_points():
     from bayesflow_nddms_amd import build
     L = ctypes.CDLL(build.build_train())
     for name in ("nddm_train_flow_supported", "nddm_train_flow_fwd", "nddm_train_flow_bwd", "nddm_deepset_supported",
-                 "nddm_deepset_mlp_fwd", "nddm_deepset_mlp_bwd", "nddm_deepset_pool_finalize", "nddm_deepset_reduce",
+                 "nddm_deepset_mlp_fwd", "nddm_deepset_mlp_bwd", "nddm_deepset_reduce",
                  "nddm_train_adam_step"):
         assert hasattr(L, name), name
     L.nddm_train_flow_supported.argtypes = [ctypes.c_int] * 5
