@@ -50,118 +50,23 @@ struct Args {
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid = ceil(R / TRF) workgroups of 256 threads over tiles of TRF = 8 rows (four workgroups at batch 32: the work is latency,
-// not arithmetic, so it is spread).  Layers 1 and 3 are plain FMAs (thread t: hidden unit j = t % 128, row half rh = t / 128);
-// layer 2, the 128 x 128 product, is v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain) on operands read from LDS --
-// W2 is staged there with coalesced loads (a thread streaming its own row of W2 from global memory was address-processing
-// bound: 64 cache lines per wave instruction, 4.4 of the half-layer's 11 microseconds).
+// not arithmetic, so it is spread), each taking its rows through every layer.  What a row carries from half-layer to half-layer
+// (the permuted ActNorm output z, the layer's output, the condition) stays in LDS; global memory only receives what the
+// backward needs.  Layers 1 and 3 are plain FMAs (thread t: hidden unit j = t % 128, row half rh = t / 128); layer 2, the
+// 128 x 128 product, is v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain) on operands read from LDS with 16-byte loads
+// (the order of the sum is free: lane group k takes the k's [32 k, 32 k + 32) of both operands).  The NEXT half-layer's weights
+// are fetched into registers at the top of a half-layer and written to LDS once their buffers' last readers are done: a
+// half-layer is a chain of five short phases, and a cold load at the head of each was 3.3 of its 8.4 microseconds.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TRF = 8, RPT = TRF / 2;
-constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2 in LDS: the MFMA operand reads (16 lanes down
-                                // a column, 4 lanes along it) then touch every bank exactly twice per wave
-__device__ __forceinline__ void coupling_fwd_tile(const Args &A, const int r0, float *y, int ldy, float *s_out, int lds, float *h1_out,
-                                               float *h2_out, float (*s_tile)[M_MAX])
-{
-    __shared__ float in_s[TRF][DI_MAX];
-    __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TRF..15 stay zero (the MFMA tile has 16 rows)
-    __shared__ __attribute__((aligned(16))) float h2r[TRF][LDR];
-    __shared__ float o_s[TRF][M_MAX];
-    __shared__ float w3s[M_MAX][H + 1];       // W3, fetched while layers 1 and 2 run (+ 1: the rows' readers are lanes m)
-    __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
-    const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7;
-    const int DI = A.Dh + A.C, M = 2 * A.Dt;
-    {   // W2: 16-byte loads, coalesced; in flight while layer 1 runs
-        const float4 *src = reinterpret_cast<const float4 *>(A.W2);
-#pragma unroll
-        for (int k = 0; k < H * H / 4 / 256; ++k) {
-            const int p4 = t + 256 * k;
-            *reinterpret_cast<float4 *>(&w2s[p4 >> 5][4 * (p4 & 31)]) = src[p4];
-        }
-    }
-    for (int p = t; p < M * H; p += 256) w3s[p >> 7][p & (H - 1)] = A.W3[p];
-    for (int p = t; p < (16 - TRF) * H; p += 256) h1r[TRF + (p >> 7)][p & (H - 1)] = 0.0f;
-    for (int p = t; p < TRF * DI; p += 256) {
-        const int r = p / DI, c = p - r * DI, row = r0 + r;
-        float v = 0.0f;
-        if (row < A.R) v = c < A.Dh ? A.xh[(long long)row * A.ldh + c] : A.cond[(long long)row * A.C + (c - A.Dh)];
-        in_s[r][c] = v;
-    }
-    __syncthreads();
-    STAMP(1);
-    {   // layer 1 (register arrays are only ever indexed by unrolled constants: no private scratch)
-        float acc[RPT];
-        const float b = A.b1[j];
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) acc[q] = b;
-#pragma unroll 4
-        for (int c = 0; c < DI; ++c) {
-            const float wv = A.W1[j * DI + c];
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) acc[q] = fmaf(wv, in_s[rh * RPT + q][c], acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = rh * RPT + q;
-            const float v = elu(acc[q]);
-            h1r[r][j] = v;
-            if (r0 + r < A.R) h1_out[(long long)(r0 + r) * H + j] = v;
-        }
-    }
-    __syncthreads();
-    STAMP(2);
-    {   // layer 2: wave w owns units [32 w, 32 w + 32) as two 16 x 16 tiles (two independent accumulators);
-        // lane l: A[row l & 15][k = l >> 4] = h1[row][4 s + k], B[k][unit l & 15] = W2[unit][4 s + k]
-        const int lane = t & 63, w = t >> 6, n = lane & 15, kk = lane >> 4;
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-        const float *ap = &h1r[n][kk], *bp0 = &w2s[32 * w + n][kk], *bp1 = &w2s[32 * w + 16 + n][kk];
-#pragma unroll 8
-        for (int s4 = 0; s4 < H; s4 += 4) {
-            const float a = ap[s4];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[s4], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[s4], acc1, 0, 0, 0);
-        }
-        // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register: rows < TRF live in lanes 0..31
-        if (kk < TRF / 4) {
-            const int u0 = 32 * w + n, u1 = u0 + 16;
-            const float b0 = A.b2[u0], b1 = A.b2[u1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * kk + q;
-                const float v0 = elu(acc0[q] + b0), v1 = elu(acc1[q] + b1);
-                h2r[r][u0] = v0;
-                h2r[r][u1] = v1;
-                if (r0 + r < A.R) {
-                    h2_out[(long long)(r0 + r) * H + u0] = v0;
-                    h2_out[(long long)(r0 + r) * H + u1] = v1;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(3);
-    for (int p = t; p < 2 * TRF * M; p += 256) {      // layer 3: two threads (adjacent lanes) per output, half the units each
-        const int pr = p >> 1, half = p & 1, r = pr / M, m = pr - r * M;
-        float acc = half ? 0.0f : A.b3[m];
-#pragma unroll 8
-        for (int i = half * (H / 2); i < (half + 1) * (H / 2); ++i) acc = fmaf(w3s[m][i], h2r[r][i], acc);
-        acc += __shfl_xor(acc, 1);
-        if (!half) o_s[r][m] = acc;
-    }
-    __syncthreads();
-    STAMP(4);
-    for (int p = t; p < TRF * A.Dt; p += 256) {       // soft clamp + affine transform
-        const int r = p / A.Dt, d = p - r * A.Dt, row = r0 + r;
-        if (row >= A.R) continue;
-        const float s = A.clamp * tanhf(o_s[r][d] / A.clamp);
-        s_tile[r][d] = s;
-        s_out[(long long)row * lds + d] = s;
-        y[(long long)row * ldy + d] = fmaf(A.xtr[(long long)row * A.ldt + d], expf(s), o_s[r][A.Dt + d]);
-    }
-    __syncthreads();                  // the outputs are visible to the workgroup, and the LDS arrays are free again
-    STAMP(5);
-}
+constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2 in LDS: 16-byte aligned rows whose operand reads
+                                // (16 rows x 4 column groups per wave instruction) spread evenly over the banks
+// A barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the thread has in flight
+// -- which is exactly what the forward's weight prefetch must not do: its loads are issued a half-layer ahead and nothing in
+// this kernel reads global memory that the kernel wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- the whole flow forward.  grid = ceil(R / TRF) workgroups of 256 threads, each takes its rows through every layer.
 constexpr int L_MAX = 8, D_MAX = 8;
 struct HalfP { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 struct LayerP { const float *scale, *bias; HalfP a, b; };
@@ -171,46 +76,177 @@ struct FlowSaved { float *z_all, *out_all, *s_all, *h_all; };    // [L, R, D] pe
                                                                   // log-scales; [L, 4, R, H] activations of the sub-networks
 __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
 {
-    __shared__ float s_tile[TRF][M_MAX];                    // the current half-layer's log-scales (rows beyond R: stale, unused)
-    float ld_acc = 0.0f;                                     // threads t < TRF: log|det| of row r0 + t, summed as the layers go
-    const int t = threadIdx.x, r0 = blockIdx.x * TRF, D = Q.D, d1 = Q.d1, d2 = D - d1;
+    __shared__ __attribute__((aligned(16))) float in_s[TRF][DI_MAX];
+    __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TRF..15 stay zero (the MFMA tile has 16 rows)
+    __shared__ __attribute__((aligned(16))) float h2r[TRF][LDR];
+    __shared__ float o_s[TRF][M_MAX];
+    __shared__ float w3s[M_MAX][H + 1];       // (+ 1: the rows' readers are lanes m)
+    __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
+    __shared__ float xs[2][TRF][D_MAX];       // the layer's input / output rows (alternating), zs: its permuted ActNorm output
+    __shared__ float zs[TRF][D_MAX], cs[TRF][DI_MAX];
+    __shared__ float w1f[H * DI_MAX];         // W1 as it lies in memory: [unit][DI]
+    const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7, lane = t & 63, w = t >> 6;
+    const int r0 = blockIdx.x * TRF, D = Q.D, d1 = Q.d1, d2 = D - d1;
     const long long RD = (long long)Q.R * D, RH = (long long)Q.R * H;
+    float ld_acc = 0.0f;                                     // threads t < TRF: log|det| of row r0 + t, summed as the layers go
     STAMP(0);
-    for (int hl = 0; hl < 2 * Q.L; ++hl) {                  // half-layers: ONE copy of the tile function's code
+    // one thread's share of the next half-layer's weights (plain local arrays indexed by unrolled constants: registers)
+    f32x4 nw2[H * H / 4 / 256];           // (the compiler's own vector type: HIP's float4 struct kept the array in memory)
+    float nw1[H * DI_MAX / 256], nw3[M_MAX * H / 256], nb1, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
+#define NDDM_FETCH_WEIGHTS(Wn, DIn, Mn) do {                                                                                  \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>((Wn).W2);                                                         \
+        _Pragma("unroll") for (int k = 0; k < H * H / 4 / 256; ++k) nw2[k] = src_[t + 256 * k];                                \
+        /* (coalesced; every load unconditional, from a clamped address: a guarded load is a branch and a block of its own) */     \
+        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / 256; ++k) nw1[k] = (Wn).W1[min(t + 256 * k, H * (DIn) - 1)];          \
+        _Pragma("unroll") for (int k = 0; k < M_MAX * H / 256; ++k) {                                                          \
+            const int p_ = t + 256 * k; const float v_ = (Wn).W3[min(p_, (Mn) * H - 1)]; nw3[k] = p_ < (Mn) * H ? v_ : 0.0f; } \
+        nb1 = (Wn).b1[j]; nb20 = (Wn).b2[32 * w + (lane & 15)]; nb21 = (Wn).b2[32 * w + 16 + (lane & 15)];                     \
+        nb3 = (Wn).b3[(t >> 1) % (Mn)];                                                                                         \
+    } while (0)
+    NDDM_FETCH_WEIGHTS(P.layer[0].a, d1 + Q.C, 2 * d2);
+    if (t < TRF * D) { const int p = P.perm[0][t % D]; nsc = P.layer[0].scale[p]; nbi = P.layer[0].bias[p]; }
+    for (int p = t; p < (16 - TRF) * H; p += 256) h1r[TRF + (p >> 7)][p & (H - 1)] = 0.0f;
+    for (int p = t; p < TRF * DI_MAX; p += 256) (&in_s[0][0])[p] = 0.0f;
+    if (t < TRF * D) { const int r = t / D, c = t - r * D; xs[0][r][c] = r0 + r < Q.R ? theta[(long long)(r0 + r) * D + c] : 0.0f; }
+    if (t < TRF * Q.C) { const int r = t / Q.C, c = t - r * Q.C; cs[r][c] = r0 + r < Q.R ? cond[(long long)(r0 + r) * Q.C + c] : 0.0f; }
+    for (int hl = 0; hl < 2 * Q.L; ++hl) {
         const int l = hl >> 1;
         const bool second = hl & 1;
         const LayerP &Y = P.layer[l];
-        const float *x = l ? S.out_all + (l - 1) * RD : theta;
-        float *z = S.z_all + l * RD, *out = S.out_all + l * RD, *sl = S.s_all + l * RD, *h = S.h_all + 4 * l * RH;
+        const HalfP &W = second ? Y.b : Y.a;
+        const int Dh = second ? d2 : d1, Dt = second ? d1 : d2, DI = Dh + Q.C, M = 2 * Dt;
+        float *z_g = S.z_all + l * RD, *out_g = S.out_all + l * RD, *sl = S.s_all + l * RD + (second ? d2 : 0), *h = S.h_all + 4 * l * RH;
+        float *h1_out = h + (second ? 2 : 0) * RH, *h2_out = h + (second ? 3 : 1) * RH;
+        float (*xin)[D_MAX] = xs[l & 1], (*xout)[D_MAX] = xs[(l & 1) ^ 1];
+        // this half-layer's weights: out of the registers (fetched a half-layer ago) into LDS / this thread's W1 row
+        lds_barrier();                                     // (the previous half-layer's readers of w2s, w3s, xs are done)
+#pragma unroll
+        for (int k = 0; k < H * H / 4 / 256; ++k) { const int p4 = t + 256 * k; *reinterpret_cast<f32x4 *>(&w2s[p4 >> 5][4 * (p4 & 31)]) = nw2[k]; }
+#pragma unroll
+        for (int k = 0; k < M_MAX * H / 256; ++k) { const int p = t + 256 * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
+#pragma unroll
+        for (int k = 0; k < H * DI_MAX / 256; ++k) w1f[t + 256 * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, unread)
+        const float b1v = nb1, b20 = nb20, b21 = nb21, b3v = nb3, scv = nsc, biv = nbi;
+        if (hl + 1 < 2 * Q.L) {                              // ... and the next one's into the registers
+            const HalfP &Wn = second ? P.layer[l + 1].a : Y.b;
+            NDDM_FETCH_WEIGHTS(Wn, (second ? d1 : d2) + Q.C, 2 * (second ? d2 : d1));
+            if (second && t < TRF * D) { const int p = P.perm[l + 1][t % D]; nsc = P.layer[l + 1].scale[p]; nbi = P.layer[l + 1].bias[p]; }
+        }
         if (!second) {
             if (t < TRF * D) {                               // ActNorm, then the permutation: z[:, c] = u[:, perm[c]]
-                const int r = t / D, c = t - r * D, row = r0 + r;
-                if (row < Q.R) {
-                    const int p = P.perm[l][c];
-                    z[(long long)row * D + c] = fmaf(x[(long long)row * D + p], expf(Y.scale[p]), Y.bias[p]);
-                }
+                const int r = t / D, c = t - r * D, p = P.perm[l][c];
+                const float v = fmaf(xin[r][p], expf(scv), biv);
+                zs[r][c] = v;
+                if (r0 + r < Q.R) z_g[(long long)(r0 + r) * D + c] = v;
             }
             if (t < TRF) {
 #pragma unroll
                 for (int d = 0; d < D_MAX; ++d) if (d < D) ld_acc += Y.scale[d];
             }
-            __syncthreads();
+            lds_barrier();
         }
         // first:  conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s[:, :d2]
         // second: conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s[:, d2:]
-        const HalfP &W = second ? Y.b : Y.a;
-        const Args A = {second ? out + d1 : z, D, second ? d2 : d1, cond, Q.C, second ? z : z + d1, D, second ? d1 : d2,
-                        W.W1, W.b1, W.W2, W.b2, W.W3, W.b3, Q.clamp, Q.R};
-        coupling_fwd_tile(A, r0, second ? out : out + d1, D, second ? sl + d2 : sl, D, h + (second ? 2 : 0) * RH,
-                          h + (second ? 3 : 1) * RH, s_tile);
-        if (t < TRF) {                                       // (the tile function ends with a barrier; the next one's writes to
-            const int Dt = second ? d1 : d2;                 // s_tile come after three more)
-#pragma unroll
-            for (int d = 0; d < M_MAX / 2; ++d) if (d < Dt) ld_acc += s_tile[t][d];
+        for (int p = t; p < TRF * DI; p += 256) {
+            const int r = p / DI, c = p - r * DI;
+            in_s[r][c] = c < Dh ? (second ? xout[r][d1 + c] : zs[r][c]) : cs[r][c - Dh];
         }
+        lds_barrier();
+        STAMP(1);
+        {   // layer 1 (register arrays are only ever indexed by unrolled constants: no private scratch)
+            float acc[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) acc[q] = b1v;
+#pragma unroll
+            for (int c0 = 0; c0 < DI_MAX; c0 += 4) {         // (columns beyond DI: a zero weight against a finite -- zeroed or old -- input)
+                if (c0 < DI) {
+                    float wv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wv[u] = c0 + u < DI ? w1f[j * DI + c0 + u] : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&in_s[rh * RPT + q][c0]);
+                        acc[q] = fmaf(wv[3], v.w, fmaf(wv[2], v.z, fmaf(wv[1], v.y, fmaf(wv[0], v.x, acc[q]))));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = rh * RPT + q;
+                const float v = elu(acc[q]);
+                h1r[r][j] = v;
+                if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + j] = v;
+            }
+        }
+        lds_barrier();
+        STAMP(2);
+        {   // layer 2: wave w owns units [32 w, 32 w + 32) as two 16 x 16 tiles (two independent accumulators);
+            // lane l: A[row l & 15][k] = h1[row][k], B[k][unit l & 15] = W2[unit][k] for the k's 32 (l >> 4) + s, s = 0 .. 31
+            const int n = lane & 15, kk = lane >> 4;
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+            const float4 *ap = reinterpret_cast<const float4 *>(&h1r[n][32 * kk]);
+            const float4 *bp0 = reinterpret_cast<const float4 *>(&w2s[32 * w + n][32 * kk]);
+            const float4 *bp1 = reinterpret_cast<const float4 *>(&w2s[32 * w + 16 + n][32 * kk]);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 a = ap[q4], b0 = bp0[q4], b1 = bp1[q4];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+            }
+            // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register: rows < TRF live in lanes 0..31
+            if (kk < TRF / 4) {
+                const int u0 = 32 * w + n, u1 = u0 + 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * kk + q;
+                    const float v0 = elu(acc0[q] + b20), v1 = elu(acc1[q] + b21);
+                    h2r[r][u0] = v0;
+                    h2r[r][u1] = v1;
+                    if (r0 + r < Q.R) {
+                        h2_out[(long long)(r0 + r) * H + u0] = v0;
+                        h2_out[(long long)(r0 + r) * H + u1] = v1;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        STAMP(3);
+        for (int p = t; p < 2 * TRF * M; p += 256) {      // layer 3: two threads (adjacent lanes) per output, half the units each
+            const int pr = p >> 1, half = p & 1, r = pr / M, m = pr - r * M;
+            float acc = half ? 0.0f : b3v;                   // (one pass: 2 TRF M <= 256 threads)
+#pragma unroll 8
+            for (int i = half * (H / 2); i < (half + 1) * (H / 2); ++i) acc = fmaf(w3s[m][i], h2r[r][i], acc);
+            acc += __shfl_xor(acc, 1);
+            if (!half) o_s[r][m] = acc;
+        }
+        lds_barrier();
+        STAMP(4);
+        if (t < TRF * Dt) {                                  // soft clamp + affine transform
+            const int r = t / Dt, d = t - r * Dt, row = r0 + r;
+            const float sv = Q.clamp * tanhf(o_s[r][d] / Q.clamp);
+            const float yv = fmaf(second ? zs[r][d] : zs[r][d1 + d], expf(sv), o_s[r][Dt + d]);
+            xout[r][second ? d : d1 + d] = yv;
+            o_s[r][d] = sv;                                  // (its reader, this thread, is done with it)
+            if (row < Q.R) {
+                sl[(long long)row * D + d] = sv;
+                out_g[(long long)row * D + (second ? d : d1 + d)] = yv;
+            }
+        }
+        lds_barrier();
+        if (t < TRF) {
+#pragma unroll
+            for (int d = 0; d < M_MAX / 2; ++d) if (d < Dt) ld_acc += o_s[t][d];
+        }
+        STAMP(5);
     }
-    if (t < TRF && r0 + t < Q.R) ld[r0 + t] = ld_acc;
-    STAMP(6);        // log|det| of the row: every log-scale, and the ActNorms'
+    if (t < TRF && r0 + t < Q.R) ld[r0 + t] = ld_acc;        // log|det| of the row: every log-scale, and the ActNorms'
+    STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
