@@ -261,21 +261,24 @@ constexpr int NTB = 1024;
 constexpr int LDW2 = H + 8;      // row stride of W2 in LDS: d(h1)'s B operand reads 4 rows x 16 columns per wave instruction
 
 struct HalfD {                   // one half-layer of kernel (1), resolved by the host
-    const float *xtr, *W1, *W2, *W3, *s, *h1, *h2, *gy, *gy2;
-    float *gxh, *gxtr, *da2, *da1, *dos;     // da2, da1 [R, H], dos [R, M_MAX]: for kernel (2)
-    int Dh, Dt, ldgh, acc_gxh, acc_gcond, norm;          // norm: the layer's ActNorm / permutation backward follows (-1: no)
+    const float *xtr, *W1, *W2, *W3, *s, *h1, *h2;       // xtr, s: [R, .] slices with row stride D (saved by the forward)
+    float *da2, *da1, *dos;      // da2, da1 [R, H], dos [R, M_MAX]: for kernel (2)
+    int Dh, Dt;
 };
-struct NormD { const float *scale; const float *gz; unsigned char perm[D_MAX]; };
+struct NormD { const float *scale; float *gz; unsigned char perm[D_MAX]; };      // gz [R, D]: d(permuted ActNorm output), for kernel (2)
 struct FlowD { HalfD half[2 * L_MAX]; NormD norm[L_MAX]; };
 struct FlowBwdBuf {
-    const float *g_ld;             // [R] gradient of the flow's log|det|
-    float *gx;                     // [R, D]: gradient of a layer's input; after layer 0, of theta
+    const float *g_z, *g_ld;       // [R, D], [R]: gradients of the flow's output and log|det| (g_nll null)
+    float *gx;                     // [R, D]: the gradient of theta
     float *gcond;                  // [R, C]
-    const float *g_nll;            // not null: the gradient of the mean negative log-likelihood (a scalar); the kernel then WRITES
-    float *w_gz, *w_gld;           // the gradients of z and log|det| it reads -- z g / R and -g / R -- from the forward's z
+    const float *g_nll;            // not null: the gradient of the mean negative log-likelihood (a scalar): the gradients of z and
+    float *w_gld;                  // log|det| are then z g / R and -g / R, from the forward's z (w_gld [R] is written for kernel (2))
     const float *z_last;
 };
 
+// What a row carries from half-layer to half-layer (the gradients of the layer's output, of its permuted ActNorm output, of the
+// condition) stays in LDS, the next half-layer's weights and saved activations are fetched into registers a half-layer ahead, and
+// the barriers order LDS traffic only (nothing here reads global memory that the kernel wrote): as in the forward.
 __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, FlowBwdBuf U)
 {
     __shared__ float h1r[TR][LDR];        // [row][unit]
@@ -285,47 +288,73 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     __shared__ float w2s[H][LDW2];
     __shared__ float w1s[H][DI_MAX + 1];
     __shared__ float w3s[M_MAX][H];
-    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D;
-    const int r0 = blockIdx.x * TR, rows = min(TR, Q.R - r0);
-    if (U.g_nll) {                                           // (this workgroup's rows; the first half-layer starts with a barrier)
-        const float sc = *U.g_nll / (float)Q.R;
-        for (int i = t; i < rows * D; i += NTB) U.w_gz[(long long)r0 * D + i] = U.z_last[(long long)r0 * D + i] * sc;
-        for (int r = t; r < rows; r += NTB) U.w_gld[r0 + r] = -sc;
+    __shared__ float gout_s[TR][D_MAX], gz_s[TR][D_MAX], gy2_s[TR][D_MAX], gcond_s[TR][DI_MAX];
+    const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D, d1 = Q.d1, d2 = D - d1;
+    const int r0 = blockIdx.x * TR;
+    // this thread's (row, column) of the affine phase: rows 0 .. TR - 1 x up to M_MAX / 2 columns
+    float gld_sc = 0.0f;                                     // nll form: the uniform gradient of log|det|
+    if (U.g_nll) gld_sc = -*U.g_nll / (float)Q.R;
+    if (t < TR * D) {
+        const int r = t / D, c = t - r * D, row = r0 + r;
+        float v = 0.0f;
+        if (row < Q.R) v = U.g_nll ? U.z_last[(long long)row * D + c] * (-gld_sc) : U.g_z[(long long)row * D + c];
+        gout_s[r][c] = v;
     }
+    if (U.g_nll && t < TR && r0 + t < Q.R) U.w_gld[r0 + t] = gld_sc;
+    for (int p = t; p < TR * DI_MAX; p += NTB) (&gcond_s[0][0])[p] = 0.0f;
+    // one thread's share of the next half-layer's operands
+    float nw2[H * H / NTB], nw1[H * DI_MAX / NTB], nw3[M_MAX * H / NTB], nh1[TR * H / NTB], nh2[TR * H / NTB], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
+#define NDDM_FETCH_HALF(X) do {                                                                                               \
+        const int DIn_ = (X).Dh + Q.C, Mn_ = 2 * (X).Dt;                                                                       \
+        _Pragma("unroll") for (int k = 0; k < H * H / NTB; ++k) nw2[k] = (X).W2[t + NTB * k];                                  \
+        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NTB; ++k) nw1[k] = (X).W1[min(t + NTB * k, H * DIn_ - 1)];          \
+        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTB; ++k) nw3[k] = (X).W3[min(t + NTB * k, Mn_ * H - 1)];            \
+        _Pragma("unroll") for (int k = 0; k < TR * H / NTB; ++k) {                                                             \
+            const long long o_ = (long long)min(r0 + g + 8 * k, Q.R - 1) * H + j;                                              \
+            nh1[k] = (X).h1[o_]; nh2[k] = (X).h2[o_];                                                                          \
+        }                                                                                                                      \
+        {   const int r_ = t / (X).Dt, d_ = t - r_ * (X).Dt; const long long o_ = (long long)min(r0 + min(r_, TR - 1), Q.R - 1) * D + d_; \
+            ns = (X).s[o_]; nx = (X).xtr[o_]; ngl = U.g_nll ? gld_sc : U.g_ld[min(r0 + min(r_, TR - 1), Q.R - 1)]; }           \
+    } while (0)
+    NDDM_FETCH_HALF(T.half[2 * Q.L - 1]);
     for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
         const HalfD &X = T.half[hl];
-        const int DI = X.Dh + Q.C, M = 2 * X.Dt;
-        __syncthreads();                  // the previous half-layer's last phase read w1s and h2r; its global writes are visible
+        const bool second = hl & 1;
+        const int DI = X.Dh + Q.C, M = 2 * X.Dt, Dt = X.Dt;
+        lds_barrier();                    // the previous half-layer's readers are done
         STAMP(10);
 #pragma unroll
-        for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = X.W2[t + NTB * k];
-        for (int p = t; p < H * DI; p += NTB) { const int jj = p / DI; w1s[jj][p - jj * DI] = X.W1[p]; }
-        for (int p = t; p < M * H; p += NTB) (&w3s[0][0])[p] = X.W3[p];
+        for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = nw2[k];
+#pragma unroll
+        for (int k = 0; k < H * DI_MAX / NTB; ++k) {
+            const int p = t + NTB * k, jj = p / DI;
+            if (p < H * DI) w1s[jj][p - jj * DI] = nw1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < M_MAX * H / NTB; ++k) (&w3s[0][0])[t + NTB * k] = nw3[k];
 #pragma unroll
         for (int k = 0; k < TR * H / NTB; ++k) {         // saved activations (rows beyond R: zero)
-            const int r = g + 8 * k, row = r0 + r;
-            h1r[r][j] = row < Q.R ? X.h1[(long long)row * H + j] : 0.0f;
-            h2r[r][j] = row < Q.R ? X.h2[(long long)row * H + j] : 0.0f;
+            const int r = g + 8 * k;
+            const bool ok = r0 + r < Q.R;
+            h1r[r][j] = ok ? nh1[k] : 0.0f;
+            h2r[r][j] = ok ? nh2[k] : 0.0f;
         }
-        for (int p = t; p < TR * X.Dt; p += NTB) {       // through the affine transform and the soft clamp
-            const int r = p / X.Dt, d = p - r * X.Dt, row = r0 + r;
-            float d_os = 0.0f, d_t = 0.0f;
-            if (row < Q.R) {
-                const float s = X.s[(long long)row * D + d], es = expf(s);
-                float gg = X.gy[(long long)row * D + d];
-                if (X.gy2) gg += X.gy2[(long long)row * (D - Q.d1) + d];
-                const float d_sc = fmaf(gg * X.xtr[(long long)row * D + d], es, U.g_ld[row]);
-                const float u = s / Q.clamp;
-                d_os = d_sc * (1.0f - u * u);
-                d_t = gg;
-                X.gxtr[(long long)row * D + d] = gg * es;
-                X.dos[(long long)row * M_MAX + d] = d_os;
-                X.dos[(long long)row * M_MAX + X.Dt + d] = d_t;
-            }
+        if (t < TR * Dt) {                               // through the affine transform and the soft clamp
+            const int r = t / Dt, d = t - r * Dt, row = r0 + r;
+            // second: the gradient of out[:, :d1]; first: of out[:, d1:] plus what came through net 2's conditioning input
+            const float gg = second ? gout_s[r][d] : gout_s[r][d1 + d] + gy2_s[r][d];
+            const float es = expf(ns), u = ns / Q.clamp;
+            const float d_os = row < Q.R ? fmaf(gg * nx, es, ngl) * (1.0f - u * u) : 0.0f, d_t = row < Q.R ? gg : 0.0f;
+            gz_s[r][second ? d : d1 + d] = gg * es;      // d z of the transformed half (the other half: the input gradient below)
             do_s[r][d] = d_os;
-            do_s[r][X.Dt + d] = d_t;
+            do_s[r][Dt + d] = d_t;
+            if (row < Q.R) {
+                X.dos[(long long)row * M_MAX + d] = d_os;
+                X.dos[(long long)row * M_MAX + Dt + d] = d_t;
+            }
         }
-        __syncthreads();
+        if (hl > 0) NDDM_FETCH_HALF(T.half[hl - 1]);     // (the loads' results are not waited for before the next half-layer)
+        lds_barrier();
         STAMP(11);
         {   // d h2 -> d(pre-activation 2): thread (unit j, rows 4 g .. 4 g + 3)
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 if (r0 + r < Q.R) X.da2[(long long)(r0 + r) * H + j] = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(12);
         {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k = l >> 4] = da2[row][4 s + k], B[k][i = l & 15] = W2[4 s + k][i]
             const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
@@ -360,13 +389,13 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 if (r0 + r < Q.R) X.da1[(long long)(r0 + r) * H + i] = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(13);
         // d in: (row, column) pairs, `parts` adjacent lanes each (a power of two: every thread busy for 512 pairs or fewer)
         {
             const int npairs = TR * DI, parts = npairs <= NTB / 4 ? 4 : (npairs <= NTB / 2 ? 2 : 1), span = H / parts;
             const int pr = t / parts, part = t - pr * parts;
-            const int r = pr / DI, c = pr - r * DI, row = r0 + r;
+            const int r = pr / DI, c = pr - r * DI;
             float acc = 0.0f;
             if (pr < npairs) {
 #pragma unroll 8
@@ -374,28 +403,30 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
             }
             if (parts >= 2) acc += __shfl_xor(acc, 1);
             if (parts >= 4) acc += __shfl_xor(acc, 2);
-            if (pr < npairs && part == 0 && row < Q.R) {
-                if (c < X.Dh) {
-                    float *o = &X.gxh[(long long)row * X.ldgh + c];
-                    *o = X.acc_gxh ? *o + acc : acc;
-                } else {
-                    float *o = &U.gcond[(long long)row * Q.C + (c - X.Dh)];
-                    *o = X.acc_gcond ? *o + acc : acc;
-                }
+            if (pr < npairs && part == 0) {
+                if (c >= X.Dh) gcond_s[r][c - X.Dh] += acc;
+                else if (second) gy2_s[r][c] = acc;      // net 2 is conditioned on out[:, d1:]
+                else gz_s[r][c] += acc;                  // net 1 on z[:, :d1], which net 2 also transformed
             }
         }
         STAMP(14);
-        if (X.norm < 0) continue;
-        __syncthreads();
+        if (second) continue;
+        lds_barrier();
         // back through the permutation and the ActNorm (the parameters' gradients: kernel (2))
-        const NormD &N = T.norm[X.norm];
+        const NormD &N = T.norm[hl >> 1];
         if (t < TR * D) {
-            const int r = t / D, c = t - r * D, row = r0 + r;
-            if (row < Q.R) {
-                const int p = N.perm[c];
-                U.gx[(long long)row * D + p] = N.gz[(long long)row * D + c] * expf(N.scale[p]);
-            }
+            const int r = t / D, c = t - r * D, row = r0 + r, p = N.perm[c];
+            const float gv = gz_s[r][c];
+            gout_s[r][p] = gv * expf(N.scale[p]);
+            if (row < Q.R) N.gz[(long long)row * D + c] = gv;
         }
+    }
+#undef NDDM_FETCH_HALF
+    lds_barrier();
+    if (t < TR * D) { const int r = t / D, c = t - r * D; if (r0 + r < Q.R) U.gx[(long long)(r0 + r) * D + c] = gout_s[r][c]; }
+    for (int p = t; p < TR * Q.C; p += NTB) {
+        const int r = p / Q.C, c = p - r * Q.C;
+        if (r0 + r < Q.R) U.gcond[(long long)(r0 + r) * Q.C + c] = gcond_s[r][c];
     }
 }
 
@@ -616,8 +647,8 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
 }
 
 /* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results -- or, with
- * g_nll (the gradient of the forward's nll, a device scalar) not NULL, scratch of those sizes that the kernel fills itself.
- * Scratch: gz_all [L, R, D], gy2 [R, D - d1], work [2 L, R, 2 * 128 + 16].  gx [R, D] ends as the gradient of theta, gcond [R, C]
+ * g_nll (the gradient of the forward's nll, a device scalar) not NULL, g_z unused and g_ld [R] scratch that the kernel fills.
+ * Scratch: gz_all [L, R, D], work [2 L, R, 2 * 128 + 16] (gy2: unused).  gx [R, D] ends as the gradient of theta, gcond [R, C]
  * as that of the condition. */
 int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         void *const *grads, const float *theta, const float *cond, float *z_all, float *out_all, float *s_all,
@@ -635,22 +666,19 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
         float *const *g = reinterpret_cast<float *const *>(grads) + 14 * l;
         const float *x = l ? out_all + (l - 1) * RD : theta;
         const float *z = z_all + l * RD, *out = out_all + l * RD, *sl = s_all + l * RD, *h = h_all + 4 * l * RH;
-        const float *g_out = l == L - 1 ? g_z : gx;
         float *gz = gz_all + l * RD, *wa = work + (2 * l) * RW, *wb = work + (2 * l + 1) * RW;
-        // sub-network 2 (runs first): d out[:, :d1] -> d z[:, :d1] (written), d out[:, d1:] through its input (gy2), d cond
-        TD.half[2 * l + 1] = {z, q[8], q[10], q[12], sl + d2, h + 2 * RH, h + 3 * RH, g_out, nullptr,
-                              gy2, gz, wb, wb + RH, wb + 2 * RH, d2, d1, d2, 0, l != L - 1, -1};
+        // sub-network 2 (runs first): conditioned on out[:, d1:], transformed z[:, :d1]
+        TD.half[2 * l + 1] = {z, q[8], q[10], q[12], sl + d2, h + 2 * RH, h + 3 * RH, wb, wb + RH, wb + 2 * RH, d2, d1};
         TW.half[2 * l + 1] = {out + d1, h + 2 * RH, h + 3 * RH, wb, wb + RH, wb + 2 * RH, g[8], g[9], g[10], g[11], g[12], g[13], d2, d1, -1, 0};
-        // sub-network 1: d out[:, d1:] + gy2 -> d z[:, d1:] (written), d z[:, :d1] and d cond (accumulated)
-        TD.half[2 * l] = {z + d1, q[2], q[4], q[6], sl, h, h + RH, g_out + d1, gy2,
-                          gz, gz + d1, wa, wa + RH, wa + 2 * RH, d1, d2, D, 1, 1, l};
+        // sub-network 1: conditioned on z[:, :d1], transformed z[:, d1:]
+        TD.half[2 * l] = {z + d1, q[2], q[4], q[6], sl, h, h + RH, wa, wa + RH, wa + 2 * RH, d1, d2};
         TW.half[2 * l] = {z, h, h + RH, wa, wa + RH, wa + 2 * RH, g[2], g[3], g[4], g[5], g[6], g[7], d1, d2, l, 0};
         TD.norm[l] = {q[0], gz, {}};
         TW.norm[l] = {x, q[0], gz, g[0], g[1], {}};
         for (int d = 0; d < D; ++d) TD.norm[l].perm[d] = TW.norm[l].perm[d] = (unsigned char)perm[l * D + d];
     }
     const FlowDims Q = {L, R, D, d1, C, clamp};
-    const FlowBwdBuf U = {g_ld, gx, gcond, g_nll, g_z, g_ld, out_all + (long long)(L - 1) * RD};
+    const FlowBwdBuf U = {g_z, g_ld, gx, gcond, g_nll, g_ld, out_all + (long long)(L - 1) * RD};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(flow_dgrad_kernel, dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
     hipLaunchKernelGGL(flow_wgrad_kernel, dim3(2 * L), dim3(NTB), 0, st, Q, TW, cond, static_cast<const float *>(g_ld));
