@@ -28,8 +28,8 @@ def lib():
     #                               L    R    D    d1   C    clamp params perm theta cond z_all out_all s_all h_all ld nll stream
     L.nddm_train_flow_fwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
     L.nddm_train_flow_fwd.restype = i32
-    #                               ... params perm grads theta cond z_all out_all s_all h_all g_z g_ld g_nll gz_all gy2 gx gcond work stream
-    L.nddm_train_flow_bwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
+    #                               ... params perm grads theta cond z_all out_all s_all h_all g_z g_ld g_nll gz_all gx gcond work stream
+    L.nddm_train_flow_bwd.argtypes = [i32, i32, i32, i32, i32, f32, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
     L.nddm_train_flow_bwd.restype = i32
     L.nddm_deepset_supported.argtypes = [i32, i32]
     L.nddm_deepset_supported.restype = i32

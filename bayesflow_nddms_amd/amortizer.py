@@ -298,7 +298,7 @@ class _FusedFlowFn(torch.autograd.Function):
         n_rd = nl * R * D
         sizes = [p.numel() for p in params]
         Hd = params[4].shape[0]
-        n_scratch = [nl * R * D, R * D, R * D, R * (D - d1), R * C, R, 2 * nl * R * (2 * Hd + 16)]
+        n_scratch = [nl * R * D, R * D, R * C, R, 2 * nl * R * (2 * Hd + 16)]
         flat = torch.empty(sum(sizes) + sum(n_scratch), dtype=torch.float32, device=dev)
         grads, o = [], 0
         for p, n in zip(params, sizes):
@@ -308,9 +308,9 @@ class _FusedFlowFn(torch.autograd.Function):
         for n in n_scratch:
             scratch.append(flat[o:o + n])
             o += n
-        gz_all, gx, w_gz, gy2, gcond, w_gld, work = scratch
+        gz_all, gx, gcond, w_gld, work = scratch
         if ctx.nll:
-            g_nll, g_z, g_ld = gs[0].contiguous(), w_gz, w_gld
+            g_nll, g_z, g_ld = gs[0].contiguous(), None, w_gld
         else:
             g_nll = None
             g_z = gs[0].contiguous() if gs[0] is not None else torch.zeros_like(theta)
@@ -318,8 +318,8 @@ class _FusedFlowFn(torch.autograd.Function):
         gptr = (ctypes.c_void_p * (14 * nl))(*[g.data_ptr() for g in grads])
         sp, F = saved.data_ptr(), 4
         rc = L.nddm_train_flow_bwd(nl, R, D, d1, C, ctx.clamp, ctx.ptrs, ctx.perm, gptr, theta.data_ptr(), cond.data_ptr(),
-                                   sp, sp + n_rd * F, sp + 2 * n_rd * F, sp + 3 * n_rd * F, g_z.data_ptr(), g_ld.data_ptr(),
-                                   None if g_nll is None else g_nll.data_ptr(), gz_all.data_ptr(), gy2.data_ptr(), gx.data_ptr(),
+                                   sp, sp + n_rd * F, sp + 2 * n_rd * F, sp + 3 * n_rd * F, None if g_z is None else g_z.data_ptr(),
+                                   g_ld.data_ptr(), None if g_nll is None else g_nll.data_ptr(), gz_all.data_ptr(), gx.data_ptr(),
                                    gcond.data_ptr(), work.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"nddm_train_flow_bwd failed ({rc})")

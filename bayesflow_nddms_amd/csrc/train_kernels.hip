@@ -39,15 +39,6 @@ __device__ int g_nstamps;
 __device__ __forceinline__ float elu(float v) { return v > 0.0f ? v : expm1f(v); }
 __device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }   // alpha = 1
 
-struct Args {
-    const float *xh; int ldh, Dh;         // [R, Dh] with row stride ldh: the conditioning half
-    const float *cond; int C;             // [R, C]
-    const float *xtr; int ldt, Dt;        // [R, Dt] with row stride ldt: the transformed half
-    const float *W1, *b1, *W2, *b2, *W3, *b3;   // [H, Dh+C], [H], [H, H], [H], [2 Dt, H], [2 Dt]
-    float clamp;
-    int R;
-};
-
 // ------------------------------------------------------------------------------------------------ forward
 // grid = ceil(R / TRF) workgroups of 256 threads over tiles of TRF = 8 rows (four workgroups at batch 32: the work is latency,
 // not arithmetic, so it is spread), each taking its rows through every layer.  What a row carries from half-layer to half-layer
@@ -647,12 +638,13 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
 }
 
 /* grads: L x 14 device pointers, the layout of params.  g_z [R, D], g_ld [R]: gradients of the forward's two results -- or, with
- * g_nll (the gradient of the forward's nll, a device scalar) not NULL, g_z unused and g_ld [R] scratch that the kernel fills.
- * Scratch: gz_all [L, R, D], work [2 L, R, 2 * 128 + 16] (gy2: unused).  gx [R, D] ends as the gradient of theta, gcond [R, C]
+ * g_nll (the gradient of the forward's nll, a device scalar) not NULL, g_z unused (may be NULL) and g_ld [R] scratch that the
+ * kernel fills.
+ * Scratch: gz_all [L, R, D], work [2 L, R, 2 * 128 + 16].  gx [R, D] ends as the gradient of theta, gcond [R, C]
  * as that of the condition. */
 int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         void *const *grads, const float *theta, const float *cond, float *z_all, float *out_all, float *s_all,
-                        float *h_all, float *g_z, float *g_ld, const float *g_nll, float *gz_all, float *gy2, float *gx, float *gcond,
+                        float *h_all, const float *g_z, float *g_ld, const float *g_nll, float *gz_all, float *gx, float *gcond,
                         float *work, void *stream)
 {
     if (!nddm_train_flow_supported(H, L, D, d1, C) || R <= 0) return 1;
