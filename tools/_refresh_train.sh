@@ -14,3 +14,8 @@ cd $ROOT
 python3 tools/train_trace_summary.py $(dirname $(find gpurun_out/train_trace -name "*kernel_trace.csv" | head -1)) > $OUT/r3_train_graph_trace.md 2>&1 && echo ok summary
 cp $(find gpurun_out/train_trace -name "*kernel_stats.csv" | head -1) $OUT/r3_train_graph_kernel_stats.csv
 rm -rf gpurun_out/train_trace
+run() { name=$1; shift; python3 bench.py "$@" > "$OUT/$name" 2> "$OUT/$name.err" && echo "ok $name" || { echo "FAILED $name"; tail -3 "$OUT/$name.err"; }; }
+run r3_bench_dist_summary_world1.json --dist --backend nccl --gather summary --no-ceiling --no-ks --no-cpu-baseline
+run r3_bench_dist_trials_world1.json --dist --backend nccl --gather trials --no-ceiling --no-ks --no-cpu-baseline
+run r3_bench_dist_codes_world1.json --dist --backend nccl --gather codes --no-ceiling --no-ks --no-cpu-baseline
+(python3 tools/train_stamps.py flow 0; python3 tools/train_stamps.py deepset 0) 2>&1 | grep -v "amdgpu.ids" > $OUT/r3_train_stamps.txt && echo ok stamps
