@@ -272,9 +272,9 @@ struct FlowBwdBuf {
 // the barriers order LDS traffic only (nothing here reads global memory that the kernel wrote): as in the forward.
 __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, FlowBwdBuf U)
 {
-    __shared__ float h1r[TR][LDR];        // [row][unit]
-    __shared__ float h2r[TR][LDR];        // later: d(pre-activation 1)
-    __shared__ float da2r[TR][LDR];       // d(pre-activation 2)
+    __shared__ __attribute__((aligned(16))) float h1r[TR][LDR];        // [row][unit]
+    __shared__ __attribute__((aligned(16))) float h2r[TR][LDR];        // later: d(pre-activation 1)
+    __shared__ __attribute__((aligned(16))) float da2r[TR][LDR];       // d(pre-activation 2); later: partial tiles of the input gradient
     __shared__ float do_s[TR][M_MAX];
     __shared__ float w2s[H][LDW2];
     __shared__ float w1s[H][DI_MAX + 1];
@@ -382,19 +382,25 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         }
         lds_barrier();
         STAMP(13);
-        // d in: (row, column) pairs, `parts` adjacent lanes each (a power of two: every thread busy for 512 pairs or fewer)
-        {
-            const int npairs = TR * DI, parts = npairs <= NTB / 4 ? 4 : (npairs <= NTB / 2 ? 2 : 1), span = H / parts;
-            const int pr = t / parts, part = t - pr * parts;
-            const int r = pr / DI, c = pr - r * DI;
-            float acc = 0.0f;
-            if (pr < npairs) {
-#pragma unroll 8
-                for (int jj = part * span; jj < (part + 1) * span; ++jj) acc = fmaf(w1s[jj][c], h2r[r][jj], acc);
+        {   // d in = d(a1) W1, [TR x DI] with k over the H units: wave -> (row block, column block, a quarter of the k's), 8 MFMAs;
+            // the four partial tiles are summed through LDS in fixed order.  Lane l: A[row l & 15][k], B[k][column l & 15] for
+            // k = 32 q + 8 (l >> 4) + s, s = 0 .. 7.  (Columns >= DI of w1s are never written: they only reach columns >= DI.)
+            const int n = lane & 15, kk = lane >> 4, rb = wave & 1, cb = (wave >> 1) & 1, q = wave >> 2;
+            float (*part)[TR][DI_MAX + 1] = reinterpret_cast<float (*)[TR][DI_MAX + 1]>(&da2r[0][0]);    // (da2r's readers are done)
+            if (16 * cb < DI) {
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float *ap = &h2r[16 * rb + n][32 * q + 8 * kk], *bp = &w1s[32 * q + 8 * kk][16 * cb + n];
+                const float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = *reinterpret_cast<const float4 *>(ap + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], bp[s_ * (DI_MAX + 1)], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part[q][16 * rb + 4 * kk + v][16 * cb + n] = acc[v];
             }
-            if (parts >= 2) acc += __shfl_xor(acc, 1);
-            if (parts >= 4) acc += __shfl_xor(acc, 2);
-            if (pr < npairs && part == 0) {
+            lds_barrier();
+            if (t < TR * DI) {
+                const int r = t / DI, c = t - r * DI;
+                const float acc = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
                 if (c >= X.Dh) gcond_s[r][c - X.Dh] += acc;
                 else if (second) gy2_s[r][c] = acc;      // net 2 is conditioned on out[:, d1:]
                 else gz_s[r][c] += acc;                  // net 1 on z[:, :d1], which net 2 also transformed
