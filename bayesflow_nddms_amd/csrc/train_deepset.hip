@@ -96,11 +96,16 @@ __device__ __forceinline__ f32x16 zero16()
 // a multiple of 4)
 __device__ __forceinline__ void stage64(float (*dst)[LD], const float *src, int ldw, int t, int rows = HS)
 {
-    for (int p = t; p < HS * HS / 4; p += NT) {
-        const int r = p >> 4, c4 = p & 15;
-        float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (r < rows) v = *reinterpret_cast<const float4 *>(src + (long long)r * ldw + 4 * c4);
-        *reinterpret_cast<float4 *>(&dst[r][4 * c4]) = v;
+    float4 v[HS * HS / 4 / NT];
+#pragma unroll                                       // all loads first (from a clamped row: no branch), then the stores
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        v[k] = *reinterpret_cast<const float4 *>(src + (long long)min(r, rows - 1) * ldw + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        *reinterpret_cast<float4 *>(&dst[r][4 * c4]) = r < rows ? v[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -172,22 +177,12 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     const int n_begin = sp * C.rows_per_wg, n_end = min(C.N, n_begin + C.rows_per_wg);
     const long long row0 = (long long)b * C.N;
     STAMP(100);
-    stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t, C.d_out);
-    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
-    else
-        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
-    context(C, b, pooled, cs, t);
-    __syncthreads();
-    const int u = 32 * ub + m;                       // this lane's column of every result tile
     const float inv_n = inv_count(C);
-    const float bias2 = C.P.b2[u], bias3 = u < C.d_out ? C.P.b3[u] : 0.0f, bias1 = cs[u];
-    float pacc = 0.0f;
-    STAMP(101);
-    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
+    auto load_x_tile = [&](const int n0) {           // rows beyond the workgroup's range: zero
         if (BIG) {
-            for (int p = t; p < TM * HS / 4; p += NT) {
-                const int r = p >> 4, c4 = p & 15, n = n0 + r;
+#pragma unroll
+            for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+                const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
                 float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (n < n_end) v = x_row4(C, row0 + n, c4, inv_n);
                 *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = v;
@@ -198,7 +193,24 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
             }
         }
-        __syncthreads();
+    };
+    load_x_tile(n_begin);                            // (first: its latency runs beside the weights')
+    stage64(w2s, C.P.W2, HS, t);
+    stage64(w3s, C.P.W3, HS, t, C.d_out);
+    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    else
+        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
+    context(C, b, pooled, cs, t);
+    __syncthreads();
+    const int u = 32 * ub + m;                       // this lane's column of every result tile
+    const float bias2 = C.P.b2[u], bias3 = u < C.d_out ? C.P.b3[u] : 0.0f, bias1 = cs[u];
+    float pacc = 0.0f;
+    STAMP(101);
+    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
+        if (n0 != n_begin) {
+            load_x_tile(n0);
+            __syncthreads();
+        }
         STAMP(102);
         if (BIG) {                                   // layer 1
             const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
@@ -298,39 +310,10 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const long long row0 = (long long)b * C.N;
     const float inv_n = inv_count(C);
     STAMP(200);
-    stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t, C.d_out);
-    if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
-    context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
-    if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
-        if (Q.gp_W) {
-            if (t < HS) {
-                float a = 0.0f;
-                for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
-                dsum[t] = a;
-            }
-            __syncthreads();
-            if (t < HS) {
-                float a = 0.0f;
-#pragma unroll 8
-                for (int uu = 0; uu < HS; ++uu) a = fmaf(Q.gp_W[(long long)uu * Q.gp_ldw + t], dsum[uu], a);
-                gp[t] = a * inv_n;
-            }
-        } else if (t < HS) {
-            gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
-        }
-    }
-    __syncthreads();
-    const int u = 32 * ub + m;
-    f32x16 aW1 = zero16(), aW2 = zero16(), aW3 = zero16();
-    float db[3] = {0.0f, 0.0f, 0.0f};                // thread (unit t & 63, rows 16 (t >> 6) ..): column sums of d(pre-activation 1..3)
-    float dw1[DS_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};    // (!BIG) row t & 63 of dW1 over the same rows
-    const int uu = t & 63, rg = t >> 6;
-    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
-        __syncthreads();                             // the previous tile's readers are done
-        STAMP(201);
-        for (int p = t; p < TM * HS / 4; p += NT) {
-            const int r = p >> 4, c4 = p & 15, n = n0 + r;
+    auto load_tile = [&](const int n0) {             // saved activations, input and output gradient (the pooled part: added below)
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
             float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vg = v1, vx = v1;
             if (n < n_end) {
                 const long long o = (row0 + n) * HS + 4 * c4;
@@ -347,11 +330,6 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                     }
                 }
                 if (BIG) vx = x_row4(C, row0 + n, c4, inv_n);
-                if (Q.gpool) {
-                    const float mk = mask_of(C, n);
-                    vg.x = fmaf(mk, gp[4 * c4], vg.x); vg.y = fmaf(mk, gp[4 * c4 + 1], vg.y);
-                    vg.z = fmaf(mk, gp[4 * c4 + 2], vg.z); vg.w = fmaf(mk, gp[4 * c4 + 3], vg.w);
-                }
             }
             *reinterpret_cast<float4 *>(&h1s[r][4 * c4]) = v1;
             *reinterpret_cast<float4 *>(&h2s[r][4 * c4]) = v2;
@@ -363,6 +341,59 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
                 xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
             }
+    };
+    load_tile(n_begin);                              // (first: its latency runs beside the weights')
+    stage64(w2s, C.P.W2, HS, t);
+    stage64(w3s, C.P.W3, HS, t, C.d_out);
+    if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
+    if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
+        if (Q.gp_W) {
+            if (t < HS) {
+                float a = 0.0f;
+                for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
+                dsum[t] = a;
+            }
+            __syncthreads();
+            {   // four threads per unit, 16 independent loads each
+                const int k = t >> 2, q = t & 3;
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a = fmaf(Q.gp_W[(long long)(16 * q + i) * Q.gp_ldw + k], dsum[16 * q + i], a);
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                if (q == 0) gp[k] = a * inv_n;
+            }
+        } else if (t < HS) {
+            gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
+        }
+    }
+    __syncthreads();
+    const int u = 32 * ub + m;
+    f32x16 aW1 = zero16(), aW2 = zero16(), aW3 = zero16();
+    float db[3] = {0.0f, 0.0f, 0.0f};                // thread (unit t & 63, rows 16 (t >> 6) ..): column sums of d(pre-activation 1..3)
+    float dw1[DS_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};    // (!BIG) row t & 63 of dW1 over the same rows
+    const int uu = t & 63, rg = t >> 6;
+    for (int n0 = n_begin; n0 < n_end; n0 += TM) {
+        if (n0 != n_begin) {
+            __syncthreads();                         // the previous tile's readers are done
+            load_tile(n0);
+        }
+        STAMP(201);
+        if (Q.gpool) {                               // the pooled output's gradient, spread over the set's real trials
+            if (n0 != n_begin) __syncthreads();
+#pragma unroll
+            for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+                const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
+                if (n < n_end) {
+                    const float mk = mask_of(C, n);
+                    float4 vg = *reinterpret_cast<float4 *>(&gs[r][4 * c4]);
+                    vg.x = fmaf(mk, gp[4 * c4], vg.x); vg.y = fmaf(mk, gp[4 * c4 + 1], vg.y);
+                    vg.z = fmaf(mk, gp[4 * c4 + 2], vg.z); vg.w = fmaf(mk, gp[4 * c4 + 3], vg.w);
+                    *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = vg;
+                }
+            }
+        }
         __syncthreads();
         STAMP(202);
         // layer 3: dW3 [unit out, unit in] += g^T h2 (the k's are the tile's rows); d h2 = g W3 -> d(pre-activation 2)
