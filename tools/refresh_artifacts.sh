@@ -1,5 +1,5 @@
 #!/bin/bash
-# Re-collect every bench artifact that profiles/README.md lists (run on the GPU box through gpurun; ~8 min; the default bench
+# Re-collect every bench artifact that profiles/README.md lists (run on the GPU box through gpurun; ~10 min; the default bench
 # line now includes BASELINE configs[0] at full size, ~35 s of CPU time per model that has a NumPy port).
 # Writes gpurun_out/art/*; copy what you want judged into profiles/ (tools/refresh_artifacts.sh does not touch profiles/).
 set -o pipefail
@@ -26,3 +26,10 @@ python3 bench.py --gpus 2 --share-device --backend gloo --train --train-iters 60
 python3 tools/overlap_probe.py > "$OUT/r3_overlap_probe.txt" 2>&1 && echo "ok overlap_probe"
 python3 tools/quick_time.py > "$OUT/r3_quick_time.txt" 2>&1 && echo "ok quick_time"
 python3 tools/wave_timeline.py 0:1000000:300:0.001:4000 0:1000000:300:0.01:400 0:1000000:60:0.01:400 0:30000:300:0.001:4000 0:10000:300:0.001:4000 > "$OUT/r3_wave_timeline.txt" 2>&1 && echo "ok wave_timeline"
+(python3 tools/recovery_probe.py 3000; python3 tools/recovery_probe.py 20000) 2>&1 | grep -v "amdgpu.ids" > "$OUT/r3_recovery.txt" && echo "ok recovery"
+(python3 tools/train_stamps.py flow 0; python3 tools/train_stamps.py deepset 0) 2>&1 | grep -v "amdgpu.ids" > "$OUT/r3_train_stamps.txt" && echo "ok train_stamps"
+# rocprofv3 kernel trace of the graph-replayed training loop -> kernels per iteration, GPU busy fraction
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/train_trace" -o train --output-format csv -- python3 "$ROOT/bench.py" --train --train-mode graph > "$OUT/train_trace_bench.json" 2> "$OUT/train_trace.err") && echo "ok train_trace"
+python3 tools/train_trace_summary.py "$(dirname "$(find gpurun_out/train_trace -name '*kernel_trace.csv' | head -1)")" > "$OUT/r3_train_graph_trace.md" 2>&1 && echo "ok train_trace_summary"
+cp "$(find gpurun_out/train_trace -name '*kernel_stats.csv' | head -1)" "$OUT/r3_train_graph_kernel_stats.csv"
+rm -rf gpurun_out/train_trace
