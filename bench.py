@@ -651,6 +651,7 @@ def train_bench(a, ctx):
     from bayesflow_nddms_amd import basic_ddm_dc
     from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
     from bayesflow_nddms_amd.distributed import shared_prior_N
+    from bayesflow_nddms_amd import _train_lib
     from bayesflow_nddms_amd.graph_trainer import GraphTrainer
     from bayesflow_nddms_amd.priors import DevicePrior
     Bl, warm = a.batch, 10
@@ -817,7 +818,9 @@ def train_bench(a, ctx):
                                    f"N ~ U{{60..300}} per batch, dt=.01/max 400 (reference default; dt=.001/4000 also reported), "
                                    f"device prior -> simulate -> DeepSet + 6-layer coupling flow, Adam; {driver}",
                        "arithmetic": ARITHMETIC, "parallelism": par, "backend": a.backend,
-                       "train_mode": a.train_mode},
+                       "train_mode": a.train_mode,
+                       # libnddm_train.so (flow, summary network, optimizer step as HIP kernels) or the PyTorch composition
+                       "training_kernels": "libnddm_train.so" if _train_lib.lib() is not None else "PyTorch (library not built)"},
             "loss_first10": ref["loss_first10"], "loss_last10": ref["loss_last10"],
             "train": results})
 

@@ -132,6 +132,7 @@ def test_bench_train_ddp_at_world_1_over_rccl():
                          "--train-iters", "30", env=env, timeout=1200))
     assert d["n_gpus"] == 1 and d["loss_last10"] < d["loss_first10"]
     assert d["train"]["dt.01_max400"]["graph"]["two_graphs_with_collective_between"] is True
+    assert d["config"]["training_kernels"] == "libnddm_train.so"      # (a silent fall-back to PyTorch would be a 4 x slower line)
 
 
 def test_bench_refuses_more_ranks_than_gpus_in_the_parent():
