@@ -69,3 +69,24 @@ def test_trainer_loops_reduce_loss_and_checkpoint(tmp_path):
     d = conf(gm(4))
     assert torch.allclose(am.compute_loss(d), am2.compute_loss(d))
     assert len(tr2.loss_history) == len(tr.loss_history)
+
+
+def test_padded_batches_pool_over_the_real_trials_only():
+    """The three ways to say "the first n of these N trials are real" give the unpadded batch's summary: a 0/1 mask with
+    1/n, the count as a scalar tensor (what the graph trainer passes, `summary_n`), and simply not padding."""
+    import torch
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    torch.manual_seed(1)
+    net = InvariantNetwork()
+    B, N, n = 4, 50, 37
+    x = torch.randn(B, N, 2)
+    want = net(x[:, :n])
+    mask = (torch.arange(N) < n).float().view(1, N, 1)
+    assert torch.allclose(net(x, mask, torch.tensor(1.0 / n)), want, atol=1e-5)
+    assert torch.allclose(net(x, n_valid=torch.tensor([float(n)])), want, atol=1e-5)
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), net)
+    theta = torch.randn(B, 5)
+    direct = torch.full((B, 1), 3.6)
+    a = am.compute_loss({"summary_conditions": x, "summary_n": torch.tensor([float(n)]), "direct_conditions": direct, "parameters": theta})
+    b = am.compute_loss({"summary_conditions": x[:, :n], "direct_conditions": direct, "parameters": theta})
+    assert torch.allclose(a, b, atol=1e-5)
