@@ -17,6 +17,7 @@ PyTorch modules; on the GPU the flow and the summary network's per-trial MLPs ru
 (csrc/train_kernels.hip, csrc/train_deepset.hip -- at batch 32 the PyTorch composition is ~600 launches of a few
 microseconds per training iteration), with the PyTorch composition as the definition they are tested against.
 """
+import math
 import os
 import pickle
 
@@ -105,6 +106,12 @@ class InvariantNetwork(nn.Module):
         """libnddm_train.so if its per-trial MLP kernels cover this network and this tensor, else None (the PyTorch composition)."""
         if not (self.fused and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] >= 1):
             return None
+        # the kernels are the TRAINING path: their forward always stores every hidden activation for the backward (2.5 KB per
+        # trial row) and the backward one partial weight-gradient block per 64 rows.  Inference (no_grad: validation_loss,
+        # sample) and batches beyond FUSED_MAX_ROWS trial rows take the PyTorch composition, which keeps nothing; and the
+        # kernels produce no gradient of the data.
+        if not torch.is_grad_enabled() or x.shape[0] * x.shape[1] > self.FUSED_MAX_ROWS or x.requires_grad:
+            return None
         mlps = [m for blk in self.equiv for m in (blk.inv, blk.eq)] + [self.pre_pool, self.post_pool]
         if any(len(m) != 5 or not isinstance(m[1], nn.ReLU) or m[2].weight.shape != (64, 64) or m[4].weight.shape[1] != 64
                for m in mlps) or any(m[4].weight.shape[0] != 64 for m in mlps[:-1]) or not 1 <= self.summary_dim <= 64:
@@ -112,6 +119,8 @@ class InvariantNetwork(nn.Module):
         from . import _train_lib
         L = _train_lib.lib()
         return L if L is not None and L.nddm_deepset_supported(64, x.shape[2]) else None
+
+    FUSED_MAX_ROWS = 1 << 19      # sets x trials (the training loop's 32 x 300 is 9600): 1.3 GB of saved activations at the cap
 
     def forward(self, x, mask=None, inv_n=None, n_valid=None):
         """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors -- or
@@ -373,7 +382,8 @@ class InvertibleNetwork(nn.Module):
         for i in range(num_coupling_layers):
             perm = torch.randperm(num_params, generator=g)
             self.register_buffer(f"perm{i}", perm)
-            self.register_buffer(f"pmat{i}", torch.eye(num_params)[:, perm].contiguous())
+            # (derived from perm{i}: not part of the state dict, rebuilt after a load -- a mismatched pair cannot be loaded)
+            self.register_buffer(f"pmat{i}", torch.eye(num_params)[:, perm].contiguous(), persistent=False)
         # one parameter per layer (not rows of one matrix: selecting a row costs autograd a zero-fill and a copy each way)
         self.an_scale = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
         self.an_bias = nn.ParameterList(nn.Parameter(torch.zeros(num_params)) for _ in range(num_coupling_layers))
@@ -416,6 +426,22 @@ class InvertibleNetwork(nn.Module):
 
     def _refresh_host_perms(self, *_):
         self._perm_host = [getattr(self, f"perm{i}").tolist() for i in range(len(self.layers))]
+        with torch.no_grad():
+            for i, perm in enumerate(self._perm_host):
+                pm = getattr(self, f"pmat{i}")
+                pm.copy_(torch.eye(self.num_params)[:, perm])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Checkpoints of earlier layouts: ActNorm's log-scale and bias were ONE [layers, D] tensor each (now one parameter per
+        layer, `an_scale.0` ...), and `pmat{i}` used to be stored (now derived from `perm{i}`)."""
+        for name in ("an_scale", "an_bias"):
+            old = state_dict.pop(prefix + name, None)
+            if old is not None:
+                for i in range(old.shape[0]):
+                    state_dict.setdefault(f"{prefix}{name}.{i}", old[i].clone())
+        for i in range(len(self.layers)):
+            state_dict.pop(f"{prefix}pmat{i}", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, theta, cond):
         L = self._fused_lib(theta, cond)
@@ -500,6 +526,7 @@ class Trainer:
         self.lr = learning_rate
         self.optimizer = torch.optim.Adam(self.amortizer.parameters(), lr=learning_rate)
         self.scheduler = None
+        self._optimizer_spent = False      # set when a train_* call ends with reuse_optimizer=False (BayesFlow's default)
         self.stream_state = stream_state
         self.loss_history = []
         self.replay = []
@@ -517,8 +544,26 @@ class Trainer:
             self.scheduler.step()
         return float(loss.detach())
 
-    def _setup_schedule(self, total_steps):
-        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=max(1, total_steps))
+    def _setup_schedule(self, total_steps, optimizer=None, scheduler=None):
+        """`optimizer` given (BayesFlow's train_*(optimizer=...)): the caller's optimizer -- and learning-rate scheduler, if
+        any -- is used as it is; nothing is reset (one schedule can then span several calls).  Otherwise:
+        every train_* call is a run of its own, as in BayesFlow 1.1's Trainer: a cosine decay from the Trainer's learning
+        rate over THIS call's epochs x iterations (held at its final value beyond, like Keras' CosineDecay) and -- unless the
+        previous call was made with reuse_optimizer=True, or a checkpoint has just been loaded -- a fresh Adam.  (Stacking a
+        second CosineAnnealingLR on an optimizer whose rate the first one had annealed to 0 trained the second call, and every
+        resumed run, at rate 0.)"""
+        if optimizer is not None:
+            self.optimizer, self.scheduler, self._optimizer_spent = optimizer, scheduler, False
+            return
+        if self._optimizer_spent:
+            self.optimizer = torch.optim.Adam(self.amortizer.parameters(), lr=self.lr)
+            self._optimizer_spent = False
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.lr
+            g["initial_lr"] = self.lr
+        total = max(1, int(total_steps))
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(
+            self.optimizer, lambda step: 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total)))
 
     def _prefetcher(self, batch_size, total):
         """Yields `total` configured batches, simulating batch i+1 on a side stream BEFORE batch i is trained on: the
@@ -550,8 +595,9 @@ class Trainer:
                 nxt = launch()
             yield conf
 
-    def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, prefetch=True, **_):
-        self._setup_schedule(epochs * iterations_per_epoch)
+    def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, prefetch=True, reuse_optimizer=False,
+                     optimizer=None, scheduler=None, **_):
+        self._setup_schedule(epochs * iterations_per_epoch, optimizer, scheduler)
         for ep in range(epochs):
             batches = (self._prefetcher(batch_size, iterations_per_epoch) if prefetch
                        else (self._simulate(batch_size) for _ in range(iterations_per_epoch)))
@@ -559,14 +605,16 @@ class Trainer:
                 self.loss_history.append(self._step(conf))
             if save_checkpoint:
                 self.save_checkpoint()
+        self._optimizer_spent = not (reuse_optimizer or optimizer is not None)
         return self.loss_history
 
     def train_experience_replay(self, epochs, iterations_per_epoch, batch_size, capacity_in_batches=100,
-                                save_checkpoint=True, validation_sims=None, prefetch=True, **_):
+                                save_checkpoint=True, validation_sims=None, prefetch=True, reuse_optimizer=False,
+                                optimizer=None, scheduler=None, **_):
         """Each iteration simulates one fresh batch into a ring buffer of `capacity_in_batches` batches and trains on
         a randomly chosen stored batch (BayesFlow's experience replay, used at basic_ddm_dc.py:199-202).  Batches keep
         their own N (the non-batchable context), as in BayesFlow's buffer."""
-        self._setup_schedule(epochs * iterations_per_epoch)
+        self._setup_schedule(epochs * iterations_per_epoch, optimizer, scheduler)
         rng = np.random.default_rng(0)
         val = []
         for ep in range(epochs):
@@ -583,6 +631,7 @@ class Trainer:
                     val.append(float(self.amortizer.compute_loss(self.configurator(validation_sims))))
             if save_checkpoint:
                 self.save_checkpoint()
+        self._optimizer_spent = not (reuse_optimizer or optimizer is not None)
         return {"train_losses": self.loss_history, "val_losses": val}
 
     # ---- checkpoint / resume -----------------------------------------------------------------------
@@ -605,6 +654,7 @@ class Trainer:
         state = torch.load(path, map_location=self.device)
         self.amortizer.load_state_dict(state["model"])
         self.optimizer.load_state_dict(state["optimizer"])
+        self._optimizer_spent = False      # the loaded moments serve the next train_* call (which sets its own schedule)
         self.loss_history = list(state.get("loss_history", []))
         if self.stream_state is not None and "stream_state" in state:
             self.stream_state.set_state(state["stream_state"])

@@ -63,6 +63,26 @@ static int fail(int code, const char *fmt, const char *detail = "")
 
 static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Every entry point that takes a stream validates the handle FIRST, with the one HIP call that checks instead of dereferencing:
+// hipStreamGetDevice answers hipErrorContextIsDestroyed for a destroyed stream, for a stream of another copy of the HIP runtime
+// in the process and for an integer that never was a stream, whereas hipStreamIsCapturing, hipStreamQuery, hipStreamSynchronize,
+// hipEventRecord (and the launch calls) dereference the handle -- a SIGSEGV in the caller's thread (probed call by call on ROCm
+// 7.0: tools/probe_stream_validation.py, profiles/r4_stream_validation.txt).  The stream must also belong to the current device:
+// the launch's memory is taken from that device's slots.
+static int check_stream(hipStream_t st)
+{
+    int sdev = -1, cur = -1;
+    const hipError_t e = hipStreamGetDevice(st, &sdev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NDDM_ERR_HIP, "`stream` is not a live stream of this process's HIP runtime (destroyed, or created by another copy "
+                                  "of the runtime): %s", hipGetErrorString(e));
+    }
+    if (hipGetDevice(&cur) == hipSuccess && st != nullptr && st != hipStreamPerThread && sdev != cur)
+        return fail(NDDM_ERR_PARAM, "`stream` belongs to another device than the current one (nddm_set_device / hipSetDevice)%s");
+    return NDDM_OK;
+}
+
 // ---- process-wide state, all of it behind one mutex -------------------------------------------------------------------
 // Entry points are re-entrant: each call takes a SNAPSHOT of the developer knobs at entry and owns the device memory it is
 // handed (a LaunchSlot) until the work it enqueued has completed.
@@ -203,18 +223,57 @@ static void release_slot(LaunchSlot *s, hipStream_t st)
 
 // Memory of launches captured into a hipGraph: the graph replays with the pointers it captured, at times the library
 // cannot see, so such a launch gets an allocation of its own that nothing else ever uses (queue words + ALL of its
-// scratch).  It lives until nddm_release_graph_memory().
+// scratch).  Every such allocation has an OWNER (ABI 3): the graph arena bound to the capturing thread
+// (nddm_graph_arena_create / _bind / _release), or -- with no arena bound -- the ownerless list that
+// nddm_release_graph_memory() frees.  Releasing one owner never touches what another owner's graphs replay into.
 constexpr size_t GRAPH_SCRATCH_MAX = 64u << 20;
-struct GraphAlloc { void *p; GraphAlloc *next; };
-static GraphAlloc *g_graph_allocs[MAX_DEVICES];
+struct GraphAlloc { void *p; int dev; size_t bytes; GraphAlloc *next; };
+struct GraphArena { uint64_t id; GraphAlloc *list; GraphArena *next; };
+static GraphArena g_ownerless = {0, nullptr, nullptr};
+static GraphArena *g_arenas = nullptr;                 // live arenas (behind g_mu)
+static uint64_t g_next_arena = 1;
+static thread_local uint64_t g_cur_arena = 0;          // the arena captured launches of THIS thread are charged to (0 = none)
+
+static GraphArena *find_arena_locked(uint64_t id)
+{
+    if (id == 0) return &g_ownerless;
+    for (GraphArena *a = g_arenas; a; a = a->next)
+        if (a->id == id) return a;
+    return nullptr;
+}
+
+// hipFree with the calling thread's capture mode relaxed (see malloc_relaxed), on the device the block came from
+static void free_list(GraphAlloc *list)
+{
+    if (!list) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    while (list) {
+        GraphAlloc *n = list->next;
+        if (list->dev != cur && hipSetDevice(list->dev) == hipSuccess) cur = list->dev;
+        (void)hipFree(list->p);
+        delete list;
+        list = n;
+    }
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+}
 
 static char *graph_alloc(int dev, size_t bytes, hipError_t *err)
 {
+    *err = hipSuccess;
+    {   // refuse before allocating when the thread's arena is gone (released while still bound)
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!find_arena_locked(g_cur_arena)) { *err = hipErrorInvalidResourceHandle; return nullptr; }
+    }
     void *p = nullptr;
     *err = malloc_relaxed(&p, bytes);
     if (*err != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
-    g_graph_allocs[dev] = new GraphAlloc{p, g_graph_allocs[dev]};
+    GraphArena *a = find_arena_locked(g_cur_arena);
+    if (!a) a = &g_ownerless;                          // released between the two looks: never leak, never dangle
+    a->list = new GraphAlloc{p, dev, bytes, a->list};
     return static_cast<char *>(p);
 }
 
@@ -343,6 +402,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
                                     "or NDDM_GAUSS_PACKED, max_steps < 2^14%s");
     if (B * (((long long)n_trials + 511) / 512) >= (1ll << 31))
         return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
+
+    if (const int rc = check_stream(reinterpret_cast<hipStream_t>(stream))) return rc;
 
     // snapshot of the developer knobs, and the device this call runs on
     Tuning tun;
@@ -525,6 +586,8 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
             return fail(NDDM_ERR_PARAM, "this launch needs more than 64 MB of scratch and cannot be captured in a hipGraph%s");
         hipError_t e;
         char *mem = graph_alloc(dev, SLOT_QUEUE_BYTES + scratch_bytes, &e);
+        if (!mem && e == hipErrorInvalidResourceHandle)
+            return fail(NDDM_ERR_PARAM, "the graph arena bound to this thread has been released (nddm_graph_arena_bind(0) or a live arena)%s");
         if (!mem) return fail(NDDM_ERR_HIP, "hipMalloc(captured launch): %s", hipGetErrorString(e));
         A.chunk_counter = reinterpret_cast<unsigned int *>(mem);
         scratch = mem + SLOT_QUEUE_BYTES;
@@ -695,16 +758,81 @@ int nddm_debug_set_slot_limit(int n)
     return NDDM_OK;
 }
 
-/* Frees the memory the library allocated for launches that were captured into hipGraphs on the current device.  The
- * caller asserts that every graph that captured a launch of this library has been destroyed (or will not be replayed). */
+/* Frees the OWNERLESS memory behind captured launches of the current device: allocations made for launches that were
+ * captured while no graph arena was bound to the capturing thread.  Memory charged to an arena is not touched (ABI 3; up to
+ * ABI 2 this call freed every captured launch's memory on the device, whoever's graph it belonged to). */
 int nddm_release_graph_memory(void)
 {
+    nddm::g_err[0] = 0;
     int dev = 0;
     const hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= nddm::MAX_DEVICES) return nddm::fail(NDDM_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
-    nddm::GraphAlloc *list;
-    { std::lock_guard<std::mutex> lock(nddm::g_mu); list = nddm::g_graph_allocs[dev]; nddm::g_graph_allocs[dev] = nullptr; }
-    while (list) { nddm::GraphAlloc *n = list->next; (void)hipFree(list->p); delete list; list = n; }
+    nddm::GraphAlloc *mine = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(nddm::g_mu);
+        nddm::GraphAlloc **pp = &nddm::g_ownerless.list;
+        while (*pp) {
+            nddm::GraphAlloc *a = *pp;
+            if (a->dev == dev) { *pp = a->next; a->next = mine; mine = a; }
+            else pp = &a->next;
+        }
+    }
+    nddm::free_list(mine);
+    return NDDM_OK;
+}
+
+/* ---- graph arenas: the owner of the memory behind captured launches ---------------------------------------------------- */
+int nddm_graph_arena_create(uint64_t *arena)
+{
+    nddm::g_err[0] = 0;
+    if (!arena) return nddm::fail(NDDM_ERR_NULL, "arena is NULL%s");
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
+    nddm::GraphArena *a = new nddm::GraphArena{nddm::g_next_arena++, nullptr, nddm::g_arenas};
+    nddm::g_arenas = a;
+    *arena = a->id;
+    return NDDM_OK;
+}
+
+int nddm_graph_arena_bind(uint64_t arena, uint64_t *previous)
+{
+    nddm::g_err[0] = 0;
+    {
+        std::lock_guard<std::mutex> lock(nddm::g_mu);
+        if (!nddm::find_arena_locked(arena)) return nddm::fail(NDDM_ERR_PARAM, "unknown (or released) graph arena%s");
+    }
+    if (previous) *previous = nddm::g_cur_arena;
+    nddm::g_cur_arena = arena;
+    return NDDM_OK;
+}
+
+int nddm_graph_arena_info(uint64_t arena, uint64_t *bytes, int32_t *n_allocations)
+{
+    nddm::g_err[0] = 0;
+    std::lock_guard<std::mutex> lock(nddm::g_mu);
+    const nddm::GraphArena *a = nddm::find_arena_locked(arena);
+    if (!a) return nddm::fail(NDDM_ERR_PARAM, "unknown (or released) graph arena%s");
+    uint64_t b = 0;
+    int32_t n = 0;
+    for (const nddm::GraphAlloc *g = a->list; g; g = g->next) { b += g->bytes; ++n; }
+    if (bytes) *bytes = b;
+    if (n_allocations) *n_allocations = n;
+    return NDDM_OK;
+}
+
+int nddm_graph_arena_release(uint64_t arena)
+{
+    nddm::g_err[0] = 0;
+    if (arena == 0) return nddm::fail(NDDM_ERR_PARAM, "arena 0 is the ownerless list: nddm_release_graph_memory() frees it%s");
+    nddm::GraphArena *a = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(nddm::g_mu);
+        for (nddm::GraphArena **pp = &nddm::g_arenas; *pp; pp = &(*pp)->next)
+            if ((*pp)->id == arena) { a = *pp; *pp = a->next; break; }
+    }
+    if (!a) return nddm::fail(NDDM_ERR_PARAM, "unknown (or already released) graph arena%s");
+    if (nddm::g_cur_arena == arena) nddm::g_cur_arena = 0;      // this thread's binding; another thread's is refused at its next capture
+    nddm::free_list(a->list);
+    delete a;
     return NDDM_OK;
 }
 
@@ -777,6 +905,7 @@ int nddm_decode_codes(int32_t model, const uint16_t *codes, const float *params,
     if (!(dt > 0.0f) || !isfinite(dt)) return nddm::fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
     if (B == 0) return NDDM_OK;
     if (!codes || !params || !out_trials) return nddm::fail(NDDM_ERR_NULL, "null pointer%s");
+    if (const int rc = nddm::check_stream(reinterpret_cast<hipStream_t>(stream))) return rc;
     const long long n = B * (long long)n_trials;
     const int threads = 256;
     hipLaunchKernelGGL(nddm::decode_codes_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0,
@@ -806,6 +935,7 @@ static int draw_prior_impl(int32_t model, int64_t B, uint64_t seed, uint64_t set
     if (B < 0) return nddm::fail(NDDM_ERR_SHAPE, "B < 0%s");
     if (B == 0) return NDDM_OK;
     if (!out_params) return nddm::fail(NDDM_ERR_NULL, "out_params is NULL%s");
+    if (const int rc = nddm::check_stream(reinterpret_cast<hipStream_t>(stream))) return rc;
     const int threads = 256;
     const long long blocks = (B + threads - 1) / threads;
     hipLaunchKernelGGL(nddm::prior_kernel, dim3((unsigned)blocks), dim3(threads), 0,
@@ -846,6 +976,7 @@ int nddm_debug_normals(const uint32_t *counters, int64_t n, uint32_t k0, uint32_
     if (n < 0) return nddm::fail(NDDM_ERR_SHAPE, "n < 0%s");
     if (n == 0) return NDDM_OK;
     if (!counters || !out) return nddm::fail(NDDM_ERR_NULL, "null pointer%s");
+    if (const int rc = nddm::check_stream(reinterpret_cast<hipStream_t>(stream))) return rc;
     const int threads = 256;
     const long long blocks = (n + threads - 1) / threads;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

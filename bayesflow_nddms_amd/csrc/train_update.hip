@@ -31,10 +31,12 @@ __global__ __launch_bounds__(NT) void sqnorm_partial_kernel(const float4 *g, lon
 
 struct Hyper { float grad_scale, clip, lr0, total_steps, beta1, beta2, eps; };
 
-// learning rate of the step that is about to run: 0.5 lr0 (1 + cos(pi step / total))
+// learning rate of the step that is about to run: 0.5 lr0 (1 + cos(pi min(step, total) / total)) -- past `total` steps the rate
+// HOLDS the schedule's final value, as Keras' CosineDecay (BayesFlow's default schedule) does; it does not climb back
 __device__ __forceinline__ float cosine_lr(const Hyper &H, float step_f)
 {
-    return 0.5f * H.lr0 * (1.0f + cosf(step_f * (float)(M_PI / (double)fmaxf(1.0f, H.total_steps))));
+    const float total = fmaxf(1.0f, H.total_steps);
+    return 0.5f * H.lr0 * (1.0f + cosf(fminf(step_f, total) * (float)(M_PI / (double)total)));
 }
 
 __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, float4 *m, float4 *v, long long n4, const float *partial,
@@ -82,7 +84,7 @@ __global__ void counters_kernel(Hyper H, long long *step_i, float *step_f, float
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long s = *step_i;
     *loss_slot *= H.grad_scale;
-    if (loss_cap > 0) loss_buf[s < loss_cap ? s : loss_cap - 1] = *loss_slot;
+    if (loss_cap > 0) loss_buf[s % loss_cap] = *loss_slot;          // a RING: the host drains it before it wraps (GraphTrainer._drain_losses)
     *lr_out = cosine_lr(H, *step_f);
     *step_i = s + 1;
     *step_f += 1.0f;
@@ -93,8 +95,8 @@ __global__ void counters_kernel(Hyper H, long long *step_i, float *step_f, float
 using namespace nddm_update;
 
 /* One optimizer step on flat buffers of n floats (n a multiple of 4, 16-byte aligned): p -= Adam(clip(grad_scale * g)) with the
- * cosine learning rate of step *step_f; then loss_buf[min(*step_i, loss_cap - 1)] = grad_scale * *loss_slot (written back to the
- * slot too), *lr_out = the rate used, and both counters advance.  partial: 256 floats of scratch.  Adam's step count is *step_i + 1. */
+ * cosine learning rate of step min(*step_f, total_steps); then loss_buf[*step_i mod loss_cap] = grad_scale * *loss_slot (written
+ * back to the slot too; the history is a ring the caller reads out before it wraps), *lr_out = the rate used, and both counters advance.  partial: 256 floats of scratch.  Adam's step count is *step_i + 1. */
 extern "C" int nddm_train_adam_step(float *p, const float *g, float *m, float *v, long long n, float *partial, float grad_scale, float clip,
                                     float lr0, float total_steps, float beta1, float beta2, float eps, long long *step_i, float *step_f,
                                     float *lr_out, float *loss_buf, int loss_cap, float *loss_slot, void *stream)

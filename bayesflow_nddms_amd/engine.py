@@ -307,23 +307,81 @@ class debug_trace:
 
 
 def release_graph_memory():
-    """Free the device memory the library holds for launches that were captured into hipGraphs on the current device
-    (include/nddm.h: nddm_release_graph_memory).  Call only after every such graph has been destroyed."""
+    """Free the OWNERLESS memory behind captured launches on the current device: what launches captured with no graph
+    arena bound were given (include/nddm.h: nddm_release_graph_memory).  Memory charged to a GraphArena is never touched."""
     _lib.check(_lib.lib().nddm_release_graph_memory())
 
 
-class graph_memory:
-    """Owner of the library memory behind captured launches: `with engine.graph_memory(): ...capture, replay, delete the
-    graphs...` releases it on exit.  Every captured launch pins an allocation of its own (queue words + scratch) until
-    then, so a loop that re-captures -- one graph per n_trials bucket, say -- grows without an owner (amortizer.GraphTrainer
-    is one)."""
+class GraphArena:
+    """Owner of the library memory behind captured launches (include/nddm.h: nddm_graph_arena_*).  Every launch captured
+    into a hipGraph pins an allocation of its own (queue words + scratch); launches captured inside `with arena.bound():`
+    are charged to this arena, and `release()` frees exactly those -- another owner's graphs keep replaying.  The holder
+    destroys its graphs first, then releases."""
+
+    def __init__(self):
+        import ctypes
+        h = ctypes.c_uint64(0)
+        _lib.check(_lib.lib().nddm_graph_arena_create(ctypes.byref(h)))
+        self.handle = int(h.value)
+
+    def bound(self):
+        """Context manager: captured launches of THIS thread are charged to the arena inside the block."""
+        return _ArenaBinding(self)
+
+    def info(self):
+        import ctypes
+        b, n = ctypes.c_uint64(0), ctypes.c_int32(0)
+        _lib.check(_lib.lib().nddm_graph_arena_info(self.handle, ctypes.byref(b), ctypes.byref(n)))
+        return {"bytes": int(b.value), "allocations": int(n.value)}
+
+    @property
+    def released(self):
+        return self.handle == 0
+
+    def release(self):
+        """Free the arena's memory (idempotent).  Call after its graphs have been destroyed and the device is idle with
+        respect to them."""
+        if self.handle:
+            h, self.handle = self.handle, 0
+            _lib.check(_lib.lib().nddm_graph_arena_release(h))
+
+
+class _ArenaBinding:
+    def __init__(self, arena):
+        self.arena, self.prev = arena, None
 
     def __enter__(self):
-        return self
+        import ctypes
+        if self.arena.released:
+            raise RuntimeError("this GraphArena has been released")
+        prev = ctypes.c_uint64(0)
+        _lib.check(_lib.lib().nddm_graph_arena_bind(self.arena.handle, ctypes.byref(prev)))
+        self.prev = int(prev.value)
+        return self.arena
 
     def __exit__(self, *exc):
+        L = _lib.lib()
+        if L.nddm_graph_arena_bind(self.prev, None) != 0:      # the outer owner was released meanwhile: no owner
+            L.nddm_graph_arena_bind(0, None)
+        return False
+
+
+class graph_memory:
+    """`with engine.graph_memory(): ...capture, replay, delete the graphs...`: an arena of its own is bound for the block
+    and released on exit -- only what was captured INSIDE the block is freed (a GraphTrainer alive beside it, or an outer
+    graph_memory block, keeps its memory).  A loop that re-captures -- one graph per n_trials bucket, say -- grows
+    without an owner."""
+
+    def __enter__(self):
+        self.arena = GraphArena()
+        self._binding = self.arena.bound()
+        self._binding.__enter__()
+        return self.arena
+
+    def __exit__(self, *exc):
+        self._binding.__exit__(*exc)
         require_device().cuda.synchronize()
-        release_graph_memory()
+        self.arena.release()
         return False
 
 

@@ -4,7 +4,8 @@ generative model feeding `trainer.train_*(batch_size=32)`) with every iteration 
     device prior -> simulate (HIP kernels, C ABI) -> configurator -> DeepSet + coupling flow forward -> backward
     -> gradient clipping -> Adam (+ cosine learning-rate schedule, + the loss stored into a device buffer)
 
-(at one rank as two graphs on two streams: the simulation of batch i + 1 runs beside the training step on batch i)
+(as graphs on two or three streams: the simulation of batch i + 1 -- and, with more than one rank, the all-gather that
+reassembles it -- runs beside the training step on batch i)
 
 The eager loop (amortizer.Trainer) spends ~10 ms of host time per iteration launching ~1000 small kernels and reads the
 loss back every step; the MI355X is busy for a few per cent of it.  Here the host's share of an iteration is: draw the
@@ -24,8 +25,11 @@ What makes the iteration capturable:
 More than one rank (`world` > 1, one process per GPU): `parallel='gather'` keeps north_star's shape -- every rank simulates
 its shard, ONE all-gather reassembles the minibatch, every rank runs the same training step (replicated); `parallel='ddp'`
 shards the training too -- every rank trains on its own shard and the flat gradient buffer is all-reduced.  The collective
-sits BETWEEN two graphs (simulate [+ forward/backward] | collective | [forward/backward +] clip + Adam): RCCL calls are not
-captured.
+sits BETWEEN two graphs (simulate | all-gather | forward/backward + clip + Adam; simulate | forward/backward | all-reduce |
+clip + Adam): RCCL calls are not captured.  The feed is PIPELINED at every world size: simulate (i + 1) and its all-gather go
+to the simulate and communication streams while the training stream works on batch i; only the gradient all-reduce of `ddp`
+stays on the critical path, between its two graphs.  Replicas are made identical at construction and after a checkpoint load
+(weights, buffers, Adam's moments and the counters are broadcast from rank 0).
 
 PyTorch is plumbing here (autograd nodes, the caching allocator, graphs): the simulator is the library's, and so -- where
 libnddm_train.so builds -- are the networks' forward / backward (amortizer.py) and the optimizer step on flat buffers
@@ -52,10 +56,12 @@ class GraphTrainer:
     def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=16, dt=0.01,
                  max_steps=400.0, seed=2023, learning_rate=5e-4, clip=5.0, device=None, use_graph=True,
                  world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic", overlap=True):
-        """total_steps: length of the cosine schedule and capacity of the loss buffer.  use_graph=False runs the SAME
-        iteration eagerly (the comparator of the parity test).  split: force the two-graph form (the one used with a
-        collective in the middle) at world 1.  overlap (one rank, graphs): batch i + 1 is simulated on a stream of its own
-        while batch i is trained on -- same batches, same order, same result."""
+        """total_steps: length of the cosine schedule (past it the rate holds the schedule's final value) and size of the
+        device-side loss ring (read out by the host before it wraps: the history is complete for any number of iterations).
+        use_graph=False runs the SAME iteration eagerly (the comparator of the parity test).  split: force the two-graph
+        form (the one used with a collective in the middle) at world 1.  overlap (graphs, any world size): batch i + 1 is
+        simulated -- and all-gathered -- on streams of its own while batch i is trained on: same batches, same order, same
+        result as the sequential loop (overlap=False)."""
         if parallel not in ("gather", "ddp"):
             raise ValueError("parallel must be 'gather' or 'ddp'")
         torch_ = engine.require_device()
@@ -71,8 +77,9 @@ class GraphTrainer:
         self.use_graph = bool(use_graph)
         self.world, self.rank, self.parallel, self.backend = int(world), int(rank), parallel, backend
         self.split = (self.world > 1) if split is None else bool(split)
-        self.overlap = bool(overlap) and self.use_graph and self.world == 1 and not self.split
+        self.overlap = bool(overlap) and self.use_graph
         self.iteration = 0
+        self._loss_host = []               # losses already read out of the device ring (_drain_losses)
         with torch.cuda.device(self.dev):
             # ONE flat buffer each for the parameters (the modules' tensors become views of it), the gradients (+ 1 slot that
             # carries the loss through the all-reduce) and Adam's two moments: the optimizer step is then three launches of the
@@ -126,7 +133,11 @@ class GraphTrainer:
         self._comm = torch.cuda.Stream(device=self.dev)
         self._sim_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
+        # the library's memory behind THIS trainer's captured launches (include/nddm.h: nddm_graph_arena_*): close() frees
+        # it and nothing else -- a second trainer, or a user's own captured graph, keeps replaying
+        self._arena = engine.GraphArena() if self.use_graph else None
         self._closed = False
+        self._sync_replicas()
 
     # ------------------------------------------------------------------------------------------------ the iteration
     def bucket_top(self, n):
@@ -173,11 +184,12 @@ class GraphTrainer:
         g = self.flat[:self.n_el]
         if scale != 1.0:
             self.flat.mul_(scale)                                     # mean over ranks (gradients and the loss slot)
-        self.lr_t.copy_((0.5 * self.lr0 * (1.0 + torch.cos(self.step_f * (math.pi / max(1, self.T))))).view(()))
+        total = float(max(1, self.T))                                 # (held at the final value past `total`, as the kernel does)
+        self.lr_t.copy_((0.5 * self.lr0 * (1.0 + torch.cos(torch.clamp(self.step_f, max=total) * (math.pi / total)))).view(()))
         coef = torch.clamp(self.clip / (g.norm() + 1e-6), max=1.0)
         g.mul_(coef)
         self.optimizer.step()
-        self.loss_buf.index_copy_(0, torch.clamp(self.step_i, max=self.loss_buf.numel() - 1), self.flat[self.n_el:])
+        self.loss_buf.index_copy_(0, torch.remainder(self.step_i, self.loss_buf.numel()), self.flat[self.n_el:])
         self.step_i += 1
         self.step_f += 1.0
 
@@ -206,6 +218,32 @@ class GraphTrainer:
         import torch.distributed as dist
         return self.world > 1 or (self.split and dist.is_available() and dist.is_initialized())
 
+    def _sync_replicas(self):
+        """More than one rank: every replica starts from RANK 0's weights, buffers (the flow's permutations), Adam moments,
+        counters and learning rate.  `gather` is replicated training and `ddp` all-reduces gradients only -- ranks that
+        built their amortizer from different seeds, or of which only one loaded a checkpoint, would otherwise train
+        different models without any error."""
+        import torch.distributed as dist
+        if not (self.world > 1 and dist.is_available() and dist.is_initialized()):
+            return
+        m, v = self._moments()
+        ts = [self.flat_p, m, v, self.step_i, self.step_f, self.lr_t] + [b for b in self.amortizer.buffers()]
+        if self.optimizer is not None:
+            ts.append(self.optimizer.state[self._flat_param]["step"])
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.device(self.dev), torch.cuda.stream(self._comm), torch.no_grad():
+            for t in ts:
+                if t.is_cuda:
+                    dist.broadcast(t, 0)
+                else:                                        # (a buffer left on the host)
+                    d = t.to(self.dev)
+                    dist.broadcast(d, 0)
+                    t.copy_(d)
+        self._comm.synchronize()
+        for mod in self.amortizer.modules():                 # host copies derived from buffers (the flow's permutations)
+            if hasattr(mod, "_refresh_host_perms"):
+                mod._refresh_host_perms()
+
     # ------------------------------------------------------------------------------------------------ graphs
     def _mutable(self):
         # (the flat gradient buffer too: a stretch that starts with the update clips it in place)
@@ -229,14 +267,15 @@ class GraphTrainer:
             bk.params = torch.empty((self.B, self.P), dtype=torch.float32, device=self.dev)
             bk.trials = torch.empty((self.B, n_top, 2), dtype=torch.float32, device=self.dev)
             bk.g_params = bk.g_trials = None
+            src_p, src_t = bk.params, bk.trials
             if self.parallel == "gather" and self._has_collective():
                 bk.g_params = torch.empty((self.world, self.B, self.P), dtype=torch.float32, device=self.dev)
                 bk.g_trials = torch.empty((self.world, self.B, n_top, 2), dtype=torch.float32, device=self.dev)
-                bk.t_params, bk.t_trials = bk.g_params.view(-1, self.P), bk.g_trials.view(-1, n_top, 2)
-            elif self.overlap:                      # the simulator refills params / trials while these are trained on
-                bk.t_params, bk.t_trials = torch.empty_like(bk.params), torch.empty_like(bk.trials)
+                src_p, src_t = bk.g_params.view(-1, self.P), bk.g_trials.view(-1, n_top, 2)
+            if self.overlap:                        # the simulator (and the all-gather) refill the sources while these are trained on
+                bk.t_params, bk.t_trials = torch.empty_like(src_p), torch.empty_like(src_t)
             else:
-                bk.t_params, bk.t_trials = bk.params, bk.trials
+                bk.t_params, bk.t_trials = src_p, src_t
             bk.r_params = bk.r_trials = None          # staging of a replayed batch: allocated by the first replay iteration
             bk.graphs = {}
         self._buckets[n_top] = bk
@@ -264,7 +303,7 @@ class GraphTrainer:
             g = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
             # default (global) capture mode turns into an error that kills the process
-            with torch.cuda.graph(g, pool=self._pool, stream=stream, capture_error_mode="thread_local"):
+            with self._arena.bound(), torch.cuda.graph(g, pool=self._pool, stream=stream, capture_error_mode="thread_local"):
                 fn()
             bk.graphs[key] = g
         g.replay()
@@ -276,6 +315,7 @@ class GraphTrainer:
         forward/backward | update around a gradient all-reduce."""
         coll, ddp = self._has_collective(), self.parallel == "ddp"
         gather = coll and not ddp
+        self._keep_loss_ring()
         bk = self._bucket(self.bucket_top(n))
         self.n_f.fill_(float(n))
         sim = lambda: self._simulate(bk)
@@ -310,50 +350,81 @@ class GraphTrainer:
             self._run(bt, "r:fb+up", lambda: (fb(), up()))
 
     def _train_overlapped(self, iterations, replay):
-        """One rank, graphs: the simulator runs one batch AHEAD on its own stream -- `sim` graph of batch i + 1 | training graph
-        of batch i side by side (the simulate launch is a few dozen waves for 30-200 microseconds: alone on the chip it is
-        pure latency) -- within this call only: nothing is simulated beyond the last iteration, so the random stream's
-        position after the call is what the sequential loop leaves."""
-        T, S = self._stream, self._sim_stream
+        """The pipelined loop (graphs, any world size): the PRODUCER of batch i + 1 -- its `sim` graph on the simulate stream
+        and, in `gather` mode, the all-gather that reassembles it on the communication stream -- runs beside the training
+        graph(s) of batch i on the training stream.  (A simulate launch of 32 sets is a few dozen waves for 30-200
+        microseconds: alone on the chip it is pure latency, and so is a small all-gather.)  The gradient all-reduce of `ddp`
+        stays between its two graphs on the training side.  Within this call only: nothing is simulated beyond the last
+        iteration, so the random stream's position after the call is what the sequential loop leaves."""
+        T, S, C = self._stream, self._sim_stream, self._comm
+        coll, ddp = self._has_collective(), self.parallel == "ddp"
+        gather = coll and not ddp
+        two = (coll and ddp) or (self.split and not gather)          # forward/backward | [all-reduce] | update
         cur = torch.cuda.current_stream(self.dev)
         T.wait_stream(cur)
         S.wait_stream(T)
+        C.wait_stream(T)
         ns = [shared_prior_N(self.seed, self.iteration + k, self.n_min, self.n_max) for k in range(int(iterations))]
-        up = lambda: self._update(1.0)
+        up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
 
-        def simulate(n):
+        def produce(n):
             bk = self._bucket(self.bucket_top(n))
             with torch.cuda.stream(S):
                 self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
                 ev = torch.cuda.Event()
                 ev.record(S)
+            if gather:
+                C.wait_event(ev)
+                with torch.cuda.stream(C):
+                    self._gather(bk)
+                    ev = torch.cuda.Event()
+                    ev.record(C)
             return ev
 
+        def sources(bk):
+            if gather:
+                return bk.g_params.view(-1, self.P), bk.g_trials.view(-1, bk.n_top, 2)
+            return bk.params, bk.trials
+
         with torch.cuda.device(self.dev):
-            ev = simulate(ns[0]) if ns else None
+            ev = produce(ns[0]) if ns else None
             for k, n in enumerate(ns):
                 bk = self._bucket(self.bucket_top(n))
+                src_p, src_t = sources(bk)
                 with torch.cuda.stream(T):
                     T.wait_event(ev)
                     if replay is None:
-                        bk.t_params.copy_(bk.params); bk.t_trials.copy_(bk.trials)
+                        bk.t_params.copy_(src_p); bk.t_trials.copy_(src_t)
                     else:
-                        entry = (bk.params.clone(), bk.trials.clone(), n)
+                        entry = (src_p.clone(), src_t.clone(), n)
                     taken = torch.cuda.Event()
                     taken.record(T)
-                if k + 1 < len(ns):
-                    S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers
-                    ev = simulate(ns[k + 1])
-                with torch.cuda.stream(T):
+                with torch.cuda.stream(T):              # (enqueued BEFORE the next batch's producer: a host-blocking exchange --
+                    self._keep_loss_ring()              #  gloo -- then waits while the device trains)
                     if replay is None:
                         self.n_f.fill_(float(n))
-                        self._run(bk, "fb+up", lambda: (self._forward_backward(bk.t_params, bk.t_trials), up()))
+                        b, pre = bk, ""
+                        fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
                     else:
                         bt = self._replay_stage(entry, replay)
-                        self._run(bt, "r:fb+up", lambda: (self._forward_backward(bt.r_params, bt.r_trials), up()))
+                        b, pre = bt, "r:"
+                        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
+                    if two:
+                        self._run(b, pre + "fb", fb)
+                        if coll:
+                            self._on_comm_stream(self._all_reduce_gradients)
+                        self._run(b, "up", up)
+                    else:
+                        self._run(b, pre + "fb+up", lambda: (fb(), up()))
+                if k + 1 < len(ns):
+                    S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers ...
+                    if gather:
+                        C.wait_event(taken)             # ... and its all-gather the reassembled minibatch
+                    ev = produce(ns[k + 1])
                 self.iteration += 1
         cur.wait_stream(T)
         cur.wait_stream(S)
+        cur.wait_stream(C)
 
     def _replay_stage(self, entry, replay):
         """Experience replay's host side: the fresh batch into the buffer (overwriting a random slot once it is full), a stored
@@ -398,10 +469,24 @@ class GraphTrainer:
                 self.iteration += 1
         torch.cuda.current_stream(self.dev).wait_stream(self._stream)
 
+    def _drain_losses(self):
+        """Read the losses the host does not hold yet out of the device ring (one synchronisation of the training stream)."""
+        have, done, cap = len(self._loss_host), self.iteration, self.loss_buf.numel()
+        if done > have:
+            self._stream.synchronize()
+            buf = self.loss_buf.cpu().numpy()
+            self._loss_host += [float(buf[i % cap]) for i in range(have, done)]
+
+    def _keep_loss_ring(self):
+        """Before the iteration that would overwrite a loss the host has not read: read the ring out (once per
+        `total_steps` iterations, so the history is complete however long the run is)."""
+        if self.iteration - len(self._loss_host) >= self.loss_buf.numel():
+            self._drain_losses()
+
     def loss_history(self):
-        """The losses of the iterations run so far (one device synchronisation)."""
-        self._stream.synchronize()
-        return self.loss_buf[:min(self.iteration, self.loss_buf.numel())].cpu().numpy().tolist()
+        """The losses of ALL iterations run so far (one device synchronisation)."""
+        self._drain_losses()
+        return list(self._loss_host)
 
     @torch.no_grad()
     def validation_loss(self, conf):
@@ -416,7 +501,7 @@ class GraphTrainer:
         self._stream.synchronize()
         st = {"model": self.amortizer.state_dict(), "optimizer": self._optimizer_state(), "iteration": self.iteration,
               "offset": self.offset.cpu(), "step_i": self.step_i.cpu(), "step_f": self.step_f.cpu(), "lr": self.lr_t.cpu(),
-              "loss_buf": self.loss_buf.cpu(), "replay": None}
+              "loss_buf": self.loss_buf.cpu(), "loss_host": self.loss_history(), "replay": None}
         if self._replay is not None:
             ring, rng, cap = self._replay
             st["replay"] = {"ring": [(p.cpu(), t.cpu(), n) for p, t, n in ring], "rng": rng.bit_generator.state, "capacity": cap}
@@ -448,11 +533,14 @@ class GraphTrainer:
             n = min(self.loss_buf.numel(), st["loss_buf"].numel())
             self.loss_buf[:n].copy_(st["loss_buf"][:n])
         self.iteration = int(st["iteration"])
+        # (a checkpoint written before the ring existed holds the first min(iteration, capacity) losses in its buffer)
+        self._loss_host = list(st["loss_host"]) if "loss_host" in st else st["loss_buf"][:min(self.iteration, n)].tolist()
         self._replay = None
         if st.get("replay") is not None:
             rng = np.random.default_rng(0)
             rng.bit_generator.state = st["replay"]["rng"]
             self._replay = ([(p.to(self.dev), t.to(self.dev), n) for p, t, n in st["replay"]["ring"]], rng, st["replay"]["capacity"])
+        self._sync_replicas()          # more than one rank: whatever each rank loaded, all continue from rank 0's state
 
     def save_checkpoint(self, path):
         import os
@@ -468,18 +556,17 @@ class GraphTrainer:
 
     # ------------------------------------------------------------------------------------------------ ownership
     def close(self):
-        """Destroy the graphs, then hand the library's memory behind their captured launches back (the trainer owns it:
-        include/nddm.h, nddm_release_graph_memory)."""
+        """Destroy the graphs, then hand the library's memory behind THEIR captured launches back: the trainer's own graph
+        arena (include/nddm.h: nddm_graph_arena_release) -- other trainers' and the user's graphs are not touched."""
         if self._closed:
             return
         self._closed = True
         torch.cuda.synchronize(self.dev)
-        had = any(b.graphs for b in self._buckets.values())
+        self._drain_losses()
         self._buckets.clear()
         self._replay = None
-        if had:
-            with torch.cuda.device(self.dev):
-                engine.release_graph_memory()
+        if self._arena is not None:
+            self._arena.release()
 
     def __enter__(self):
         return self

@@ -28,6 +28,7 @@ microseconds per simulate launch (eager and hipGraph), simulator share of a step
 import argparse
 import glob
 import json
+import math
 import os
 import sys
 import time
@@ -378,6 +379,9 @@ def worker(a):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # rank <-> device: whatever the process group did at start-up, THIS rank's work must go to its own card
+        if torch.cuda.current_device() != local_rank:
+            sys.exit(f"bench.py: rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank} after init_process_group")
     from bayesflow_nddms_amd import _lib, engine
     from bayesflow_nddms_amd import priors as prior_util
     ctx = dict(world=world, rank=rank, local_rank=local_rank, dev=dev, torch=torch, dist=dist, engine=engine, _lib=_lib,
@@ -411,8 +415,13 @@ def simulate_bench(a, ctx):
     model_id = getattr(engine, model_attr)
     # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
     # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
+    t_prior = time.perf_counter()
     p_host = getattr(prior_util, prior_fn)(B, 2023 + rank)
     p_dev = torch.as_tensor(p_host).to(dev)
+    t_prior = time.perf_counter() - t_prior
+    # per-rank host work before the timed region: N ranks share the node's host cores (vectorised draws: ~0.2 s per 1M rows on one)
+    print(f"bench.py: rank {rank}/{world} on cuda:{torch.cuda.current_device()}: {B} parameter rows drawn on the host and copied in "
+          f"{t_prior:.2f} s", file=sys.stderr, flush=True)
     # Output buffers.  With a minibatch all-gather (north_star's reassembly step) the collective runs on a COMMUNICATION
     # stream and the outputs are double-buffered: step i+1's simulate is enqueued before step i's gather is waited on, so the
     # two overlap (at weak scale the gather of the trials moves as many bytes over xGMI as the simulate
@@ -558,6 +567,11 @@ def simulate_bench(a, ctx):
     if tr:
         res["roofline"]["traffic"] = tr["bytes"]
         res["roofline"]["traffic_source"] = tr["source"]
+    res["host_prior_seconds_rank0"] = t_prior
+    if world > 1:
+        # the per-kernel analysis belongs to the one-GPU line: these objects are measured at N = 1 only (their absence here is
+        # by design, not a failure); `roofline` (the contract's object) and `launch` are on every line
+        res["n1_only"] = ["roofline_valu", "occupancy", "ks_vs_ref", "packed_gauss", "cpu_baseline", "gpu_over_cpu_1core"]
     if world == 1:
         achieved_steps = em_steps / (kern_ms * 1e-3)
         rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
@@ -687,11 +701,18 @@ def train_bench(a, ctx):
                 amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
                 trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, device=dev)
                 counter["i"] = 0
-                trainer.train_online(epochs=1, iterations_per_epoch=warm, batch_size=Bl, save_checkpoint=False, prefetch=prefetch)
+                # the same run as the graph leg below: `warm + train_iters` iterations untimed, `train_iters` timed, ONE cosine
+                # schedule of warm + 2 train_iters steps over both calls (the Trainer's own default is a schedule per call), so
+                # the two drivers' loss columns are comparable at equal iteration counts
+                total = warm + 2 * a.train_iters
+                opt = torch.optim.Adam(amortizer.parameters(), lr=trainer.lr)
+                sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s, total=total: 0.5 * (1.0 + math.cos(math.pi * min(s, total) / total)))
+                trainer.train_online(epochs=1, iterations_per_epoch=warm + a.train_iters, batch_size=Bl, save_checkpoint=False,
+                                     prefetch=prefetch, optimizer=opt, scheduler=sched)
                 barrier(a, ctx)
                 t0 = time.perf_counter()
                 trainer.train_online(epochs=1, iterations_per_epoch=a.train_iters, batch_size=Bl, save_checkpoint=False,
-                                     prefetch=prefetch)
+                                     prefetch=prefetch, optimizer=opt, scheduler=sched)
                 barrier(a, ctx)
                 el = time.perf_counter() - t0
                 h = trainer.loss_history
@@ -735,7 +756,9 @@ def train_bench(a, ctx):
                                 "graphs_captured": gt.n_graphs, "graphs_captured_in_first_pass": n_graphs,
                                 "buckets": gt.n_buckets, "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:])),
                                 "parallel": a.train_parallel if world > 1 else "one rank",
-                                "two_graphs_with_collective_between": bool(dist_on)}
+                                "two_graphs_with_collective_between": bool(dist_on),
+                                # simulate (+ all-gather) of batch i + 1 on their own streams beside the training graph(s) of batch i
+                                "pipelined_feed": bool(gt.overlap)}
             # the reference's own call, trainer.train_experience_replay (basic_ddm_dc.py:199-202): simulate graph | buffer of
             # 100 batches | training graph of the drawn batch's bucket
             torch.manual_seed(0)

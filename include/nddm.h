@@ -11,6 +11,10 @@
  *     call's work on `stream` has completed.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *     asynchronous with respect to the host: they enqueue work on `stream` and return.
+ *     The handle is VALIDATED at entry (ABI 3): a destroyed stream, a stream created by another copy of the HIP runtime
+ *     in the process, or an integer that never was a stream is refused with NDDM_ERR_HIP before anything is enqueued,
+ *     and a stream of another device than the current one with NDDM_ERR_PARAM.  (HIP itself dereferences such a handle
+ *     in hipStreamIsCapturing / hipEventRecord / the launch calls: a SIGSEGV in the caller's thread.)
  *   - parameter rows are row-major float32 [B, P] in the REFERENCE'S parameter order.
  *   - trial output is row-major float32 [B, n_trials, 2]; summary output float32 [B, NDDM_SUMMARY_K].
  *     Either may be NULL (summary-only mode never writes the 8 bytes per trial).
@@ -23,7 +27,9 @@
  *     that launch until the work it enqueued has COMPLETED (reuse is keyed on stream order or on a completion event, never
  *     on a launch count); the developer knobs (nddm_set_tuning, nddm_set_debug_trace) are read once, atomically, at entry.
  *   - hipGraph: a call made while `stream` is capturing is recorded as kernels only; the memory such a launch needs is
- *     allocated for that launch alone and lives until nddm_release_graph_memory().  Seed and set_offset are baked in;
+ *     allocated for that launch alone and belongs to the GRAPH ARENA bound to the capturing thread (nddm_graph_arena_*;
+ *     released with its owner, and with nothing else) or, with no arena bound, to an ownerless list that
+ *     nddm_release_graph_memory() frees.  Seed and set_offset are baked in;
  *     nddm_simulate_indirect / nddm_draw_prior_indirect add a 64-bit offset read from DEVICE memory when the kernels run,
  *     so a replayed graph moves along the random stream (a captured `*dev += B` between replays).
  *
@@ -48,7 +54,10 @@ extern "C" {
 /* 2: the default Gaussian stream takes the angle from the LOW 23 bits of its word (round 2), the bridge-uniform stream
  *    serves 8 steps per block (round 3), nddm_set_debug_counters became nddm_set_debug_trace, and the *_indirect entry
  *    points, nddm_simulate_codes / nddm_decode_codes and nddm_source_hash exist.  The same (seed, set_offset) gives different bits under ABI 1. */
-#define NDDM_ABI_VERSION 2
+/* 3: memory behind captured launches has an owner (nddm_graph_arena_create / _bind / _info / _release); nddm_release_graph_memory
+ *    frees only what was captured with no arena bound (up to ABI 2: every captured launch's memory on the device, whoever's graph
+ *    replayed into it); a `stream` the HIP runtime does not know is refused with NDDM_ERR_HIP (validated with hipStreamGetDevice at entry).  The random stream is ABI 2's. */
+#define NDDM_ABI_VERSION 3
 #define NDDM_SUMMARY_K 10
 
 /* summary_stats[b, :] (single_trial_alpha_not_scaled.py:205-211,
@@ -105,8 +114,24 @@ int nddm_device_count(int *count);
 int nddm_set_device(int device);
 int nddm_summary_k(void);
 int nddm_model_nparams(int model); /* P of enum nddm_model, -1 if unknown */
-/* frees the memory held for launches captured into hipGraphs on the current device; call only when every graph that
- * captured a launch of this library has been destroyed */
+/* ---- memory behind launches captured into hipGraphs ---------------------------------------------------------------------
+ * A captured launch cannot borrow the library's per-launch memory (the graph replays at times the library cannot see): it gets
+ * an allocation of its own (two queue words + its scratch, <= 64 MB).  That allocation is charged to the graph arena that is
+ * bound to the CAPTURING THREAD at the time of the call:
+ *     uint64_t a;  nddm_graph_arena_create(&a);
+ *     nddm_graph_arena_bind(a, &prev);  ... hipStreamBeginCapture / nddm_* calls / hipStreamEndCapture ...  nddm_graph_arena_bind(prev, NULL);
+ *     ... replay the graphs ...;  destroy them;  nddm_graph_arena_release(a);
+ * The caller of nddm_graph_arena_release asserts that every graph that captured a launch under THIS arena has been destroyed
+ * (or will not be replayed); graphs captured under other arenas -- a second trainer (the checkpointed, re-entered training of
+ * basic_ddm_dc.py:169-176, 199-207 keeps more than one alive in a notebook), a user's own graph -- are not affected.
+ * The binding is per host thread; arena 0 = no owner.  A capture made while a RELEASED arena is still bound is refused
+ * (NDDM_ERR_PARAM).  nddm_graph_arena_info: bytes / allocations currently charged to an arena (0 = the ownerless list). */
+int nddm_graph_arena_create(uint64_t *arena);
+int nddm_graph_arena_bind(uint64_t arena, uint64_t *previous /* may be NULL */);
+int nddm_graph_arena_info(uint64_t arena, uint64_t *bytes /* may be NULL */, int32_t *n_allocations /* may be NULL */);
+int nddm_graph_arena_release(uint64_t arena);
+/* frees the OWNERLESS memory of the current device: what launches captured with no arena bound were given; call only when every
+ * such graph has been destroyed.  Never touches an arena's memory. */
 int nddm_release_graph_memory(void);
 /* testing aid (not part of the drop-in surface): cap the number of launch slots per device, so that a test can drive the
  * library into queueing a launch behind an in-flight one */

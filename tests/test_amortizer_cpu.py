@@ -90,3 +90,72 @@ def test_padded_batches_pool_over_the_real_trials_only():
     a = am.compute_loss({"summary_conditions": x, "summary_n": torch.tensor([float(n)]), "direct_conditions": direct, "parameters": theta})
     b = am.compute_loss({"summary_conditions": x[:, :n], "direct_conditions": direct, "parameters": theta})
     assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_every_train_call_has_a_schedule_of_its_own(tmp_path):
+    """basic_ddm_dc.py:199-207 re-enters training (load_pretrained_network, another train_* call).  Every call is a run of its
+    own, as in BayesFlow 1.1's Trainer: the cosine decay starts from the Trainer's rate again (a second CosineAnnealingLR
+    stacked on an optimizer already annealed to 0 used to train the second call -- and every resumed run -- at rate 0), holds its
+    final value past the schedule's length, and Adam is fresh unless reuse_optimizer=True was asked for."""
+    torch.manual_seed(0)
+    gm, conf = _toy_model()
+    am = AmortizedPosterior(InvertibleNetwork(num_params=2, cond_dim=11, num_coupling_layers=2, hidden=32), InvariantNetwork(hidden=32))
+    tr = Trainer(am, gm, conf, checkpoint_path=str(tmp_path / "ckpt"), device="cpu", learning_rate=2e-3)
+    rates = []
+    step = tr._step
+    tr._step = lambda c: (rates.append(tr.optimizer.param_groups[0]["lr"]), step(c))[1]
+    tr.train_online(epochs=1, iterations_per_epoch=20, batch_size=8)
+    first = list(rates)
+    assert abs(first[0] - 2e-3) < 1e-12 and 0 < first[-1] < 0.02 * 2e-3 and all(a > b for a, b in zip(first, first[1:]))
+    adam1 = tr.optimizer
+    w = [p.detach().clone() for p in am.parameters()]
+    del rates[:]
+    tr.train_online(epochs=1, iterations_per_epoch=20, batch_size=8)                      # the second call: lr > 0 throughout
+    assert np.allclose(rates, first, rtol=0, atol=1e-15) and tr.optimizer is not adam1   # the same schedule again, a fresh Adam
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(w, am.parameters()))        # ... and the weights moved
+    del rates[:]
+    tr.train_experience_replay(epochs=2, iterations_per_epoch=5, batch_size=8, capacity_in_batches=4, reuse_optimizer=True)
+    adam3 = tr.optimizer
+    assert abs(rates[0] - 2e-3) < 1e-12 and rates[-1] > 0 and len(rates) == 10
+    del rates[:]
+    tr.train_online(epochs=1, iterations_per_epoch=4, batch_size=8)
+    assert tr.optimizer is adam3 and abs(rates[0] - 2e-3) < 1e-12                         # reuse_optimizer=True kept the moments
+    # a resumed run: the loaded optimizer (whose stored rate is the annealed one) trains at the Trainer's rate again
+    am2 = AmortizedPosterior(InvertibleNetwork(num_params=2, cond_dim=11, num_coupling_layers=2, hidden=32), InvariantNetwork(hidden=32))
+    tr2 = Trainer(am2, gm, conf, checkpoint_path=str(tmp_path / "ckpt"), device="cpu", learning_rate=2e-3)
+    assert tr2.load_pretrained_network() and tr2.optimizer.param_groups[0]["lr"] < 2e-3
+    seen = []
+    step2 = tr2._step
+    tr2._step = lambda c: (seen.append(tr2.optimizer.param_groups[0]["lr"]), step2(c))[1]
+    tr2.train_online(epochs=1, iterations_per_epoch=6, batch_size=8, save_checkpoint=False)
+    assert abs(seen[0] - 2e-3) < 1e-12 and min(seen) > 0
+    # past its length a schedule HOLDS its final value
+    tr2._setup_schedule(3)
+    for _ in range(9):
+        tr2.optimizer.step(); tr2.scheduler.step()
+    assert abs(tr2.optimizer.param_groups[0]["lr"]) < 1e-12
+
+
+def test_flow_state_dict_accepts_the_earlier_layout():
+    """Checkpoints written before the per-layer ActNorm parameters: `an_scale` / `an_bias` as ONE [layers, D] tensor each and
+    the permutation matrices stored beside the permutations.  They load (strict), `pmat{i}` is rebuilt from `perm{i}` -- a
+    mismatched pair cannot be loaded -- and is no longer part of the state dict."""
+    torch.manual_seed(0)
+    a = InvertibleNetwork(num_params=5, num_coupling_layers=3, seed=4)
+    with torch.no_grad():
+        for p in list(a.an_scale) + list(a.an_bias):
+            p.copy_(torch.randn_like(p))
+    sd = a.state_dict()
+    assert not any(k.startswith("pmat") for k in sd)
+    old = {k: v for k, v in sd.items() if not k.startswith(("an_scale", "an_bias"))}
+    old["an_scale"] = torch.stack([sd[f"an_scale.{i}"] for i in range(3)])
+    old["an_bias"] = torch.stack([sd[f"an_bias.{i}"] for i in range(3)])
+    for i in range(3):
+        old[f"pmat{i}"] = torch.eye(5)                                  # a WRONG matrix: must be ignored
+    b = InvertibleNetwork(num_params=5, num_coupling_layers=3, seed=9)    # other permutations until the load
+    b.load_state_dict(old)
+    x, c = torch.randn(7, 5), torch.randn(7, 11)
+    za, la = a(x, c)
+    zb, lb = b(x, c)
+    assert torch.equal(za, zb) and torch.equal(la, lb) and b._perm_host == a._perm_host
+    assert torch.allclose(b.inverse(zb, c), x, atol=1e-4)

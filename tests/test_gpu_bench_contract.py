@@ -67,6 +67,23 @@ def test_bench_gpus_2_starts_two_ranks(gather):
     assert abs(d["value"] - 2 * 20000 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
+def test_bench_many_ranks_rehearsal_names_what_an_n_gpu_line_omits():
+    """The driver's 8-GPU command, rehearsed with FIVE ranks sharing cuda:0 over gloo (this test process holds the card as well
+    and the box allows six GPU processes at once): the parent starts the ranks, every rank reports its device and its host-side
+    parameter draw on standard error, rank 0 prints ONE line with n_gpus 5 -- and, because the per-kernel analysis
+    (roofline_valu, KS, CPU baseline ...) is measured at N = 1 only, the line NAMES the objects it omits (`n1_only`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = _bench("--gpus", "5", "--share-device", "--backend", "gloo", "--sets", "20000", "--steps", "3", "--warmup", "1", env=env)
+    d = _one_line(r)
+    assert d["n_gpus"] == 5 and d["scaling"] == "weak" and "roofline" in d and "launch" in d
+    assert abs(d["value"] - 5 * 20000 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert set(d["n1_only"]) >= {"roofline_valu", "ks_vs_ref", "cpu_baseline"} and not (set(d["n1_only"]) & set(d))
+    seen = [l for l in r.stderr.splitlines() if l.startswith("bench.py: rank ")]
+    assert sorted(int(l.split()[2].split("/")[0]) for l in seen) == [0, 1, 2, 3, 4] and all("/5 on cuda:0" in l for l in seen)
+    one = _one_line(_bench("--sets", "20000", "--steps", "2", "--warmup", "1", "--no-ceiling", "--no-ks", "--no-cpu-baseline", env=env))
+    assert "n1_only" not in one and one["host_prior_seconds_rank0"] < 5.0
+
+
 def _one_line(r):
     """Standard output is EXACTLY the JSON line: what libraries print to file descriptor 1 (RCCL's version banner) is sent to
     standard error by bench.py."""
@@ -121,7 +138,11 @@ def test_bench_train_two_ranks_sharded_feed():
         leg = d["train"][tag]
         for k in ("eager_prefetch_off", "eager_prefetch_on", "graph"):
             assert leg[k]["loss_last10"] < leg[k]["loss_first10"], (tag, k, leg[k])
-        assert leg["graph"]["two_graphs_with_collective_between"] is True
+        assert leg["graph"]["two_graphs_with_collective_between"] is True and leg["graph"]["pipelined_feed"] is True
+        # the eager comparator LEARNS (it used to run its timed iterations at learning rate 0): same schedule, same number of
+        # iterations as the graph leg -> the same neighbourhood of the loss
+        for k in ("eager_prefetch_off", "eager_prefetch_on"):
+            assert abs(leg[k]["loss_last10"] - leg["graph"]["loss_last10"]) < 0.25 * abs(leg["graph"]["loss_last10"]) + 0.5, (tag, k, leg)
 
 
 def test_bench_train_ddp_at_world_1_over_rccl():

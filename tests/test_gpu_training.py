@@ -82,13 +82,16 @@ def test_graph_trainer_equals_the_eager_iteration_and_tracks_the_classic_loop():
             return gt.loss_history(), gt.n_graphs
 
     h_graph, n_graphs = run(use_graph=True, overlap=False)
-    h_split, n_split = run(use_graph=True, split=True)
+    h_split, n_split = run(use_graph=True, split=True, overlap=False)     # simulate + forward/backward | update, in sequence
     h_ahead, n_ahead = run(use_graph=True)             # the default: simulate graph of batch i + 1 beside the training graph of i
+    h_ahead3, n_ahead3 = run(use_graph=True, split=True)                  # pipelined: simulate (i + 1) || forward/backward | update (i)
     h_eager, _ = run(use_graph=False)
     assert len(h_graph) == iters and n_graphs >= 5 and n_split == 2 * n_graphs == n_ahead      # several N buckets were hit
+    assert n_ahead3 == 3 * n_graphs
     assert np.allclose(h_graph, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h_graph) - np.array(h_eager)).max()
     assert np.allclose(h_split, h_eager, rtol=1e-4, atol=1e-4)
     assert np.allclose(h_ahead, h_eager, rtol=1e-4, atol=1e-4)
+    assert np.allclose(h_ahead3, h_eager, rtol=1e-4, atol=1e-4)
     assert np.mean(h_graph[-10:]) < np.mean(h_graph[:10]) - 0.5
     # the classic loop on the same batches: same prior rows, same simulator stream, exact N
     prior, step = DevicePrior("basic", seed=2023), {"i": 0}
@@ -183,6 +186,98 @@ def test_graph_trainer_checkpoint_resume_reproduces_the_uninterrupted_run(tmp_pa
         gt.train_experience_replay(25, capacity_in_batches=8)
         resumed = gt.loss_history()
     assert len(resumed) == 50 and np.allclose(resumed, straight, rtol=1e-5, atol=1e-5), np.abs(np.array(resumed) - np.array(straight)).max()
+
+
+def test_graph_trainer_past_total_steps_holds_the_rate_and_keeps_every_loss():
+    """`total_steps` is the cosine schedule's length and the size of the device-side loss ring -- not a limit of the run: past
+    it the learning rate stays at the schedule's final value (0: the weights stop moving; it used to climb back to lr0) and the
+    history still holds EVERY loss (the ring is read out before it wraps; further losses used to pile into its last slot).
+    Graph and eager forms agree over the whole run."""
+    import torch
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+    T, lr0 = 20, 1e-3
+
+    def run(use_graph, calls):
+        torch.manual_seed(0)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+        with GraphTrainer(am, batch_size=32, total_steps=T, seed=2023, learning_rate=lr0, use_graph=use_graph) as gt:
+            rates, weights = [], []
+            for n in calls:
+                gt.train_online(n)
+                torch.cuda.synchronize()
+                rates.append(float(gt.lr_t))
+                weights.append(gt.flat_p.clone())
+            return gt.loss_history(), rates, weights
+
+    h, rates, w = run(True, (T, 15, 2 * T + 7))
+    assert len(h) == 3 * T + 22 and np.all(np.isfinite(h))
+    assert 0 < rates[0] < 0.02 * lr0 and rates[1] == 0.0 and rates[2] == 0.0, rates      # (lr_t: the rate the LAST step used)
+    assert torch.equal(w[0], w[1]) and torch.equal(w[1], w[2])                            # rate 0: nothing moves after step T
+    h_eager, rates_e, _ = run(False, (T, 15, 2 * T + 7))
+    assert rates_e[1] == 0.0 and np.allclose(h, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h) - np.array(h_eager)).max()
+    h_short, _, _ = run(True, (T,))
+    assert np.allclose(h[:T], h_short, rtol=1e-6, atol=1e-6)
+
+
+def _run_train_ranks(tmp_path, world, backend, iters):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "train_rank_worker.py"), str(tmp_path), backend, str(iters)],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=1500)
+        assert p.returncode == 0, err[-3000:]
+    return [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)]
+
+
+def test_two_ranks_pipelined_feed_equals_the_sequential_loop_and_replicas_stay_identical(tmp_path):
+    """BASELINE configs[4] on two fresh ranks (gloo, both on cuda:0), each of which builds its amortizer from ANOTHER seed:
+    the trainer broadcasts rank 0's weights, permutations and optimizer state, so both ranks start -- and, in `gather`
+    (replicated step) as in `ddp` (all-reduced gradients), stay -- bit-identical.  The PIPELINED loop (simulate + all-gather
+    of batch i + 1 beside the training step of batch i) equals the sequential graph loop and the eager iteration loss for loss,
+    and leaves the random stream where they leave it."""
+    iters = 24
+    ranks = _run_train_ranks(tmp_path, 2, "gloo", iters)
+    for parallel in ("gather", "ddp"):
+        for form in ("pipelined", "sequential", "eager"):
+            a, b = ranks[0][f"{parallel}/{form}"], ranks[1][f"{parallel}/{form}"]
+            assert a["w0"] == b["w0"] and a["perm0"] == b["perm0"], (parallel, form, "replicas differ at the start")
+            assert a["w1"] == b["w1"], (parallel, form, "replicas drifted apart")
+            assert a["minibatch"] == (64 if parallel == "gather" else 32)
+            assert a["offset"] == iters * 64 and b["offset"] == iters * 64 + 32          # the stream's position after the run
+            if parallel == "gather":
+                assert a["loss"] == b["loss"]                                             # the replicated step: the same numbers
+            assert len(a["loss"]) == iters and np.all(np.isfinite(a["loss"]))
+        ref = np.array(ranks[0][f"{parallel}/eager"]["loss"])
+        for form in ("pipelined", "sequential"):
+            h = np.array(ranks[0][f"{parallel}/{form}"]["loss"])
+            assert np.allclose(h, ref, rtol=1e-4, atol=1e-4), (parallel, form, np.abs(h - ref).max())
+        # (gather: simulate | forward/backward + update either way; ddp: simulate | forward/backward | update against simulate + forward/backward | update)
+        assert ranks[0][f"{parallel}/pipelined"]["graphs"] >= ranks[0][f"{parallel}/sequential"]["graphs"] > 0
+    assert np.mean(ranks[0]["gather/pipelined"]["loss"][-6:]) < np.mean(ranks[0]["gather/pipelined"]["loss"][:6])
+
+
+def test_pipelined_feed_over_rccl_at_world_1_equals_the_sequential_loop(tmp_path):
+    """The same three forms with the collectives on RCCL (world 1 on the one GPU): all-gather and all-reduce on the communication
+    stream beside the simulate stream's graph -- loss for loss the sequential loop."""
+    iters = 24
+    (r,) = _run_train_ranks(tmp_path, 1, "nccl", iters)
+    for parallel in ("gather", "ddp"):
+        ref = np.array(r[f"{parallel}/eager"]["loss"])
+        for form in ("pipelined", "sequential"):
+            h = np.array(r[f"{parallel}/{form}"]["loss"])
+            assert len(h) == iters and np.allclose(h, ref, rtol=1e-4, atol=1e-4), (parallel, form, np.abs(h - ref).max())
+            assert r[f"{parallel}/{form}"]["offset"] == iters * 32
 
 
 def test_graph_trainer_single_trial_model():
@@ -296,11 +391,16 @@ def test_fused_deepset_equals_the_pytorch_path():
             assert torch.allclose(net(x[:, :n_real].contiguous()), res[True][0], rtol=1e-4, atol=1e-5)
     wide = InvariantNetwork(hidden=32).cuda()                # hidden width 32: not covered -> the PyTorch path, silently
     assert wide(torch.randn(4, 50, 2, device="cuda")).shape == (4, 10)
-    with torch.no_grad():                                    # inference (no autograd graph) runs the kernels too
-        net = InvariantNetwork().cuda()
-        a = net(x)
-        net.fused = False
-        assert torch.allclose(a, net(x), rtol=1e-4, atol=1e-5)
+    # The kernels are the TRAINING path (their forward always keeps every hidden activation): inference (no_grad) and batches
+    # beyond FUSED_MAX_ROWS trial rows take the PyTorch composition, and a data tensor that wants a gradient is not theirs
+    net = InvariantNetwork().cuda()
+    assert net._fused_lib(x) is not None
+    with torch.no_grad():
+        assert net._fused_lib(x) is None
+        assert net(x).shape == (x.shape[0], net.summary_dim)
+    big = torch.zeros(net.FUSED_MAX_ROWS // 512 + 1, 512, 2, device="cuda")
+    assert net._fused_lib(big) is None and net._fused_lib(big[:-1]) is not None
+    assert net._fused_lib(x.clone().requires_grad_(True)) is None
 
 
 def test_flat_adam_step_equals_pytorch():
@@ -338,7 +438,17 @@ def test_flat_adam_step_equals_pytorch():
         assert rc == 0
         assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6), (it, float((p - ref.detach()).abs().max()))
         assert abs(float(lr_out) - lr) < 1e-9 and int(step_i) == it + 1 and float(step_f) == it + 1
-    assert loss_buf.tolist() == [0.5, 1.0, 1.5, 3.0]          # scaled losses; steps beyond the capacity land in the last slot
+    assert loss_buf.tolist() == [2.5, 3.0, 1.5, 2.0]          # scaled losses in a RING of 4: steps 4 and 5 wrapped (the host drains before)
+    # past the schedule's length the rate HOLDS its final value (Keras' CosineDecay, BayesFlow's default) -- it does not climb back
+    step_i.fill_(T - 1); step_f.fill_(float(T - 1))
+    seen = []
+    for it in range(T - 1, T + 40, 13):
+        step_i.fill_(it); step_f.fill_(float(it))
+        assert L.nddm_train_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, partial.data_ptr(), scale, clip, lr0, float(T),
+                                      0.9, 0.999, 1e-8, step_i.data_ptr(), step_f.data_ptr(), lr_out.data_ptr(), loss_buf.data_ptr(), 4,
+                                      g[n:].data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        seen.append(float(lr_out))
+    assert seen[0] > 0 and seen[0] < 1e-5 * lr0 * 1e3 and all(abs(v) < 1e-9 for v in seen[1:]), seen
     assert L.nddm_train_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n + 1, partial.data_ptr(), 1.0, clip, lr0, 1.0,
                                   0.9, 0.999, 1e-8, step_i.data_ptr(), step_f.data_ptr(), lr_out.data_ptr(), loss_buf.data_ptr(), 4,
                                   g[n:].data_ptr(), None) == 1       # a length that is not a multiple of 4 is refused

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/nddm.h but not exported"
     assert set(syms) <= set(_lib.EXPORTS)
-    assert _lib.lib().nddm_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().nddm_abi_version() == _lib.ABI_VERSION == 3
     assert _lib.lib().nddm_source_hash().decode() == build.source_hash()
     assert _lib.lib().nddm_summary_k() == 10
     assert [_lib.lib().nddm_model_nparams(m) for m in range(6)] == [5, 8, 8, 6, 4, -1]
@@ -58,6 +58,40 @@ def test_c_abi_argument_errors_without_gpu():
         _lib.check(_lib.NDDM_ERR_SHAPE)
     with pytest.raises(RuntimeError):
         _lib.check(_lib.NDDM_ERR_HIP)
+
+
+def test_graph_arena_handles_without_gpu():
+    """The owner handles of captured-launch memory (include/nddm.h: nddm_graph_arena_*) are host bookkeeping: create / bind /
+    info / release and their error cases need no device.  Bindings are per thread."""
+    import threading
+    from bayesflow_nddms_amd import _lib
+    L = _lib.lib()
+    a, b, prev = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(99)
+    assert L.nddm_graph_arena_create(None) == _lib.NDDM_ERR_NULL
+    assert L.nddm_graph_arena_create(ctypes.byref(a)) == _lib.NDDM_OK and a.value != 0
+    assert L.nddm_graph_arena_create(ctypes.byref(b)) == _lib.NDDM_OK and b.value not in (0, a.value)
+    assert L.nddm_graph_arena_bind(a.value, ctypes.byref(prev)) == _lib.NDDM_OK and prev.value == 0
+    assert L.nddm_graph_arena_bind(b.value, ctypes.byref(prev)) == _lib.NDDM_OK and prev.value == a.value
+    seen = []
+
+    def other_thread():                     # a fresh thread has no arena bound, whatever this one has
+        p = ctypes.c_uint64(99)
+        seen.append((L.nddm_graph_arena_bind(0, ctypes.byref(p)), p.value))
+
+    t = threading.Thread(target=other_thread)
+    t.start(); t.join()
+    assert seen == [(_lib.NDDM_OK, 0)]
+    nbytes, n = ctypes.c_uint64(7), ctypes.c_int32(7)
+    assert L.nddm_graph_arena_info(a.value, ctypes.byref(nbytes), ctypes.byref(n)) == _lib.NDDM_OK and (nbytes.value, n.value) == (0, 0)
+    assert L.nddm_graph_arena_info(0, None, None) == _lib.NDDM_OK                      # 0 = the ownerless list
+    assert L.nddm_graph_arena_release(0) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_graph_arena_release(b.value) == _lib.NDDM_OK                          # (bound to this thread: the binding is dropped)
+    assert L.nddm_graph_arena_bind(0, ctypes.byref(prev)) == _lib.NDDM_OK and prev.value == 0
+    assert L.nddm_graph_arena_release(b.value) == _lib.NDDM_ERR_PARAM                   # already released
+    assert L.nddm_graph_arena_bind(b.value, None) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_graph_arena_info(b.value, None, None) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_graph_arena_release(a.value) == _lib.NDDM_OK
+    assert b"arena" in L.nddm_last_error() or L.nddm_last_error() == b""
 
 
 def test_product_path_fails_loudly_without_gpu():
