@@ -37,6 +37,7 @@ libnddm_train.so builds -- are the networks' forward / backward (amortizer.py) a
 is unpinned as for amortizer.py.
 """
 import math
+import os as _os
 
 import torch
 
@@ -48,8 +49,17 @@ from .distributed import shared_prior_N
 _PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5, 5), "single": (engine.SINGLE_TRIAL, 8, 7)}
 
 
+# Cross-stream dependencies of the pipelined loop are TIMING events: such an event is a barrier packet with a completion signal of
+# its own at the point of the record.  A torch.cuda.Event() (hipEventDisableTiming) refers to the stream's last command instead, and
+# a waiter on another hardware queue then waits for whatever later packet of that queue next carries a signal -- the simulate graph
+# of batch i + 1, which only waits for batch i's staging copies, was seen starting 300-400 us into the training graph of batch i
+# (profiles/r4_train_timeline.md).
+_TIMED_EVENTS = True
+
+
 class _Bucket:
-    __slots__ = ("n_top", "params", "trials", "g_params", "g_trials", "t_params", "t_trials", "r_params", "r_trials", "graphs")
+    __slots__ = ("n_top", "shard", "params", "trials", "g_shard", "g_params", "g_trials", "t_params", "t_trials", "staged",
+                 "r_params", "r_trials", "graphs")
 
 
 class GraphTrainer:
@@ -130,14 +140,50 @@ class GraphTrainer:
         # everything the trainer enqueues -- warm-up passes, captures, replays -- goes to ONE stream of its own: autograd's
         # gradient-accumulation nodes remember the stream they were first used on, and capture needs a non-default one
         self._stream = torch.cuda.Stream(device=self.dev)
-        self._comm = torch.cuda.Stream(device=self.dev)
-        self._sim_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        # The pipelined loop needs its streams on DIFFERENT hardware queues (HIP multiplexes all streams of a priority onto four;
+        # which one a stream gets is not ours to choose): a communication stream that shared the training stream's queue ran the
+        # all-gather of batch i + 1 behind the training graph of batch i instead of beside it (+ 45 us per iteration,
+        # profiles/r4_train_timeline.md).  So the side streams are CHOSEN by a probe: independent of the streams before them.
+        # (A high-priority stream has a queue of its own by construction, but its mere existence slowed every kernel that ran
+        # beside the simulator by 2-7 x on this chip: measured, not used.)
+        self._sim_stream = self._independent_stream([self._stream]) if self.overlap else None
+        self._comm = self._independent_stream([self._stream] + ([self._sim_stream] if self.overlap else [])) \
+            if (self.overlap and self.world > 1) or self.split else torch.cuda.Stream(device=self.dev)
         self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
         # the library's memory behind THIS trainer's captured launches (include/nddm.h: nddm_graph_arena_*): close() frees
         # it and nothing else -- a second trainer, or a user's own captured graph, keeps replaying
         self._arena = engine.GraphArena() if self.use_graph else None
         self._closed = False
         self._sync_replicas()
+
+    def _independent_stream(self, others, candidates=12):
+        """A stream whose hardware queue is none of `others`' queues, found by experiment: a ~2 ms spin kernel goes to each
+        of `others`, a 4-byte fill and an event to the candidate; if the event completes while the spins still run, the
+        candidate's work does not queue behind theirs.  Falls back to the last candidate (correct, only slower)."""
+        import time
+        flag = torch.zeros(1, device=self.dev)
+        cand = None
+        with torch.cuda.device(self.dev):
+            for _ in range(candidates):
+                cand = torch.cuda.Stream(device=self.dev)
+                if any(cand.cuda_stream == o.cuda_stream for o in others):
+                    continue
+                torch.cuda.synchronize(self.dev)
+                for o in others:
+                    with torch.cuda.stream(o):
+                        torch.cuda._sleep(5_000_000)
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(cand):
+                    flag.fill_(1.0)
+                    ev.record(cand)
+                t0 = time.perf_counter()
+                while not ev.query() and time.perf_counter() - t0 < 0.7e-3:
+                    pass
+                ok = ev.query()
+                torch.cuda.synchronize(self.dev)
+                if ok:
+                    return cand
+        return cand
 
     # ------------------------------------------------------------------------------------------------ the iteration
     def bucket_top(self, n):
@@ -203,12 +249,23 @@ class GraphTrainer:
         self._stream.wait_stream(self._comm)
 
     def _gather(self, bk):
+        """ONE all-gather reassembles the minibatch (north_star): parameter rows and trials travel in one packed shard."""
         import torch.distributed as dist
-        for dst, src in ((bk.g_trials, bk.trials), (bk.g_params, bk.params)):
-            if self.backend == "nccl":
-                dist.all_gather_into_tensor(dst, src)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(bk.g_shard, bk.shard)
+        else:
+            dist.all_gather(list(bk.g_shard.unbind(0)), bk.shard)
+
+    def _stage(self, bk):
+        """The produced batch -- this rank's shard, or the gathered minibatch (rank-major strided views of the packed buffer)
+        -- into the contiguous tensors the training graph reads."""
+        if bk.staged:
+            P, n = self.P, bk.n_top
+            if bk.g_shard is not None:
+                bk.t_params.view(self.world, self.B, P).copy_(bk.g_params)
+                bk.t_trials.view(self.world, self.B, n, 2).copy_(bk.g_trials)
             else:
-                dist.all_gather(list(dst.unbind(0)), src)
+                bk.t_params.copy_(bk.params); bk.t_trials.copy_(bk.trials)
 
     def _all_reduce_gradients(self):
         import torch.distributed as dist
@@ -264,18 +321,26 @@ class GraphTrainer:
         bk = _Bucket()
         bk.n_top = n_top
         with torch.cuda.device(self.dev):
-            bk.params = torch.empty((self.B, self.P), dtype=torch.float32, device=self.dev)
-            bk.trials = torch.empty((self.B, n_top, 2), dtype=torch.float32, device=self.dev)
-            bk.g_params = bk.g_trials = None
-            src_p, src_t = bk.params, bk.trials
+            # parameter rows and trials of this rank's shard live in ONE buffer (params padded to 16 bytes), so that the
+            # exchange step is one collective
+            bp = -(-self.B * self.P // 4) * 4
+            bk.shard = torch.empty(bp + self.B * n_top * 2, dtype=torch.float32, device=self.dev)
+            bk.params = bk.shard[:self.B * self.P].view(self.B, self.P)
+            bk.trials = bk.shard[bp:].view(self.B, n_top, 2)
+            bk.g_shard = bk.g_params = bk.g_trials = None
+            rows = self.B
             if self.parallel == "gather" and self._has_collective():
-                bk.g_params = torch.empty((self.world, self.B, self.P), dtype=torch.float32, device=self.dev)
-                bk.g_trials = torch.empty((self.world, self.B, n_top, 2), dtype=torch.float32, device=self.dev)
-                src_p, src_t = bk.g_params.view(-1, self.P), bk.g_trials.view(-1, n_top, 2)
-            if self.overlap:                        # the simulator (and the all-gather) refill the sources while these are trained on
-                bk.t_params, bk.t_trials = torch.empty_like(src_p), torch.empty_like(src_t)
+                bk.g_shard = torch.empty((self.world, bk.shard.numel()), dtype=torch.float32, device=self.dev)
+                bk.g_params = bk.g_shard[:, :self.B * self.P].view(self.world, self.B, self.P)
+                bk.g_trials = bk.g_shard[:, bp:].view(self.world, self.B, n_top, 2)
+                rows = self.world * self.B
+            # staged: the producer (simulator, all-gather) refills its buffers while the training graph reads these
+            bk.staged = self.overlap or bk.g_shard is not None
+            if bk.staged:
+                bk.t_params = torch.empty((rows, self.P), dtype=torch.float32, device=self.dev)
+                bk.t_trials = torch.empty((rows, n_top, 2), dtype=torch.float32, device=self.dev)
             else:
-                bk.t_params, bk.t_trials = src_p, src_t
+                bk.t_params, bk.t_trials = bk.params, bk.trials
             bk.r_params = bk.r_trials = None          # staging of a replayed batch: allocated by the first replay iteration
             bk.graphs = {}
         self._buckets[n_top] = bk
@@ -327,6 +392,7 @@ class GraphTrainer:
             elif gather:
                 self._run(bk, "sim", sim)
                 self._on_comm_stream(lambda: self._gather(bk))
+                self._stage(bk)
                 self._run(bk, "fb+up", lambda: (fb(), up()))
             else:                                   # ddp, or the two-graph form forced at one rank without a process group
                 self._run(bk, "sim+fb", lambda: (sim(), fb()))
@@ -339,6 +405,7 @@ class GraphTrainer:
         self._run(bk, "sim", sim)
         if gather:
             self._on_comm_stream(lambda: self._gather(bk))
+            self._stage(bk)
         bt = self._replay_stage((bk.t_params.clone(), bk.t_trials.clone(), n), replay)
         fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
         up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
@@ -366,41 +433,51 @@ class GraphTrainer:
         C.wait_stream(T)
         ns = [shared_prior_N(self.seed, self.iteration + k, self.n_min, self.n_max) for k in range(int(iterations))]
         up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
+        stamps = self.stage_stamps = [] if _os.environ.get("NDDM_TRAIN_STAGE_STAMPS") else None     # developer aid (tools/train_stage_times.py)
+        # Host order of an iteration.  The producer of batch i + 1 goes to its streams BEFORE the training graph of batch i goes
+        # to its own: a cross-stream wait is resolved against what the other stream holds when the wait is ISSUED -- enqueued
+        # after the training graph, the simulate graph (which only depends on batch i's staging copies) was seen starting
+        # 300-400 us into it, and at dt=.001 (a 200 us launch) finishing after it (profiles/r4_train_timeline.md).  Only a
+        # HOST-blocking exchange (gloo) turns the order round: the host then waits in the collective while the device trains.
+        produce_first = not (gather and self.backend != "nccl")
 
         def produce(n):
             bk = self._bucket(self.bucket_top(n))
             with torch.cuda.stream(S):
                 self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                 ev.record(S)
             if gather:
                 C.wait_event(ev)
                 with torch.cuda.stream(C):
                     self._gather(bk)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     ev.record(C)
             return ev
-
-        def sources(bk):
-            if gather:
-                return bk.g_params.view(-1, self.P), bk.g_trials.view(-1, bk.n_top, 2)
-            return bk.params, bk.trials
 
         with torch.cuda.device(self.dev):
             ev = produce(ns[0]) if ns else None
             for k, n in enumerate(ns):
                 bk = self._bucket(self.bucket_top(n))
-                src_p, src_t = sources(bk)
                 with torch.cuda.stream(T):
+                    if stamps is not None:
+                        stamps.append([torch.cuda.Event(enable_timing=True) for _ in range(4)])
+                        stamps[-1][0].record(T)
                     T.wait_event(ev)
-                    if replay is None:
-                        bk.t_params.copy_(src_p); bk.t_trials.copy_(src_t)
-                    else:
-                        entry = (src_p.clone(), src_t.clone(), n)
-                    taken = torch.cuda.Event()
+                    if stamps is not None:
+                        stamps[-1][1].record(T)
+                    self._stage(bk)
+                    if replay is not None:
+                        entry = (bk.t_params.clone(), bk.t_trials.clone(), n)
+                    taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     taken.record(T)
-                with torch.cuda.stream(T):              # (enqueued BEFORE the next batch's producer: a host-blocking exchange --
-                    self._keep_loss_ring()              #  gloo -- then waits while the device trains)
+                if produce_first and k + 1 < len(ns):
+                    S.wait_event(taken)
+                    if gather:
+                        C.wait_event(taken)
+                    ev = produce(ns[k + 1])
+                with torch.cuda.stream(T):
+                    self._keep_loss_ring()
                     if replay is None:
                         self.n_f.fill_(float(n))
                         b, pre = bk, ""
@@ -415,8 +492,12 @@ class GraphTrainer:
                             self._on_comm_stream(self._all_reduce_gradients)
                         self._run(b, "up", up)
                     else:
+                        if stamps is not None:
+                            stamps[-1][2].record(T)
                         self._run(b, pre + "fb+up", lambda: (fb(), up()))
-                if k + 1 < len(ns):
+                        if stamps is not None:
+                            stamps[-1][3].record(T)
+                if not produce_first and k + 1 < len(ns):
                     S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers ...
                     if gather:
                         C.wait_event(taken)             # ... and its all-gather the reassembled minibatch
