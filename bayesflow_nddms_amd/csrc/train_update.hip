@@ -2,7 +2,7 @@
 // of basic_ddm_dc.py:199-202 with BayesFlow's defaults: Adam, global-norm clipping, cosine learning-rate decay) on FLAT buffers:
 // every parameter is a view of one array, and so are the gradients and Adam's two moments.  In PyTorch the step is ~20 launches
 // (learning rate: 5, clip_grad_norm_: 6, the fused multi-tensor Adam: 4 of 7-23 microseconds over 130 tensors, counters and the
-// loss history: 4); here it is three: squared-norm partial sums, the update, the counters.  Everything is deterministic (fixed
+// loss history: 4); here it is two: squared-norm partial sums, and the update (whose last workgroup advances the counters).  Everything is deterministic (fixed
 // summation order).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -39,8 +39,11 @@ __device__ __forceinline__ float cosine_lr(const Hyper &H, float step_f)
     return 0.5f * H.lr0 * (1.0f + cosf(fminf(step_f, total) * (float)(M_PI / (double)total)));
 }
 
+// (the counters of the step -- loss into the history, the rate that was used, step_i / step_f -- are advanced by the LAST workgroup
+// to finish: every workgroup has read them by then; `ticket` is a device word that is zero between launches)
 __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, float4 *m, float4 *v, long long n4, const float *partial,
-                                                  Hyper H, const long long *step_i, const float *step_f)
+                                                  Hyper H, long long *step_i, float *step_f, float *lr_out, float *loss_buf, int loss_cap,
+                                                  float *loss_slot, unsigned int *ticket)
 {
     __shared__ float red[NB];
     __shared__ float sh[4];
@@ -76,18 +79,23 @@ __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, fl
         m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
         v[i] = make_float4(ww[0], ww[1], ww[2], ww[3]);
     }
-}
-
-// after the update: the loss into the history at the step's index, the learning rate that was used, the counters
-__global__ void counters_kernel(Hyper H, long long *step_i, float *step_f, float *lr_out, float *loss_buf, int loss_cap, float *loss_slot)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const long long s = *step_i;
-    *loss_slot *= H.grad_scale;
-    if (loss_cap > 0) loss_buf[s % loss_cap] = *loss_slot;          // a RING: the host drains it before it wraps (GraphTrainer._drain_losses)
-    *lr_out = cosine_lr(H, *step_f);
-    *step_i = s + 1;
-    *step_f += 1.0f;
+    // every thread of this workgroup has read step_i / step_f (through thread 0, before the barrier above); the last workgroup to
+    // get here advances them -- after all the others have passed the same point
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (relaxed: nothing this workgroup wrote is read inside the kernel, and its reads of the counters completed before the
+        //  barrier; an acquire-release here is an L2 write-back and invalidate per workgroup -- measured: + 10 us on this kernel)
+        const unsigned int done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            const long long s = *step_i;
+            *loss_slot *= H.grad_scale;
+            if (loss_cap > 0) loss_buf[s % loss_cap] = *loss_slot;      // a RING: the host drains it before it wraps (GraphTrainer._drain_losses)
+            *lr_out = cosine_lr(H, *step_f);
+            *step_i = s + 1;
+            *step_f += 1.0f;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace nddm_update
@@ -96,11 +104,12 @@ using namespace nddm_update;
 
 /* One optimizer step on flat buffers of n floats (n a multiple of 4, 16-byte aligned): p -= Adam(clip(grad_scale * g)) with the
  * cosine learning rate of step min(*step_f, total_steps); then loss_buf[*step_i mod loss_cap] = grad_scale * *loss_slot (written
- * back to the slot too; the history is a ring the caller reads out before it wraps), *lr_out = the rate used, and both counters advance.  partial: 256 floats of scratch.  Adam's step count is *step_i + 1. */
+ * back to the slot too; the history is a ring the caller reads out before it wraps), *lr_out = the rate used, and both counters advance.  partial: 256 floats of scratch + one word, partial[256], that must be ZERO at the first launch (the kernel leaves it zero).  Adam's step count is *step_i + 1. */
 extern "C" int nddm_train_adam_step(float *p, const float *g, float *m, float *v, long long n, float *partial, float grad_scale, float clip,
                                     float lr0, float total_steps, float beta1, float beta2, float eps, long long *step_i, float *step_f,
                                     float *lr_out, float *loss_buf, int loss_cap, float *loss_slot, void *stream)
 {
+    // partial: 256 floats of scratch + ONE word (index 256) that is zero between launches: the workgroups' completion ticket
     if (n <= 0 || (n & 3) || !p || !g || !m || !v || !partial || !step_i || !step_f || !lr_out || !loss_slot) return 1;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
         return 1;
@@ -110,7 +119,7 @@ extern "C" int nddm_train_adam_step(float *p, const float *g, float *m, float *v
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NB), dim3(NT), 0, st, reinterpret_cast<const float4 *>(g), n4, partial);
     const int blocks = (int)((n4 + NT - 1) / NT < 1024 ? (n4 + NT - 1) / NT : 1024);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(NT), 0, st, reinterpret_cast<float4 *>(p), reinterpret_cast<const float4 *>(g),
-                       reinterpret_cast<float4 *>(m), reinterpret_cast<float4 *>(v), n4, partial, H, step_i, step_f);
-    hipLaunchKernelGGL(counters_kernel, dim3(1), dim3(64), 0, st, H, step_i, step_f, lr_out, loss_buf, loss_cap, loss_slot);
+                       reinterpret_cast<float4 *>(m), reinterpret_cast<float4 *>(v), n4, partial, H, step_i, step_f, lr_out, loss_buf, loss_cap,
+                       loss_slot, reinterpret_cast<unsigned int *>(partial + NB));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

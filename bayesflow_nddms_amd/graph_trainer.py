@@ -113,11 +113,12 @@ class GraphTrainer:
                     pad = -p.numel() % 4
                     self._pads.append(torch.zeros(pad, dtype=torch.float32, device=self.dev) if pad else None)
             self.lr_t = torch.tensor(self.lr0, dtype=torch.float32, device=self.dev)
+            self._one = torch.ones((), dtype=torch.float32, device=self.dev)
             from . import _train_lib
             self._lib = _train_lib.lib()
             if self._lib is not None:
                 self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
-                self._partial = torch.zeros(256, dtype=torch.float32, device=self.dev)
+                self._partial = torch.zeros(256 + 4, dtype=torch.float32, device=self.dev)      # 256 partial sums + the update kernel's ticket word
                 self.optimizer = None
             else:
                 # without the library: PyTorch's fused multi-tensor Adam on the same flat layout (one tensor)
@@ -206,7 +207,7 @@ class GraphTrainer:
         loss = self.amortizer.compute_loss(conf)
         # gradients straight into the flat buffer with ONE concatenation (accumulating into pre-set .grad views costs one add
         # kernel per parameter tensor plus the zero fill; torch._foreach_copy_ runs as one copy per tensor here: ~90 launches)
-        grads = torch.autograd.grad(loss, self.params)
+        grads = torch.autograd.grad(loss, self.params, grad_outputs=self._one)      # (a constant seed: autograd's own ones_like is a fill launch)
         pieces = []
         for g, pad in zip(grads, self._pads):
             pieces.append(g.reshape(-1))

@@ -40,7 +40,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CLOCK_GHZ = 2.4                # nominal engine clock the cycle figures are quoted at
-ARITHMETIC = "f32 state and Gaussian transform, integer step index (rt = k*dt + tau exact in k); the reference integrates in f64"
+ARITHMETIC = ("f32 state and Gaussian transform, integer step index (rt = k*dt + tau exact in k); the reference integrates in f64: on the "
+              "same normals the two end a trial on another (step, choice) in 7.6e-5 of 2e6 prior-mixture trials at dt=.001/4000 and 4e-6 at "
+              "dt=.01/400, no choice differs (tests/test_oracle_golden.py::test_f32_integrator_against_the_reference_f64_recurrence)")
 
 MODELS = {  # bench name -> (engine model attribute, bridge, host prior matrix, oracle model attribute, index of tau)
     "basic": ("BASIC_DDM_DC", False, "basic_prior_matrix", "M_BASIC", 3),
@@ -592,6 +594,19 @@ def simulate_bench(a, ctx):
             rv.update({"issue_model": im, "peak_issue_model": peak_im / 1e9, "frac_vs_issue_model": achieved_steps / peak_im})
             if "frac" not in rv:
                 rv.update({"peak": peak_im / 1e9, "frac": achieved_steps / peak_im, "ceiling": "ISA issue model (no lockstep run)"})
+        # an OUTSIDE yardstick beside the two self-measured ceilings: the vendor's device API doing what north_star names
+        # ("hiprandStatePhilox per lane": rocrand_state_philox4x32_10 + rocrand_normal4 in a loop), measured on this chip by
+        # tools/ubench_rocrand.hip and read from the tracked file, like `traffic`
+        try:
+            y = json.load(open(os.path.join(ROOT, "profiles", "r4_ubench_rocrand.json")))
+            rv["vendor_philox_normals_per_s"] = y["fast_math"]["rocrand_normal4_normals_per_s"]
+            rv["vendor_philox"] = {"normals_per_s_default_build": y["rocrand_normal4_normals_per_s"],
+                                   "normals_per_s_fast_math": y["fast_math"]["rocrand_normal4_normals_per_s"],
+                                   "normals_with_an_em_step_per_s_fast_math": y["fast_math"]["rocrand_normal4_plus_step_normals_per_s"],
+                                   "raw_u32_per_s": y["rocrand4_u32_per_s"], "source": y["source"],
+                                   "this_kernel_over_vendor_with_step": achieved_steps / y["fast_math"]["rocrand_normal4_plus_step_normals_per_s"]}
+        except (OSError, KeyError, ValueError):
+            pass
         res["roofline_valu"] = rv
         # steps the lanes actually EXECUTED (incl. lanes idling on a finished trial until the next refill): one more
         # launch of the last batch, outside the timed region, with the kernel's debug counters switched on

@@ -53,6 +53,10 @@ def lib():
             ctypes.c_uint64, ctypes.c_float, ctypes.c_int, fp, ctypes.POINTER(ctypes.c_int32), fp, fp,
             ctypes.c_int]
         L.oracle_philox_simulate.restype = ctypes.c_int
+        ip = ctypes.POINTER(ctypes.c_int32)
+        L.oracle_philox_simulate_f64.argtypes = [ctypes.c_int, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                 ctypes.c_uint64, ctypes.c_uint64, ip, ip, ctypes.c_int]
+        L.oracle_philox_simulate_f64.restype = ctypes.c_int
         L.oracle_philox_normals4.argtypes = [ctypes.c_uint32] * 6 + [fp]
         L.oracle_philox_block.argtypes = [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
@@ -155,6 +159,41 @@ def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, s
     if want_ext:
         res["ext"] = ext
     return res
+
+
+def philox_simulate_f64(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, set_offset=0, threads=1):
+    """The REFERENCE'S float64 recurrence (basic_ddm_dc.py:91-103; single_trial_alpha_not_scaled.py:113-128) on the device
+    stream's normals: (k i32[B,N], choice i32[B,N]) -- compare with philox_simulate(want_k=True) trial by trial to state how
+    often the float32 integrator of the product ends on another (step, choice) than the float64 one."""
+    L = lib()
+    P = L.oracle_model_nparams(model)
+    p = np.ascontiguousarray(params, dtype=np.float32)
+    if p.ndim == 1:
+        p = p[None]
+    assert p.shape[1] == P
+    B = p.shape[0]
+    k = np.empty((B, n_trials), np.int32)
+    c = np.empty((B, n_trials), np.int32)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    rc = L.oracle_philox_simulate_f64(model, _fptr(p), B, n_trials, np.float32(dt), int(np.ceil(max_steps)), seed, set_offset,
+                                      k.ctypes.data_as(ip), c.ctypes.data_as(ip), threads)
+    if rc != 0:
+        raise ValueError(f"oracle_philox_simulate_f64 rc={rc}")
+    return k, c
+
+
+def integrator_disagreement(model, params, n_trials, dt, max_steps, seed=0, set_offset=0, threads=1):
+    """float32 (product arithmetic) against float64 (reference arithmetic) on the same normals: dict with the number of
+    trials, the fraction whose (k, choice) differ, the fraction whose choice differs, and the largest |delta k|."""
+    r = philox_simulate(model, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, want_k=True,
+                        want_summary=False, threads=threads)
+    k32 = r["k"]
+    t = r["trials"]
+    c32 = (t[..., 1] if model == M_BASIC else np.sign(t[..., 0])).astype(np.int32)
+    k64, c64 = philox_simulate_f64(model, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, threads=threads)
+    differ = (k32 != k64) | (c32 != c64)
+    return {"trials": int(k32.size), "differ": float(differ.mean()), "choice_differs": float((c32 != c64).mean()),
+            "max_abs_dk": int(np.abs(k32.astype(np.int64) - k64).max()), "n_differ": int(differ.sum())}
 
 
 def philox_normals4(c0, c1, c2, c3, k0, k1):

@@ -419,7 +419,7 @@ def test_flat_adam_step_equals_pytorch():
     opt = torch.optim.Adam([ref], lr=lr0)
     p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     g = torch.zeros(n + 1, device="cuda")
-    partial = torch.zeros(256, device="cuda")
+    partial = torch.zeros(256 + 4, device="cuda")              # (+ the ticket word of the update kernel: zero between launches)
     step_i, step_f = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, device="cuda")
     lr_out, loss_buf = torch.zeros((), device="cuda"), torch.zeros(4, device="cuda")
     for it in range(6):
