@@ -185,17 +185,18 @@ class _FusedDeepSetFn(torch.autograd.Function):
         st = torch.cuda.current_stream(dev).cuda_stream
         cm = _FusedDeepSetFn._common
         count = mask is not None and mask.numel() == 1 and inv_n is None
+        # every MLP that pools (the blocks' invariant halves, the pre-pooling MLP) consumes the rows the equivariant MLP before
+        # it produces: the two run as ONE launch (the first invariant MLP, on the raw trials, alone)
         cur, d, rc = x, d0, 0
+        pooling = [params[12 * i:12 * i + 6] for i in range(nb)] + [params[12 * nb:12 * nb + 6]]     # inv_0 .. inv_{nb-1}, pre
+        rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pooling[0]), act(0, 0).data_ptr(),
+                                     act(0, 1).data_ptr(), None, pools[0].data_ptr(), st)
         for i in range(nb):
-            inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
-            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, inv), act(2 * i, 0).data_ptr(),
-                                         act(2 * i, 1).data_ptr(), None, pools[i].data_ptr(), st)
-            rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
-                                         act(2 * i + 1, 1).data_ptr(), xs_next[i].data_ptr(), None, st)
+            eq, nxt = params[12 * i + 6:12 * i + 12], pooling[i + 1]
+            rc |= L.nddm_deepset_mlp2_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
+                                          act(2 * i + 1, 1).data_ptr(), xs_next[i].data_ptr(), *[t.data_ptr() for t in nxt],
+                                          act(2 * i + 2, 0).data_ptr(), act(2 * i + 2, 1).data_ptr(), pools[i + 1].data_ptr(), st)
             cur, d = xs_next[i], Hd
-        pre = params[12 * nb:12 * nb + 6]
-        rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pre), act(2 * nb, 0).data_ptr(),
-                                     act(2 * nb, 1).data_ptr(), None, pools[nb].data_ptr(), st)
         # (1 / N as the host's value must be THIS launch's N, not the B rows the post-pooling MLP is launched over)
         cp = list(cm(None, Hd, 1, B, Sp, rpw, mask if count else None, inv_n, None, 0, post, pools[nb], S))
         cp[9] = 1.0 / N
@@ -242,21 +243,31 @@ class _FusedDeepSetFn(torch.autograd.Function):
         cp[9] = 1.0 / N
         rc = L.nddm_deepset_mlp_bwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), g_summary.data_ptr(), None, 0, None, 0,
                                     g_pooled.data_ptr(), 0, None, pp + offs[2 * nb + 1] * F, P, st)
-        xin, d = x_of(nb)
         pre = params[12 * nb:12 * nb + 6]
-        rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, pre), act(2 * nb, 0).data_ptr(),
-                                     act(2 * nb, 1).data_ptr(), None, g_pooled.data_ptr(), 0, None, 0,
-                                     gxbuf[nb - 1].data_ptr() if nb else None, 0, None, pp + offs[2 * nb] * F, P, st)
-        for i in reversed(range(nb)):
-            inv, eq = params[12 * i:12 * i + 6], params[12 * i + 6:12 * i + 12]
-            xin, d = x_of(i)
-            gx = gxbuf[i - 1].data_ptr() if i else None
-            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
-                                         act(2 * i + 1, 1).data_ptr(), gxbuf[i].data_ptr(), None, 0, None, 0, gx, 0,
-                                         dctx[i].data_ptr(), pp + offs[2 * i + 1] * F, P, st)
-            rc |= L.nddm_deepset_mlp_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, None, 0, inv), act(2 * i, 0).data_ptr(),
-                                         act(2 * i, 1).data_ptr(), None, dctx[i].data_ptr(), S, eq[0].data_ptr() + d * F, d + Hd,
-                                         gx, 1, None, pp + offs[2 * i] * F, P, st)
+        if nb == 0:
+            rc |= L.nddm_deepset_mlp_bwd(*cm(x, d0, B, N, S, rpw, mask, inv_n, None, 0, pre), act(0, 0).data_ptr(), act(0, 1).data_ptr(),
+                                         None, g_pooled.data_ptr(), 0, None, 0, None, 0, None, pp + offs[0] * F, P, st)
+        # The backward of a pooling MLP X (pre-pooling, or a block's invariant half) and of the equivariant MLP Y that produced X's
+        # input are ONE launch each (csrc/train_deepset.hip: mlp2_bwd_kernel): pre + eq_{nb-1}, then inv_i + eq_{i-1}, then inv_0
+        # alone.  X's input gradient -- plus eq_i's, which the launch before left in gxbuf -- is Y's output gradient.
+        for j in reversed(range(nb)):                       # Y = eq_j;  X = pre (j == nb - 1) or inv_{j+1}
+            eq = params[12 * j + 6:12 * j + 12]
+            xin, d = x_of(j)
+            if j == nb - 1:
+                X, hx, ox = pre, 2 * nb, offs[2 * nb]
+                gpool, gp_S, gp_W, gp_ldw, gx_prev = g_pooled.data_ptr(), 0, None, 0, None
+            else:
+                X, hx, ox = params[12 * (j + 1):12 * (j + 1) + 6], 2 * (j + 1), offs[2 * (j + 1)]
+                eq_next = params[12 * (j + 1) + 6:12 * (j + 1) + 12]          # (its context columns carry the pooled gradient)
+                gpool, gp_S, gp_W, gp_ldw, gx_prev = dctx[j + 1].data_ptr(), S, eq_next[0].data_ptr() + Hd * F, 2 * Hd, gxbuf[j].data_ptr()
+            rc |= L.nddm_deepset_mlp2_bwd(*cm(xin, d, B, N, S, rpw, mask, inv_n, pools[j], S, eq), act(2 * j + 1, 0).data_ptr(),
+                                          act(2 * j + 1, 1).data_ptr(), gxbuf[j - 1].data_ptr() if j else None, dctx[j].data_ptr(),
+                                          pp + offs[2 * j + 1] * F, xs_next[j].data_ptr(), *[t.data_ptr() for t in X],
+                                          act(hx, 0).data_ptr(), act(hx, 1).data_ptr(), gpool, gp_S, gp_W, gp_ldw, gx_prev, pp + ox * F, P, st)
+        if nb:
+            inv, eq = params[0:6], params[6:12]
+            rc |= L.nddm_deepset_mlp_bwd(*cm(x, d0, B, N, S, rpw, mask, inv_n, None, 0, inv), act(0, 0).data_ptr(), act(0, 1).data_ptr(),
+                                         None, dctx[0].data_ptr(), S, eq[0].data_ptr() + d0 * F, d0 + Hd, None, 0, None, pp + offs[0] * F, P, st)
         rc |= L.nddm_deepset_reduce(pp, G, P, offs[2 * nb + 1], Sp, flat.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_bwd failed ({rc})")

@@ -23,6 +23,7 @@ constexpr int TM = 64;        // rows per tile
 constexpr int NT = 256;       // threads per workgroup: wave w owns the 32 x 32 tile (w >> 1, w & 1) of every 64 x 64 product
 constexpr int DS_MAX = 4;     // a "small" input (the raw trials: rt, choice) goes through layer 1 as plain FMAs
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // (register arrays of HIP's float4 STRUCT were seen kept in memory; of this type not)
 
 #ifdef NDDM_TRAIN_STAMPS      // development only: phase time stamps of one workgroup (tools/train_stamps.py)
 __device__ unsigned long long g_stamps[8192];
@@ -277,6 +278,169 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
     }
 }
 
+// ---- two MLPs in one launch --------------------------------------------------------------------------------------------------
+// An equivariant MLP (A: input x, the set's pooled context through W1's context columns, output y) and the MLP that consumes its
+// output row by row (B: the NEXT block's invariant MLP, or the pre-pooling MLP; no context; only the masked per-set sums of its
+// output are wanted).  B's rows are A's rows, so nothing crosses a workgroup between them: the y tile stays in LDS as B's input,
+// B's three weight matrices are fetched into registers while A computes and stored to LDS when A's readers are done -- one launch
+// and one exposed weight-staging latency instead of two of each.  One 64-row tile per workgroup (rows_per_wg == TM).
+__device__ __forceinline__ void fetch64(f32x4 (&v)[HS * HS / 4 / NT], const float *src, int ldw, int t, int rows = HS)
+{
+#pragma unroll
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        v[k] = *reinterpret_cast<const f32x4 *>(src + (long long)min(r, rows - 1) * ldw + 4 * c4);
+    }
+}
+__device__ __forceinline__ void store64(float (*dst)[LD], const f32x4 (&v)[HS * HS / 4 / NT], int t, int rows = HS)
+{
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        *reinterpret_cast<f32x4 *>(&dst[r][4 * c4]) = r < rows ? v[k] : z;
+    }
+}
+
+template <bool BIG>        // of MLP A: d_in == 64 or d_in <= DS_MAX (B's input is A's 64-wide output)
+__global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2, FwdOut O2)
+{
+    __shared__ __attribute__((aligned(16))) float w1s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w2s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w3s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float xs[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h1s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h2s[TM][LD];
+    __shared__ float w1small[BIG ? 1 : HS][DS_MAX], xsmall[BIG ? 1 : TM][DS_MAX];
+    __shared__ float cs[HS], pooled[HS], red[4][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, kk = lane >> 5, rb = wave >> 1, ub = wave & 1;
+    const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
+    const int n0 = sp * C.rows_per_wg, n_end = min(C.N, n0 + C.rows_per_wg);
+    const long long row0 = (long long)b * C.N;
+    const float inv_n = inv_count(C);
+    // ---- A's input tile and weights -> LDS; B's weights -> registers
+    if (BIG) {
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
+            float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (n < n_end) v = x_row4(C, row0 + n, c4, inv_n);
+            *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = v;
+        }
+    } else {
+        for (int p = t; p < TM * C.d_in; p += NT) {
+            const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
+            xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
+        }
+    }
+    stage64(w2s, C.P.W2, HS, t);
+    stage64(w3s, C.P.W3, HS, t);
+    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    else
+        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
+    f32x4 q1[HS * HS / 4 / NT], q2[HS * HS / 4 / NT], q3[HS * HS / 4 / NT];
+    fetch64(q1, P2.W1, HS, t);
+    fetch64(q2, P2.W2, HS, t);
+    fetch64(q3, P2.W3, HS, t);
+    context(C, b, pooled, cs, t);
+    __syncthreads();
+    const int u = 32 * ub + m;                       // this lane's column of every result tile
+    const float bias2 = C.P.b2[u], bias3 = C.P.b3[u], bias1 = cs[u];
+    const float c1 = P2.b1[u], c2 = P2.b2[u], c3 = P2.b3[u];
+    // ---- MLP A
+    if (BIG) {
+        const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            const float val = fmaxf(acc[v] + bias1, 0.0f);
+            h1s[r][u] = val;
+            if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + u] = val;
+        }
+    } else {
+        const int uu = t & 63, rg = t >> 6;
+        float w[DS_MAX];
+#pragma unroll
+        for (int c = 0; c < DS_MAX; ++c) w[c] = c < C.d_in ? w1small[uu][c] : 0.0f;
+        const float c0 = cs[uu];
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int r = 16 * rg + q;
+            float a = c0;
+#pragma unroll
+            for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) a = fmaf(w[c], xsmall[r][c], a);
+            const float val = fmaxf(a, 0.0f);
+            h1s[r][uu] = val;
+            if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
+        }
+    }
+    __syncthreads();
+    {
+        const f32x16 acc = mma64<1, 1>(&h1s[32 * rb + m][32 * kk], &w2s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            const float val = fmaxf(acc[v] + bias2, 0.0f);
+            h2s[r][u] = val;
+            if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
+        }
+    }
+    __syncthreads();
+    {   // A's output: to global memory (the next equivariant MLP and the backward read it) and into xs as B's input
+        const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk), n = n0 + r;
+            const float val = n < n_end ? acc[v] + bias3 : 0.0f;          // (rows beyond the set: zero, as a loaded tile has them)
+            xs[r][u] = val;                                               // (xs: A's layer 1 finished reading it two barriers ago)
+            if (n < n_end) O.y[(row0 + n) * HS + u] = val;
+        }
+    }
+    __syncthreads();                                 // A's readers of w1s / w2s / w3s / h1s / h2s are done; xs is complete
+    store64(w1s, q1, t);
+    store64(w2s, q2, t);
+    store64(w3s, q3, t);
+    __syncthreads();
+    // ---- MLP B
+    {
+        const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            const float val = fmaxf(acc[v] + c1, 0.0f);
+            h1s[r][u] = val;
+            if (n0 + r < n_end) O2.h1[(row0 + n0 + r) * HS + u] = val;
+        }
+    }
+    __syncthreads();
+    {
+        const f32x16 acc = mma64<1, 1>(&h1s[32 * rb + m][32 * kk], &w2s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            const float val = fmaxf(acc[v] + c2, 0.0f);
+            h2s[r][u] = val;
+            if (n0 + r < n_end) O2.h2[(row0 + n0 + r) * HS + u] = val;
+        }
+    }
+    __syncthreads();
+    float pacc = 0.0f;
+    {
+        const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int n = n0 + 32 * rb + drow(v, kk);
+            if (n < n_end) pacc = fmaf(mask_of(C, n), acc[v] + c3, pacc);
+        }
+    }
+    red[wave][lane] = pacc;                          // fixed-order sum of the four lanes that share a column (as mlp_fwd_kernel)
+    __syncthreads();
+    if (t < HS) {
+        const int cb = t >> 5, n = t & 31;
+        O2.pool_part[((long long)b * C.S + sp) * HS + t] = (red[cb][n] + red[cb][n + 32]) + (red[2 + cb][n] + red[2 + cb][n + 32]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 struct BwdIO {
     const float *h1, *h2;            // saved by the forward
@@ -488,6 +652,268 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     STAMP(206);
 }
 
+// ---- two MLPs' backward in one launch --------------------------------------------------------------------------------------------
+// The mirror image of mlp2_fwd_kernel: the backward of a POOLING MLP X (the next block's invariant MLP or the pre-pooling MLP: its
+// output gradient arrives through the pooled mean only; its input is the output of ...) followed by the backward of the
+// EQUIVARIANT MLP Y that produced that input.  X's input gradient -- plus, where the rows also fed an equivariant MLP, that MLP's
+// input gradient from the launch before (gx_prev) -- is Y's output gradient, row for row: it stays in LDS.  Y's weights, saved
+// activations and input tile are fetched into registers while X computes.  Common describes Y.  One tile per workgroup.
+struct Bwd2 {
+    const float *x1;                 // [B * N, 64] X's input (= Y's output, saved by the forward)
+    Mlp PX;                          // X's weights (no context: W1 [64, 64])
+    const float *h1x, *h2x;          // X's saved activations
+    const float *gpool; int gp_S;    // the gradient through X's pooled output: the two forms of BwdIO
+    const float *gp_W; int gp_ldw;
+    const float *gx_prev;            // [B * N, 64] or null: added to X's input gradient
+    float *wpart_x;                  // X's weight-gradient partial sums (row blockIdx.x, stride ld_part)
+    const float *h1y, *h2y;          // Y's saved activations
+    float *gx;                       // [B * N, 64] Y's input gradient, or null (always null for a small input)
+    float *dctx_part;                // [B, S, 64] Y's sum of d(pre-activation 1)
+    float *wpart_y; int ld_part;
+};
+
+template <bool BIG>        // of Y: d_in == 64 or d_in <= DS_MAX
+// (143 KB of LDS: one workgroup per CU, i.e. one wave per SIMD -- the whole register file is this wave's; with the default
+//  budget the prefetched operands spilled to scratch)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp2_bwd_kernel(Common C, Bwd2 Q)
+{
+    __shared__ __attribute__((aligned(16))) float w1s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w2s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float w3s[HS][LD];
+    __shared__ __attribute__((aligned(16))) float xs[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h1s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float h2s[TM][LD];
+    __shared__ __attribute__((aligned(16))) float gs[TM][LD];
+    __shared__ __attribute__((aligned(16))) float d2s[TM][LD];
+    __shared__ float xsmall[BIG ? 1 : TM][DS_MAX];
+    __shared__ float pooled[HS], cs[HS], gp[HS], dsum[HS], red[4][3][HS], redw[BIG ? 1 : 4][HS][DS_MAX], db1s[HS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, kk = lane >> 5, rb = wave >> 1, ub = wave & 1;
+    const int b = blockIdx.x / C.S, sp = blockIdx.x - b * C.S;
+    const int n0 = sp * C.rows_per_wg, n_end = min(C.N, n0 + C.rows_per_wg);
+    const long long row0 = (long long)b * C.N;
+    const float inv_n = inv_count(C);
+    const int u = 32 * ub + m, uu = t & 63, rg = t >> 6;
+    // ---- X's tile and weights -> LDS
+#pragma unroll
+    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
+        float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vx = v1;
+        if (n < n_end) {
+            const long long o = (row0 + n) * HS + 4 * c4;
+            v1 = *reinterpret_cast<const float4 *>(Q.h1x + o);
+            v2 = *reinterpret_cast<const float4 *>(Q.h2x + o);
+            vx = *reinterpret_cast<const float4 *>(Q.x1 + o);
+        }
+        *reinterpret_cast<float4 *>(&h1s[r][4 * c4]) = v1;
+        *reinterpret_cast<float4 *>(&h2s[r][4 * c4]) = v2;
+        *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = vx;
+        *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    stage64(w2s, Q.PX.W2, HS, t);
+    stage64(w3s, Q.PX.W3, HS, t);
+    stage64(w1s, Q.PX.W1, HS, t);
+    // ---- Y's operands -> registers (stored to LDS when X's readers are done)
+    f32x4 q1[HS * HS / 4 / NT], q2[HS * HS / 4 / NT], q3[HS * HS / 4 / NT], th1[TM * HS / 4 / NT], th2[TM * HS / 4 / NT], tx[TM * HS / 4 / NT];
+    fetch64(q2, C.P.W2, HS, t);
+    fetch64(q3, C.P.W3, HS, t);
+    fetch64(q1, BIG ? C.P.W1 : C.P.W2, BIG ? C.P.ldw1 : HS, t);          // (unconditional: a guarded fetch is a branch around every load)
+#pragma unroll
+    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        const long long o = (row0 + min(n0 + r, n_end - 1)) * HS + 4 * c4;          // (clamped: rows beyond the set are zeroed at the store)
+        th1[k] = *reinterpret_cast<const f32x4 *>(Q.h1y + o);
+        th2[k] = *reinterpret_cast<const f32x4 *>(Q.h2y + o);
+        tx[k] = BIG ? *reinterpret_cast<const f32x4 *>(C.x + o) : th1[k];
+    }
+    if (!BIG)
+        for (int p = t; p < TM * C.d_in; p += NT) {
+            const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
+            xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
+        }
+    context(C, b, pooled, cs, t);                    // Y's pooled context (for the context columns' weight gradient)
+    if (Q.gp_W) {                                    // the gradient of X's pooled output, per unit of this set
+        if (t < HS) {
+            float a = 0.0f;
+            for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
+            dsum[t] = a;
+        }
+        __syncthreads();
+        const int k = t >> 2, q = t & 3;
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a = fmaf(Q.gp_W[(long long)(16 * q + i) * Q.gp_ldw + k], dsum[16 * q + i], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (q == 0) gp[k] = a * inv_n;
+    } else if (t < HS) {
+        gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TM * HS / 4 / NT; ++k) {     // the pooled output's gradient, spread over the set's real trials
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
+        if (n < n_end) {
+            const float mk = mask_of(C, n);
+            *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = make_float4(mk * gp[4 * c4], mk * gp[4 * c4 + 1], mk * gp[4 * c4 + 2], mk * gp[4 * c4 + 3]);
+        }
+    }
+    __syncthreads();
+    // ================================================================================ X
+    {
+        f32x16 aW1, aW2, aW3;
+        float db[3] = {0.0f, 0.0f, 0.0f};
+        aW3 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &h2s[32 * kk][u], zero16());
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[2] += gs[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w3s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                d2s[r][u] = h2s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+        aW2 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &h1s[32 * kk][u], zero16());
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[1] += d2s[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&d2s[32 * rb + m][32 * kk], &w2s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                gs[r][u] = h1s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[0] += gs[16 * rg + q][uu];
+        aW1 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &xs[32 * kk][u], zero16());
+        {   // X's input gradient (+ the other consumer's) = Y's output gradient: into d2s (its readers finished before the barrier above)
+            const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk), n = n0 + r;
+                float g = 0.0f;
+                if (n < n_end) g = Q.gx_prev ? Q.gx_prev[(row0 + n) * HS + u] + acc[v] : acc[v];
+                d2s[r][u] = g;
+            }
+        }
+        float *wp = Q.wpart_x + (long long)blockIdx.x * Q.ld_part;
+        const int oW1 = 0, ob1 = HS * HS, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + HS * HS;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            wp[oW1 + r * HS + u] = aW1[v];
+            wp[oW2 + r * HS + u] = aW2[v];
+            wp[oW3 + r * HS + u] = aW3[v];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) red[rg][l][uu] = db[l];
+        __syncthreads();                             // (also: every reader of X's tiles and weights is done, d2s is complete)
+        if (t < 3 * HS) {
+            const int l = t >> 6, c = t & 63;
+            wp[l == 0 ? ob1 + c : (l == 1 ? ob2 + c : ob3 + c)] = (red[0][l][c] + red[1][l][c]) + (red[2][l][c] + red[3][l][c]);
+        }
+    }
+    // ================================================================================ Y
+    store64(w2s, q2, t);
+    store64(w3s, q3, t);
+    if (BIG) store64(w1s, q1, t);
+#pragma unroll
+    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        const bool ok = n0 + r < n_end;
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4 *>(&h1s[r][4 * c4]) = ok ? th1[k] : z;
+        *reinterpret_cast<f32x4 *>(&h2s[r][4 * c4]) = ok ? th2[k] : z;
+        if (BIG) *reinterpret_cast<f32x4 *>(&xs[r][4 * c4]) = ok ? tx[k] : z;
+    }
+    __syncthreads();                                 // (and the readers of red[] above are done before Y's epilogue writes it)
+    {
+        f32x16 aW1 = zero16(), aW2, aW3;
+        float db[3] = {0.0f, 0.0f, 0.0f};
+        float dw1[DS_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // the output gradient is in d2s; gs takes d(pre-activation 2), then d2s d(pre-activation 1): the single kernel's roles, swapped
+        aW3 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &h2s[32 * kk][u], zero16());
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[2] += d2s[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&d2s[32 * rb + m][32 * kk], &w3s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                gs[r][u] = h2s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+        aW2 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &h1s[32 * kk][u], zero16());
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[1] += gs[16 * rg + q][uu];
+        {
+            const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w2s[32 * kk][u], zero16());
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * rb + drow(v, kk);
+                d2s[r][u] = h1s[r][u] > 0.0f ? acc[v] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 16; ++q) db[0] += d2s[16 * rg + q][uu];
+        if (BIG) {
+            aW1 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &xs[32 * kk][u], zero16());
+            if (Q.gx) {
+                const f32x16 acc = mma64<1, LD>(&d2s[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int n = n0 + 32 * rb + drow(v, kk);
+                    if (n < n_end) Q.gx[(row0 + n) * HS + u] = acc[v];
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const float d = d2s[16 * rg + q][uu];
+#pragma unroll
+                for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) dw1[c] = fmaf(d, xsmall[16 * rg + q][c], dw1[c]);
+            }
+        }
+        float *wp = Q.wpart_y + (long long)blockIdx.x * Q.ld_part;
+        const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + HS * HS;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * rb + drow(v, kk);
+            wp[oW2 + r * HS + u] = aW2[v];
+            wp[oW3 + r * HS + u] = aW3[v];
+            if (BIG) wp[oW1 + r * ld1 + u] = aW1[v];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) red[rg][l][uu] = db[l];
+        if (!BIG) {
+#pragma unroll
+            for (int c = 0; c < DS_MAX; ++c) redw[rg][uu][c] = dw1[c];
+        }
+        __syncthreads();
+        if (t < 3 * HS) {
+            const int l = t >> 6, c = t & 63;
+            const float v = (red[0][l][c] + red[1][l][c]) + (red[2][l][c] + red[3][l][c]);
+            wp[l == 0 ? ob1 + c : (l == 1 ? ob2 + c : ob3 + c)] = v;
+            if (l == 0) {
+                db1s[c] = v;
+                Q.dctx_part[((long long)b * C.S + sp) * HS + c] = v;
+            }
+        }
+        if (!BIG && t < HS)
+            for (int c = 0; c < C.d_in; ++c) wp[oW1 + t * ld1 + c] = (redw[0][t][c] + redw[1][t][c]) + (redw[2][t][c] + redw[3][t][c]);
+        __syncthreads();                             // context columns of W1: (sum of d pre-activation 1) x pooled
+        for (int p = t; p < HS * HS; p += NT) {
+            const int r = p >> 6, k = p & 63;
+            wp[oW1 + r * ld1 + C.d_in + k] = db1s[r] * pooled[k];
+        }
+    }
+}
+
 // out[p] = sum over g of part[g][p], g in fixed order; entries p >= P_main were written by the first G_tail rows only
 __global__ void reduce_partials_kernel(const float *part, int G, int P, int P_main, int G_tail, float *out)
 {
@@ -556,6 +982,54 @@ int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, Q);
     else hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, Q);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+/* nddm_deepset_mlp_fwd for an equivariant MLP A (same first arguments; d_out 64, y required) FOLLOWED IN THE SAME LAUNCH by the
+ * MLP B that consumes A's output row by row (no context, input width 64; W1b, W2b, W3b [64, 64]): writes B's h1b, h2b [B * N, 64] and
+ * the masked sums of B's output pool_part_b [B, S, 64] -- what two calls (A with y, then B on y with pool_part) write, bit for bit.
+ * rows_per_wg must be 64 (one tile per workgroup). */
+int nddm_deepset_mlp2_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
+                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
+                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, float *h1, float *h2,
+                          float *y, const float *W1b, const float *b1b, const float *W2b, const float *b2b, const float *W3b, const float *b3b,
+                          float *h1b, float *h2b, float *pool_part_b, void *stream)
+{
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    if (!common_ok(C) || rows_per_wg != TM || d_out != HS || x_part || !h1 || !h2 || !y || !W1b || !b1b || !W2b || !b2b || !W3b || !b3b || !h1b || !h2b
+        || !pool_part_b)
+        return 1;
+    const FwdOut O = {h1, h2, y, nullptr}, O2 = {h1b, h2b, nullptr, pool_part_b};
+    const Mlp P2 = {W1b, HS, b1b, W2b, b2b, W3b, b3b};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d_in == HS) hipLaunchKernelGGL(mlp2_fwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, O, P2, O2);
+    else hipLaunchKernelGGL(mlp2_fwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, O, P2, O2);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+/* The backward of nddm_deepset_mlp2_fwd's pair, in the backward's order: first the pooling MLP X (input x1 [B * N, 64] = Y's output;
+ * weights W1x .. b3x, all [64, 64]; saved h1x, h2x; output gradient through its pooled mean: gpool / gp_S / gp_W / gp_ldw as in
+ * nddm_deepset_mlp_bwd; gx_prev [B * N, 64] or NULL is added to its input gradient), then the equivariant MLP Y (the first
+ * arguments, as nddm_deepset_mlp_bwd: its input x, context ctx_part, weights; saved h1y, h2y) whose output gradient IS that input
+ * gradient (it never leaves the chip).  Writes Y's gx [B * N, 64] (or NULL; must be NULL for a small input), dctx_part [B, S, 64] and
+ * both MLPs' weight-gradient partial sums (rows of ld_part floats, one per workgroup) -- what the two separate calls write, bit for
+ * bit.  rows_per_wg must be 64. */
+int nddm_deepset_mlp2_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
+                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
+                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, const float *h1y,
+                          const float *h2y, float *gx, float *dctx_part, float *wpart_y, const float *x1, const float *W1x, const float *b1x,
+                          const float *W2x, const float *b2x, const float *W3x, const float *b3x, const float *h1x, const float *h2x,
+                          const float *gpool, int gp_S, const float *gp_W, int gp_ldw, const float *gx_prev, float *wpart_x, int ld_part,
+                          void *stream)
+{
+    const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
+    if (!common_ok(C) || rows_per_wg != TM || d_out != HS || x_part || !ctx_part || !h1y || !h2y || !dctx_part || !wpart_y || !x1 || !W1x || !W2x || !W3x
+        || !h1x || !h2x || !gpool || !wpart_x || (gx && d_in != HS) || ld_part < HS * ldw1 + HS + 2 * (HS * HS + HS))
+        return 1;
+    const Bwd2 Q = {x1, {W1x, HS, b1x, W2x, b2x, W3x, b3x}, h1x, h2x, gpool, gp_S, gp_W, gp_ldw, gx_prev, wpart_x, h1y, h2y, gx, dctx_part, wpart_y, ld_part};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d_in == HS) hipLaunchKernelGGL(mlp2_bwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, Q);
+    else hipLaunchKernelGGL(mlp2_bwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, Q);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -38,6 +38,23 @@ def test_fast_kernels_fit_eight_waves_per_simd():
             assert rt.waves_by_sgpr(sims[name]["TotalSGPRs"]) == 8 and rt.waves_by_vgpr(sims[name]["VGPRs"]) >= 7, name
 
 
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc missing")
+def test_training_kernels_have_no_scratch_and_fit_their_lds():
+    """The amortizer's kernels (tools/resource_table.py --train): no private scratch, no spills, and the long chains' LDS
+    footprints leave room for exactly the residency their launch shapes assume (one workgroup per CU: <= 160 KB)."""
+    import resource_table as rt
+    rows = {rt.pretty(r["name"]): r for r in rt.collect(train=True)}
+    for k in ("flow_fwd_kernel", "flow_dgrad_kernel", "flow_wgrad_kernel", "mlp_fwd_kernel<true>", "mlp_fwd_kernel<false>",
+              "mlp_bwd_kernel<true>", "mlp_bwd_kernel<false>", "reduce_partials_kernel", "sqnorm_partial_kernel", "adam_kernel"):
+        assert k in rows, (k, sorted(rows))
+    for name, r in rows.items():
+        assert r.get("ScratchSize [bytes/lane]", 0) == 0, name
+        assert r.get("VGPRs Spill", 0) == 0, name               # (flow_fwd_kernel keeps 16 of its 106 SGPRs in VGPR lanes: v_writelane /
+        assert r.get("SGPRs Spill", 0) <= 16, name              #  v_readlane, not memory -- its struct of 96 weight pointers)
+        assert r.get("LDS Size [bytes/block]", 0) <= 160 * 1024, name
+        assert r["VGPRs"] <= 256, name                          # (wave64: 512 per SIMD lane; 256 keeps two waves per SIMD possible)
+
+
 @pytest.mark.skipif(not (HAVE_HIPCC and HAVE_OBJDUMP), reason="needs the ROCm toolchain (hipcc, llvm-objdump)")
 def test_issue_model_reads_the_shipped_library():
     """tools/isa_mix.py finds the step loop in the shipped library's code object: 65 VALU instructions per 4-step block

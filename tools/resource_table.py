@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Compiler resource table of every kernel in nddm_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage):
+"""Compiler resource table of every kernel in nddm_kernels.hip -- and, with --train, of the amortizer's kernels
+(train_kernels.hip, train_deepset.hip, train_update.hip) -- from hipcc -Rpass-analysis=kernel-resource-usage:
 VGPRs, SGPRs, scratch, LDS, and the waves/SIMD the register files allow on gfx950.
 
 The SGPR limit is the one measured with tools/ubench_residency.hip (profiles/r1_ubench_residency.txt): 800 SGPRs per
 SIMD, a wave is charged its SGPRs + 22 rounded up to 16 -- the occupancy the compiler prints does not know it.
 
-Usage: python tools/resource_table.py [--md]     (prints a table; --md = markdown)
+Usage: python tools/resource_table.py [--md] [--train]     (prints a table; --md = markdown; --train = the training kernels)
 """
 import os
 import re
@@ -24,10 +25,12 @@ def pretty(name):
         mod, fast, cap4, bridge, small, packed, vkeys, codes = (int(x) for x in m.groups())
         return (f"sim_kernel<{MODELS[mod]}, {'fast' if fast else 'exact'}, cap4={cap4}, bridge={bridge}, small={small}, "
                 f"packed={packed}, vkeys={vkeys}{', codes' if codes else ''}>")
-    m = re.match(r"_ZN4nddm(\d+)", name)
+    m = re.match(r"_ZN(?:4nddm|10nddm_train|12nddm_deepset|11nddm_update)(\d+)", name)
     if m:
         n = int(m.group(1))
-        return name[len(m.group(0)):len(m.group(0)) + n]
+        base, rest = name[len(m.group(0)):len(m.group(0)) + n], name[len(m.group(0)) + n:]
+        t = re.match(r"ILb(\d)E", rest)                       # (one boolean template argument: the DeepSet kernels' BIG)
+        return base + (f"<{'true' if t.group(1) == '1' else 'false'}>" if t else "")
     return name
 
 
@@ -40,15 +43,22 @@ def waves_by_vgpr(v):
     return min(8, 512 // (((v + 7) // 8) * 8))
 
 
-def collect():
+TRAIN_SRCS = [os.path.join(ROOT, "bayesflow_nddms_amd", "csrc", f) for f in ("train_kernels.hip", "train_deepset.hip", "train_update.hip")]
+
+
+def collect(train=False):
+    """One dict per kernel.  train=True: the amortizer's kernels (compiled as build.build_train does: -O3, contraction on)."""
+    text = ""
     with tempfile.TemporaryDirectory() as td:
         sys.path.insert(0, ROOT)
         from bayesflow_nddms_amd.build import _hipcc
-        r = subprocess.run([_hipcc(), "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-std=c++17", "-c",
-                            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "k.o"), SRC],
-                           capture_output=True, text=True, check=True)
+        for src in (TRAIN_SRCS if train else [SRC]):
+            flags = ["-O3", "--offload-arch=gfx950", "-std=c++17"] + ([] if train else ["-ffp-contract=off"])
+            r = subprocess.run([_hipcc()] + flags + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+                                os.path.join(td, "k.o"), src], capture_output=True, text=True, check=True)
+            text += r.stderr
     rows, cur = [], None
-    for line in r.stderr.splitlines():
+    for line in text.splitlines():
         m = re.search(r"remark: (?:\S+ )?\s*(Function Name|Name): (\S+)", line)
         if m:
             cur = {"name": m.group(2)}
@@ -62,7 +72,7 @@ def collect():
 
 def main():
     md = "--md" in sys.argv
-    rows = collect()
+    rows = collect(train="--train" in sys.argv)
     hdr = ["kernel", "VGPRs", "SGPRs", "scratch B/lane", "static LDS B", "waves/SIMD (VGPR)", "waves/SIMD (SGPR, measured rule)"]
     out = []
     for r in rows:
