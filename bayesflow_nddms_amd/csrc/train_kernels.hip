@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 // Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
 // are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of the original 33).
 constexpr int NTB = 1024;
-constexpr int LDW2 = H + 8;      // row stride of W2 in LDS: d(h1)'s B operand reads 4 rows x 16 columns per wave instruction
+constexpr int LDT = H + 4;       // row stride of W2 TRANSPOSED in LDS, w2t[in unit][out unit]: d(h1) = d(a2) W2 sums over the OUT units, and
+                                 // with the out units along a row both MFMA operands are read 16 bytes at a time (as in the forward:
+                                 // the order of the sum is free, lane group k takes the k's [32 k, 32 k + 32)) instead of a dword at a
+                                 // time down a column -- 16 LDS reads per lane instead of 64 in the longest phase of a half-layer
 
 struct HalfD {                   // one half-layer of kernel (1), resolved by the host
     const float *xtr, *W1, *W2, *W3, *s, *h1, *h2;       // xtr, s: [R, .] slices with row stride D (saved by the forward)
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     __shared__ __attribute__((aligned(16))) float h2r[TR][LDR];        // later: d(pre-activation 1)
     __shared__ __attribute__((aligned(16))) float da2r[TR][LDR];       // d(pre-activation 2); later: partial tiles of the input gradient
     __shared__ float do_s[TR][M_MAX];
-    __shared__ float w2s[H][LDW2];
+    __shared__ __attribute__((aligned(16))) float w2t[H][LDT];
     __shared__ float w1s[H][DI_MAX + 1];
     __shared__ float w3s[M_MAX][H];
     __shared__ float gout_s[TR][D_MAX], gz_s[TR][D_MAX], gy2_s[TR][D_MAX], gcond_s[TR][DI_MAX];
@@ -294,10 +297,13 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     if (U.g_nll && t < TR && r0 + t < Q.R) U.w_gld[r0 + t] = gld_sc;
     for (int p = t; p < TR * DI_MAX; p += NTB) (&gcond_s[0][0])[p] = 0.0f;
     // one thread's share of the next half-layer's operands
-    float nw2[H * H / NTB], nw1[H * DI_MAX / NTB], nw3[M_MAX * H / NTB], nh1[TR * H / NTB], nh2[TR * H / NTB], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
+    f32x4 nw2[H * H / 4 / NTB];       // thread (in unit j, g): out units 32 k4 + 4 g .. + 3, k4 = 0 .. 3, of column j
+    float nw1[H * DI_MAX / NTB], nw3[M_MAX * H / NTB], nh1[TR * H / NTB], nh2[TR * H / NTB], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
 #define NDDM_FETCH_HALF(X) do {                                                                                               \
         const int DIn_ = (X).Dh + Q.C, Mn_ = 2 * (X).Dt;                                                                       \
-        _Pragma("unroll") for (int k = 0; k < H * H / NTB; ++k) nw2[k] = (X).W2[t + NTB * k];                                  \
+        _Pragma("unroll") for (int k4 = 0; k4 < H * H / 4 / NTB; ++k4) {          /* (a wave: 64 consecutive floats of a row) */      \
+            const float *w_ = (X).W2 + (long long)(32 * k4 + 4 * g) * H + j;                                                    \
+            nw2[k4] = f32x4{w_[0], w_[H], w_[2 * H], w_[3 * H]}; }                                                              \
         _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NTB; ++k) nw1[k] = (X).W1[min(t + NTB * k, H * DIn_ - 1)];          \
         _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTB; ++k) nw3[k] = (X).W3[min(t + NTB * k, Mn_ * H - 1)];            \
         _Pragma("unroll") for (int k = 0; k < TR * H / NTB; ++k) {                                                             \
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         lds_barrier();                    // the previous half-layer's readers are done
         STAMP(10);
 #pragma unroll
-        for (int k = 0; k < H * H / NTB; ++k) w2s[g + 8 * k][j] = nw2[k];
+        for (int k4 = 0; k4 < H * H / 4 / NTB; ++k4) *reinterpret_cast<f32x4 *>(&w2t[j][32 * k4 + 4 * g]) = nw2[k4];
 #pragma unroll
         for (int k = 0; k < H * DI_MAX / NTB; ++k) {
             const int p = t + NTB * k, jj = p / DI;
@@ -365,12 +371,25 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         }
         lds_barrier();
         STAMP(12);
-        {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k = l >> 4] = da2[row][4 s + k], B[k][i = l & 15] = W2[4 s + k][i]
+        {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k] = da2[row][k], B[k][i = l & 15] = W2[k][i] = w2t[i][k] for the
+            // out units k = 32 (l >> 4) + s, s = 0 .. 31 (two accumulators: the even and the odd groups of four, a shorter dependent chain)
             const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float *ap = &da2r[16 * rb + n][kk], *bp = &w2s[kk][16 * ib + n];
-#pragma unroll 8
-            for (int s4 = 0; s4 < H; s4 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4], bp[s4 * LDW2], acc, 0, 0, 0);
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc;
+            const float4 *ap = reinterpret_cast<const float4 *>(&da2r[16 * rb + n][32 * kk]);
+            const float4 *bp = reinterpret_cast<const float4 *>(&w2t[16 * ib + n][32 * kk]);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; q4 += 2) {
+                const float4 a0 = ap[q4], b0 = bp[q4], a1 = ap[q4 + 1], b1 = bp[q4 + 1];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+            }
+            acc += acc1;
             // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register  (h2r: its readers finished before the barrier above)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
