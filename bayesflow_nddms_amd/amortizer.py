@@ -120,6 +120,16 @@ class InvariantNetwork(nn.Module):
         L = _train_lib.lib()
         return L if L is not None and L.nddm_deepset_supported(64, x.shape[2]) else None
 
+    def fused_params(self):
+        """The parameter tensors in the order the kernels (and their flat weight-gradient buffer) take them: per block the
+        invariant then the equivariant MLP, then the pre-pooling and the post-pooling MLP; W1, b1, W2, b2, W3, b3 of each."""
+        ps = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+        return ps + [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+
+    # a GraphTrainer may point this at the slice of ITS flat gradient buffer that holds fused_params() back to back: the backward's
+    # last kernel then writes the gradients where the optimizer reads them (no gather copy); None: a buffer of the call's own
+    grad_sink = None
+
     FUSED_MAX_ROWS = 1 << 19      # sets x trials (the training loop's 32 x 300 is 9600): 1.3 GB of saved activations at the cap
 
     def forward(self, x, mask=None, inv_n=None, n_valid=None):
@@ -131,19 +141,16 @@ class InvariantNetwork(nn.Module):
         if n_valid is not None and mask is None:
             n_valid = n_valid.reshape(-1).to(torch.float32)
             if L is not None:
-                params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
-                params += [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
-                return _FusedDeepSetFn.apply(L, len(self.equiv), x, n_valid, None, *params)
+                return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, n_valid, None, *self.fused_params())
             mask = (torch.arange(x.shape[1], device=x.device, dtype=torch.float32) < n_valid).to(torch.float32).view(1, -1, 1)
             inv_n = 1.0 / n_valid
         if L is not None:
-            params = [t for blk in self.equiv for mlp in (blk.inv, blk.eq) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
-            params += [t for mlp in (self.pre_pool, self.post_pool) for k in (0, 2, 4) for t in (mlp[k].weight, mlp[k].bias)]
+            params = self.fused_params()
             m = None if mask is None else mask.reshape(-1).to(torch.float32)
             inv = None if inv_n is None else (inv_n if torch.is_tensor(inv_n) else torch.full((1,), float(inv_n), device=x.device))
             if inv is not None:
                 inv = inv.reshape(-1).to(torch.float32)
-            return _FusedDeepSetFn.apply(L, len(self.equiv), x, m, inv, *params)
+            return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, m, inv, *params)
         for block in self.equiv:
             x = block(x, mask, inv_n)
         h = self.pre_pool(x)
@@ -170,7 +177,8 @@ class _FusedDeepSetFn(torch.autograd.Function):
                 prm[5].data_ptr(), prm[4].shape[0], None if x_part is None else x_part.data_ptr(), S_x)
 
     @staticmethod
-    def forward(ctx, L, nb, x, mask, inv_n, *params):
+    def forward(ctx, L_sink, nb, x, mask, inv_n, *params):
+        L, ctx.sink = L_sink
         (B, N, d0), dev, rpw = x.shape, x.device, _FusedDeepSetFn.ROWS_PER_WG
         T, S, Hd = B * N, -(-N // rpw), 64
         Sp = -(-B // rpw)                           # the post-pooling MLP runs on one row per set: B rows in all
@@ -225,7 +233,8 @@ class _FusedDeepSetFn(torch.autograd.Function):
         offs = [sum(per_mlp[:k]) for k in range(2 * nb + 2)]
         P = sum(per_mlp)
         part = torch.empty((G, P), dtype=torch.float32, device=dev)
-        flat = torch.empty(P, dtype=torch.float32, device=dev)
+        sink = ctx.sink
+        flat = sink if (sink is not None and sink.numel() == P and sink.device == dev) else torch.empty(P, dtype=torch.float32, device=dev)
         gxbuf = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
         dctx = torch.empty((max(nb, 1), B, S, Hd), dtype=torch.float32, device=dev)
         g_pooled = torch.empty((B, Hd), dtype=torch.float32, device=dev)
@@ -289,8 +298,9 @@ class _FusedFlowFn(torch.autograd.Function):
     params: per layer ActNorm log-scale and bias, then weight, bias x 3 of both sub-networks."""
 
     @staticmethod
-    def forward(ctx, L, clamp, d1, perms, nll, theta, cond, *params):
+    def forward(ctx, L_sink, clamp, d1, perms, nll, theta, cond, *params):
         import ctypes
+        L, ctx.sink = L_sink
         nl, (R, D), C = len(perms), theta.shape, cond.shape[1]
         Hd, dev = params[4].shape[0], theta.device
         theta, cond = theta.contiguous(), cond.contiguous()
@@ -298,16 +308,19 @@ class _FusedFlowFn(torch.autograd.Function):
         z_all, out_all, s_all = (saved[i * nl * R * D:(i + 1) * nl * R * D].view(nl, R, D) for i in range(3))
         h_all = saved[3 * nl * R * D:]
         ld = torch.empty(R + 1, dtype=torch.float32, device=dev)           # (+ the loss)
+        loss = ld[R:]
+        if nll and ctx.sink is not None and ctx.sink.get("loss") is not None and ctx.sink["loss"].device == dev:
+            loss = ctx.sink["loss"]                                        # the trainer's slot: no copy of the loss afterwards
         ptrs = (ctypes.c_void_p * (14 * nl))(*[p.data_ptr() for p in params])
         perm = (ctypes.c_int * (nl * D))(*[int(v) for p in perms for v in p])
         rc = L.nddm_train_flow_fwd(nl, R, D, d1, C, float(clamp), ptrs, perm, theta.data_ptr(), cond.data_ptr(), z_all.data_ptr(),
                                    out_all.data_ptr(), s_all.data_ptr(), h_all.data_ptr(), ld.data_ptr(),
-                                   ld[R:].data_ptr() if nll else None, torch.cuda.current_stream(dev).cuda_stream)
+                                   loss.data_ptr() if nll else None, torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"nddm_train_flow_fwd failed ({rc})")
         ctx.L, ctx.clamp, ctx.d1, ctx.perm, ctx.ptrs, ctx.nl, ctx.nll = L, float(clamp), d1, perm, ptrs, nl, bool(nll)
         ctx.save_for_backward(theta, cond, saved, *params)
-        return ld[R] if nll else (out_all[nl - 1], ld[:R])
+        return loss.view(()) if nll else (out_all[nl - 1], ld[:R])
 
     @staticmethod
     def backward(ctx, *gs):
@@ -319,11 +332,16 @@ class _FusedFlowFn(torch.autograd.Function):
         sizes = [p.numel() for p in params]
         Hd = params[4].shape[0]
         n_scratch = [nl * R * D, R * D, R * C, R, 2 * nl * R * (2 * Hd + 16)]
-        flat = torch.empty(sum(sizes) + sum(n_scratch), dtype=torch.float32, device=dev)
+        slots = None if ctx.sink is None else [ctx.sink["grads"].get(p.data_ptr()) for p in params]
+        in_place = slots is not None and all(s_ is not None and s_.shape == p.shape and s_.device == dev for s_, p in zip(slots, params))
+        flat = torch.empty((0 if in_place else sum(sizes)) + sum(n_scratch), dtype=torch.float32, device=dev)
         grads, o = [], 0
-        for p, n in zip(params, sizes):
-            grads.append(flat[o:o + n].view(p.shape))
-            o += n
+        for k, (p, n) in enumerate(zip(params, sizes)):      # the trainer's slots (its flat gradient buffer), or a buffer of this call's own
+            if in_place:
+                grads.append(slots[k])
+            else:
+                grads.append(flat[o:o + n].view(p.shape))
+                o += n
         scratch = []
         for n in n_scratch:
             scratch.append(flat[o:o + n])
@@ -419,6 +437,9 @@ class InvertibleNetwork(nn.Module):
     # (the fused kernels take 8 / 32 rows per workgroup, and one workgroup per half-layer sums the weight gradients over all rows:
     # made for the training loop's batches of 32 ... a few hundred rows)
     FUSED_MAX_ROWS = 4096
+    # a GraphTrainer may set {"grads": {parameter data_ptr: its slot in the trainer's flat gradient buffer}, "loss": the loss's slot}:
+    # the backward then writes every gradient (and the forward the loss) where the optimizer reads them -- no gather copies
+    grad_sink = None
 
     def _flow_params(self):
         params = []
@@ -431,7 +452,7 @@ class InvertibleNetwork(nn.Module):
         """mean(|z|^2 / 2 - log|det|): the maximum-likelihood loss of bf.amortizers.AmortizedPosterior."""
         L = self._fused_lib(theta, cond)
         if L is not None:
-            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, True, theta, cond, *self._flow_params())
+            return _FusedFlowFn.apply((L, self.grad_sink), self.layers[0].clamp, self.layers[0].d1, self._perm_host, True, theta, cond, *self._flow_params())
         z, log_det = self(theta, cond)
         return (0.5 * (z ** 2).sum(-1) - log_det).mean()
 
@@ -457,7 +478,7 @@ class InvertibleNetwork(nn.Module):
     def forward(self, theta, cond):
         L = self._fused_lib(theta, cond)
         if L is not None:
-            return _FusedFlowFn.apply(L, self.layers[0].clamp, self.layers[0].d1, self._perm_host, False, theta, cond, *self._flow_params())
+            return _FusedFlowFn.apply((L, self.grad_sink), self.layers[0].clamp, self.layers[0].d1, self._perm_host, False, theta, cond, *self._flow_params())
         z, scales = theta, []
         for i, layer in enumerate(self.layers):
             z = torch.addcmul(self.an_bias[i], z, torch.exp(self.an_scale[i]))

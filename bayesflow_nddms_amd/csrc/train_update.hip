@@ -98,6 +98,9 @@ __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, fl
     }
 }
 
+// dst[0] = a, dst[1] = b: the batch-shared number of trials and its logarithm (basic_ddm_dc.py:151-155) in ONE launch
+__global__ void set2_kernel(float *dst, float a, float b) { if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; } }
+
 }  // namespace nddm_update
 
 using namespace nddm_update;
@@ -121,5 +124,12 @@ extern "C" int nddm_train_adam_step(float *p, const float *g, float *m, float *v
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(NT), 0, st, reinterpret_cast<float4 *>(p), reinterpret_cast<const float4 *>(g),
                        reinterpret_cast<float4 *>(m), reinterpret_cast<float4 *>(v), n4, partial, H, step_i, step_f, lr_out, loss_buf, loss_cap,
                        loss_slot, reinterpret_cast<unsigned int *>(partial + NB));
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int nddm_train_set2(float *dst, float a, float b, void *stream)
+{
+    if (!dst) return 1;
+    hipLaunchKernelGGL(set2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst, a, b);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

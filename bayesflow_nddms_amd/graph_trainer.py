@@ -95,7 +95,15 @@ class GraphTrainer:
             # carries the loss through the all-reduce) and Adam's two moments: the optimizer step is then three launches of the
             # library's (csrc/train_update.hip) instead of ~20 of PyTorch's.  Every tensor starts on a 16-byte boundary (the
             # training kernels read weights with 16-byte loads): sizes are padded to multiples of four floats, the pads stay zero.
-            self.params = [p for p in self.amortizer.parameters() if p.requires_grad]
+            # order: the kernels' own (the flow's per-layer tensors, then the summary network's MLPs: amortizer.py), so that the
+            # backward kernels can write every gradient straight into its slot of the flat buffer (the sinks set below)
+            first = []
+            for net, getter in ((getattr(self.amortizer, "inference_net", None), "_flow_params"),
+                                (getattr(self.amortizer, "summary_net", None), "fused_params")):
+                if net is not None and hasattr(net, getter):
+                    first += [p for p in getattr(net, getter)() if p.requires_grad]
+            seen = {id(p) for p in first}
+            self.params = first + [p for p in self.amortizer.parameters() if p.requires_grad and id(p) not in seen]
             self._offs, o = [], 0
             for p in self.params:
                 self._offs.append(o)
@@ -112,6 +120,9 @@ class GraphTrainer:
                     p.grad = None
                     pad = -p.numel() % 4
                     self._pads.append(torch.zeros(pad, dtype=torch.float32, device=self.dev) if pad else None)
+            self._slots = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self._offs)]
+            self._loss_slot = self.flat[n_el:]
+            self._sinks = self._make_sinks()
             self.lr_t = torch.tensor(self.lr0, dtype=torch.float32, device=self.dev)
             self._one = torch.ones((), dtype=torch.float32, device=self.dev)
             from . import _train_lib
@@ -129,7 +140,8 @@ class GraphTrainer:
             self.offset = torch.tensor([self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
             self.step_i = torch.zeros(1, dtype=torch.int64, device=self.dev)
             self.step_f = torch.zeros(1, dtype=torch.float32, device=self.dev)
-            self.n_f = torch.full((1,), float(self.n_max), dtype=torch.float32, device=self.dev)
+            self._n2 = torch.tensor([float(self.n_max), math.log(float(self.n_max))], dtype=torch.float32, device=self.dev)
+            self.n_f, self.logn_f = self._n2[0:1], self._n2[1:2]       # the batch-shared N and log N (basic_ddm_dc.py:151-155): device scalars
             self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
             if self.optimizer is not None:
                 # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
@@ -201,20 +213,65 @@ class GraphTrainer:
 
     def _forward_backward(self, params, trials):
         """configurator (basic_ddm_dc.py:139-160) on device scalars + maximum-likelihood loss + backward into the flat buffer."""
+        for net, sink in self._sinks:
+            net.grad_sink = sink
+        try:
+            self._forward_backward_body(params, trials)
+        finally:
+            for net, _ in self._sinks:
+                net.grad_sink = None
+
+    def _forward_backward_body(self, params, trials):
         conf = {"summary_conditions": trials, "summary_n": self.n_f,
-                "direct_conditions": torch.log(self.n_f).view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
+                "direct_conditions": self.logn_f.view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
                 "parameters": params if self.P_net == self.P else params[:, :self.P_net]}
         loss = self.amortizer.compute_loss(conf)
         # gradients straight into the flat buffer with ONE concatenation (accumulating into pre-set .grad views costs one add
         # kernel per parameter tensor plus the zero fill; torch._foreach_copy_ runs as one copy per tensor here: ~90 launches)
         grads = torch.autograd.grad(loss, self.params, grad_outputs=self._one)      # (a constant seed: autograd's own ones_like is a fill launch)
-        pieces = []
-        for g, pad in zip(grads, self._pads):
-            pieces.append(g.reshape(-1))
-            if pad is not None:
-                pieces.append(pad)
-        torch.cat(pieces, out=self.flat[:self.n_el])
-        self.flat[self.n_el:].copy_(loss.detach().view(1))
+        placed = [g.data_ptr() == s_.data_ptr() for g, s_ in zip(grads, self._slots)]
+        if not any(placed):                                  # no sink took effect: ONE concatenation into the flat buffer
+            pieces = []
+            for g, pad in zip(grads, self._pads):
+                pieces.append(g.reshape(-1))
+                if pad is not None:
+                    pieces.append(pad)
+            torch.cat(pieces, out=self.flat[:self.n_el])
+        elif not all(placed):                                # some gradients are in their slots already (a concatenation would read
+            for g, s_, ok in zip(grads, self._slots, placed):     # and write the same memory): copy the others one by one
+                if not ok:
+                    s_.copy_(g)
+        if loss.data_ptr() != self._loss_slot.data_ptr():
+            self._loss_slot.copy_(loss.detach().view(1))
+
+    def _set_n(self, n):
+        """The batch's number of real trials and its logarithm into their device scalars (one launch; eager, on the current stream)."""
+        if self._lib is not None:
+            if self._lib.nddm_train_set2(self._n2.data_ptr(), float(n), math.log(float(n)), torch.cuda.current_stream(self.dev).cuda_stream) != 0:
+                raise RuntimeError("nddm_train_set2 failed")
+        else:
+            self.n_f.fill_(float(n)); self.logn_f.fill_(math.log(float(n)))
+
+    def _make_sinks(self):
+        """Where the networks' fused backward (and the flow's loss) may write straight into this trainer's flat gradient buffer
+        (amortizer.py: `grad_sink`): [(network, sink)].  Only where the layouts agree -- the summary network's tensors must lie back
+        to back -- otherwise the gather copy in _forward_backward serves.  The sinks are set for the duration of a
+        _forward_backward only: gradients that alias a buffer are this loop's business, not that of whoever else runs the networks."""
+        inf, summ = getattr(self.amortizer, "inference_net", None), getattr(self.amortizer, "summary_net", None)
+        slot = {id(p): (s_, o) for p, s_, o in zip(self.params, self._slots, self._offs)}
+        sinks = []
+        if inf is not None and hasattr(inf, "_flow_params") and hasattr(inf, "grad_sink"):
+            sinks.append((inf, {"grads": {p.data_ptr(): slot[id(p)][0] for p in inf._flow_params() if id(p) in slot}, "loss": self._loss_slot}))
+        if summ is not None and hasattr(summ, "fused_params") and hasattr(summ, "grad_sink"):
+            ps = summ.fused_params()
+            ok = bool(ps) and all(id(p) in slot for p in ps)
+            o0 = run = slot[id(ps[0])][1] if ok else 0
+            for p in ps if ok else []:
+                ok = ok and slot[id(p)][1] == run
+                run += p.numel()
+            if ok:
+                sinks.append((summ, self.flat[o0:run]))
+        return sinks
 
     def _update(self, scale):
         """cosine schedule, clip_grad_norm_(5.0) on the flat gradient, Adam, loss into the history buffer, counters."""
@@ -305,7 +362,7 @@ class GraphTrainer:
     # ------------------------------------------------------------------------------------------------ graphs
     def _mutable(self):
         # (the flat gradient buffer too: a stretch that starts with the update clips it in place)
-        ts = [self.flat_p, self.offset, self.step_i, self.step_f, self.lr_t, self.n_f, self.flat, self.loss_buf]
+        ts = [self.flat_p, self.offset, self.step_i, self.step_f, self.lr_t, self._n2, self.flat, self.loss_buf]
         if self.optimizer is None:
             return ts + [self.exp_avg, self.exp_avg_sq]
         for st in self.optimizer.state.values():
@@ -383,7 +440,7 @@ class GraphTrainer:
         gather = coll and not ddp
         self._keep_loss_ring()
         bk = self._bucket(self.bucket_top(n))
-        self.n_f.fill_(float(n))
+        self._set_n(n)
         sim = lambda: self._simulate(bk)
         if replay is None:
             fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
@@ -480,7 +537,7 @@ class GraphTrainer:
                 with torch.cuda.stream(T):
                     self._keep_loss_ring()
                     if replay is None:
-                        self.n_f.fill_(float(n))
+                        self._set_n(n)
                         b, pre = bk, ""
                         fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
                     else:
@@ -521,7 +578,7 @@ class GraphTrainer:
         if bt.r_params is None:
             bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
         bt.r_params.copy_(p_s); bt.r_trials.copy_(t_s)
-        self.n_f.fill_(float(n_s))
+        self._set_n(n_s)
         return bt
 
     def train_online(self, iterations):
