@@ -34,14 +34,14 @@ def lib():
     L.nddm_deepset_supported.argtypes = [i32, i32]
     L.nddm_deepset_supported.restype = i32
     common = [fp, i32, i32, i32, i32, i32, fp, i32, fp, f32, fp, i32, fp, i32, fp, fp, fp, fp, fp, i32, fp, i32]   # x .. S_x (csrc/train_deepset.hip)
-    L.nddm_deepset_mlp_fwd.argtypes = common + [fp, fp, fp, fp, vp]
+    L.nddm_deepset_mlp_fwd.argtypes = common + [fp, fp, fp, fp, i32, fp, i32, i32, vp]       # h1 h2 y pool_part | ldy extra n_extra extra_stride
     L.nddm_deepset_mlp_fwd.restype = i32
     L.nddm_deepset_mlp2_fwd.argtypes = common + [fp, fp, fp] + [fp] * 6 + [fp, fp, fp, vp]
     L.nddm_deepset_mlp2_fwd.restype = i32
     #                                        h1y h2y gx dctx wpart_y x1 | W1x..b3x | h1x h2x gpool gp_S gp_W gp_ldw gx_prev wpart_x ld_part stream
     L.nddm_deepset_mlp2_bwd.argtypes = common + [fp, fp, fp, fp, fp, fp] + [fp] * 6 + [fp, fp, fp, i32, fp, i32, fp, fp, i32, vp]
     L.nddm_deepset_mlp2_bwd.restype = i32
-    L.nddm_deepset_mlp_bwd.argtypes = common + [fp, fp, fp, fp, i32, fp, i32, fp, i32, fp, fp, i32, vp]
+    L.nddm_deepset_mlp_bwd.argtypes = common + [fp, fp, fp, i32, fp, i32, fp, i32, fp, i32, fp, fp, i32, vp]   # h1 h2 gy ldgy gpool ...
     L.nddm_deepset_mlp_bwd.restype = i32
     L.nddm_deepset_reduce.argtypes = [fp, i32, i32, i32, i32, fp, vp]
     L.nddm_deepset_reduce.restype = i32

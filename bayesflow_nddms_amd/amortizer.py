@@ -132,16 +132,22 @@ class InvariantNetwork(nn.Module):
 
     FUSED_MAX_ROWS = 1 << 19      # sets x trials (the training loop's 32 x 300 is 9600): 1.3 GB of saved activations at the cap
 
-    def forward(self, x, mask=None, inv_n=None, n_valid=None):
-        """mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors -- or
+    def forward(self, x, mask=None, inv_n=None, n_valid=None, direct=None):
+        """direct [B, k] (or broadcastable rows): "direct conditions" (log N, basic_ddm_dc.py:151-155) appended to the summary --
+        the result is then the flow's condition [B, summary_dim + k] (the kernels write both into one buffer: no concatenation,
+        and the backward takes the condition's gradient as it comes).
+        mask [1, N, 1] (1 = a real trial, 0 = padding) and inv_n = 1 / (number of real trials), both device tensors -- or
         n_valid, the number of real trials as a device scalar (the first n_valid trials are the real ones): the pooled means
         then run over the real trials only, so a batch padded to a fixed length (one hipGraph per length bucket,
         GraphTrainer) gives what the unpadded batch gives."""
         L = self._fused_lib(x)
+        if direct is not None and (L is None or direct.dim() != 2 or direct.shape[0] != x.shape[0] or direct.dtype != torch.float32
+                                   or self.summary_dim + direct.shape[1] > 64 or direct.requires_grad):
+            return torch.cat([self.forward(x, mask, inv_n, n_valid), direct.to(x.device, torch.float32)], dim=-1)
         if n_valid is not None and mask is None:
             n_valid = n_valid.reshape(-1).to(torch.float32)
             if L is not None:
-                return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, n_valid, None, *self.fused_params())
+                return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, n_valid, None, direct, *self.fused_params())
             mask = (torch.arange(x.shape[1], device=x.device, dtype=torch.float32) < n_valid).to(torch.float32).view(1, -1, 1)
             inv_n = 1.0 / n_valid
         if L is not None:
@@ -150,7 +156,7 @@ class InvariantNetwork(nn.Module):
             inv = None if inv_n is None else (inv_n if torch.is_tensor(inv_n) else torch.full((1,), float(inv_n), device=x.device))
             if inv is not None:
                 inv = inv.reshape(-1).to(torch.float32)
-            return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, m, inv, *params)
+            return _FusedDeepSetFn.apply((L, self.grad_sink), len(self.equiv), x, m, inv, direct, *params)
         for block in self.equiv:
             x = block(x, mask, inv_n)
         h = self.pre_pool(x)
@@ -177,7 +183,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
                 prm[5].data_ptr(), prm[4].shape[0], None if x_part is None else x_part.data_ptr(), S_x)
 
     @staticmethod
-    def forward(ctx, L_sink, nb, x, mask, inv_n, *params):
+    def forward(ctx, L_sink, nb, x, mask, inv_n, direct, *params):
         L, ctx.sink = L_sink
         (B, N, d0), dev, rpw = x.shape, x.device, _FusedDeepSetFn.ROWS_PER_WG
         T, S, Hd = B * N, -(-N // rpw), 64
@@ -189,7 +195,11 @@ class _FusedDeepSetFn(torch.autograd.Function):
         xs_next = torch.empty((max(nb, 1), T, Hd), dtype=torch.float32, device=dev)
         pools = torch.empty((nb + 1, B, S, Hd), dtype=torch.float32, device=dev)
         post = params[12 * nb + 6:]
-        summary = torch.empty((B, post[4].shape[0]), dtype=torch.float32, device=dev)
+        d_sum = post[4].shape[0]
+        n_extra = 0 if direct is None else direct.shape[1]
+        if direct is not None and n_extra > 1 and direct.stride(1) != 1:
+            direct = direct.contiguous()
+        summary = torch.empty((B, d_sum + n_extra), dtype=torch.float32, device=dev)      # (+ the direct conditions' columns)
         st = torch.cuda.current_stream(dev).cuda_stream
         cm = _FusedDeepSetFn._common
         count = mask is not None and mask.numel() == 1 and inv_n is None
@@ -198,7 +208,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
         cur, d, rc = x, d0, 0
         pooling = [params[12 * i:12 * i + 6] for i in range(nb)] + [params[12 * nb:12 * nb + 6]]     # inv_0 .. inv_{nb-1}, pre
         rc |= L.nddm_deepset_mlp_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, None, 0, pooling[0]), act(0, 0).data_ptr(),
-                                     act(0, 1).data_ptr(), None, pools[0].data_ptr(), st)
+                                     act(0, 1).data_ptr(), None, pools[0].data_ptr(), 0, None, 0, 0, st)
         for i in range(nb):
             eq, nxt = params[12 * i + 6:12 * i + 12], pooling[i + 1]
             rc |= L.nddm_deepset_mlp2_fwd(*cm(cur, d, B, N, S, rpw, mask, inv_n, pools[i], S, eq), act(2 * i + 1, 0).data_ptr(),
@@ -208,10 +218,11 @@ class _FusedDeepSetFn(torch.autograd.Function):
         # (1 / N as the host's value must be THIS launch's N, not the B rows the post-pooling MLP is launched over)
         cp = list(cm(None, Hd, 1, B, Sp, rpw, mask if count else None, inv_n, None, 0, post, pools[nb], S))
         cp[9] = 1.0 / N
-        rc |= L.nddm_deepset_mlp_fwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), summary.data_ptr(), None, st)
+        rc |= L.nddm_deepset_mlp_fwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), summary.data_ptr(), None, d_sum + n_extra,
+                                     None if direct is None else direct.data_ptr(), n_extra, 0 if direct is None else direct.stride(0), st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_fwd failed ({rc})")
-        ctx.L, ctx.nb, ctx.has_mask, ctx.has_inv = L, nb, mask is not None, inv_n is not None
+        ctx.L, ctx.nb, ctx.has_mask, ctx.has_inv, ctx.ld_out = L, nb, mask is not None, inv_n is not None, d_sum + n_extra
         ctx.save_for_backward(x, acts, xs_next, pools, *([mask] if mask is not None else []), *([inv_n] if inv_n is not None else []),
                               *params)
         return summary
@@ -250,12 +261,12 @@ class _FusedDeepSetFn(torch.autograd.Function):
         post = params[12 * nb + 6:]
         cp = list(cm(None, Hd, 1, B, Sp, rpw, mask if count else None, inv_n, None, 0, post, pools[nb], S))
         cp[9] = 1.0 / N
-        rc = L.nddm_deepset_mlp_bwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), g_summary.data_ptr(), None, 0, None, 0,
+        rc = L.nddm_deepset_mlp_bwd(*cp, act_post(0).data_ptr(), act_post(1).data_ptr(), g_summary.data_ptr(), ctx.ld_out, None, 0, None, 0,
                                     g_pooled.data_ptr(), 0, None, pp + offs[2 * nb + 1] * F, P, st)
         pre = params[12 * nb:12 * nb + 6]
         if nb == 0:
             rc |= L.nddm_deepset_mlp_bwd(*cm(x, d0, B, N, S, rpw, mask, inv_n, None, 0, pre), act(0, 0).data_ptr(), act(0, 1).data_ptr(),
-                                         None, g_pooled.data_ptr(), 0, None, 0, None, 0, None, pp + offs[0] * F, P, st)
+                                         None, 0, g_pooled.data_ptr(), 0, None, 0, None, 0, None, pp + offs[0] * F, P, st)
         # The backward of a pooling MLP X (pre-pooling, or a block's invariant half) and of the equivariant MLP Y that produced X's
         # input are ONE launch each (csrc/train_deepset.hip: mlp2_bwd_kernel): pre + eq_{nb-1}, then inv_i + eq_{i-1}, then inv_0
         # alone.  X's input gradient -- plus eq_i's, which the launch before left in gxbuf -- is Y's output gradient.
@@ -276,7 +287,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
         if nb:
             inv, eq = params[0:6], params[6:12]
             rc |= L.nddm_deepset_mlp_bwd(*cm(x, d0, B, N, S, rpw, mask, inv_n, None, 0, inv), act(0, 0).data_ptr(), act(0, 1).data_ptr(),
-                                         None, dctx[0].data_ptr(), S, eq[0].data_ptr() + d0 * F, d0 + Hd, None, 0, None, pp + offs[0] * F, P, st)
+                                         None, 0, dctx[0].data_ptr(), S, eq[0].data_ptr() + d0 * F, d0 + Hd, None, 0, None, pp + offs[0] * F, P, st)
         rc |= L.nddm_deepset_reduce(pp, G, P, offs[2 * nb + 1], Sp, flat.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"nddm_deepset_mlp_bwd failed ({rc})")
@@ -284,7 +295,7 @@ class _FusedDeepSetFn(torch.autograd.Function):
         for p, n in zip(params, sizes):
             grads.append(flat[o:o + n].view(p.shape))
             o += n
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class _FusedFlowFn(torch.autograd.Function):
@@ -511,12 +522,18 @@ class AmortizedPosterior(nn.Module):
         pad = input_dict.get("summary_mask", None)        # (mask, inv_n) of a batch padded to a bucket length (additive keys), or
         nv = input_dict.get("summary_n", None)            # the number of real trials, a device scalar
         x = self._t(input_dict["summary_conditions"])
+        direct = input_dict.get("direct_conditions", None)
+        direct = None if direct is None else self._t(direct)
+        if direct is not None and isinstance(self.summary_net, InvariantNetwork):
+            # (the summary network appends the direct conditions itself: with the kernels, without a concatenation)
+            if nv is not None:
+                return self.summary_net(x, n_valid=nv, direct=direct)
+            return self.summary_net(x, direct=direct) if pad is None else self.summary_net(x, pad[0], pad[1], direct=direct)
         if nv is not None:
             summ = self.summary_net(x, n_valid=nv)
         else:
             summ = self.summary_net(x) if pad is None else self.summary_net(x, pad[0], pad[1])
-        direct = input_dict.get("direct_conditions", None)
-        return summ if direct is None else torch.cat([summ, self._t(direct)], dim=-1)
+        return summ if direct is None else torch.cat([summ, direct], dim=-1)
 
     def forward(self, input_dict):
         return self.inference_net(self._t(input_dict["parameters"]), self._conditions(input_dict))

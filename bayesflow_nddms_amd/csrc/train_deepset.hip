@@ -158,8 +158,11 @@ __device__ __forceinline__ void context(const Common &C, int b, float *pooled, f
 // ------------------------------------------------------------------------------------------------ forward
 struct FwdOut {
     float *h1, *h2;        // [B * N, 64] the two hidden activations (after their ReLU): saved for the backward
-    float *y;              // [B * N, 64] the output, or null (only its pooled sums are wanted)
+    float *y;              // [B * N, ldy] the output (columns [0, d_out)), or null (only its pooled sums are wanted)
     float *pool_part;      // [B, S, 64] masked sums of the output over this workgroup's trials, or null
+    int ldy;               // row stride of y (>= d_out + n_extra)
+    const float *extra;    // not null: columns [d_out, d_out + n_extra) of y are filled from extra[row * extra_stride + .] -- the
+    int n_extra, extra_stride;   // "direct conditions" of the amortizer (log N) appended to the summary without a concatenation
 };
 
 template <bool BIG>        // d_in == 64 (layer 1 is an MFMA product) or d_in <= DS_MAX
@@ -260,8 +263,10 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 const int n = n0 + 32 * rb + drow(v, kk);
                 if (n < n_end && u < C.d_out) {
                     const float val = acc[v] + bias3;
-                    if (O.y) O.y[(row0 + n) * C.d_out + u] = val;
+                    if (O.y) O.y[(row0 + n) * O.ldy + u] = val;
                     if (O.pool_part) pacc = fmaf(mask_of(C, n), val, pacc);
+                } else if (O.extra && n < n_end && u < C.d_out + O.n_extra) {
+                    O.y[(row0 + n) * O.ldy + u] = O.extra[(row0 + n) * O.extra_stride + (u - C.d_out)];
                 }
             }
         }
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
 // ------------------------------------------------------------------------------------------------ backward
 struct BwdIO {
     const float *h1, *h2;            // saved by the forward
-    const float *gy;                 // [B * N, 64] gradient of the output, or null
+    const float *gy; int ldgy;       // [B * N, ldgy] gradient of the output (columns [0, d_out)), or null
     const float *gpool; int gp_S;    // gradient through the pooled output (null: none), one of two forms:
     const float *gp_W; int gp_ldw;   //   gp_W != null: gpool [B, gp_S, 64] = the consumer's per-workgroup sums of d(pre-activation 1),
                                      //     to be taken through the consumer's context columns gp_W [64, gp_ldw] and 1 / n;
@@ -484,9 +489,9 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 v1 = *reinterpret_cast<const float4 *>(Q.h1 + o);
                 v2 = *reinterpret_cast<const float4 *>(Q.h2 + o);
                 if (Q.gy) {
-                    if (C.d_out == HS) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
+                    if (C.d_out == HS && Q.ldgy == HS) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
                     else {
-                        const float *gr = Q.gy + (row0 + n) * C.d_out;
+                        const float *gr = Q.gy + (row0 + n) * Q.ldgy;
                         vg.x = 4 * c4 < C.d_out ? gr[4 * c4] : 0.0f;
                         vg.y = 4 * c4 + 1 < C.d_out ? gr[4 * c4 + 1] : 0.0f;
                         vg.z = 4 * c4 + 2 < C.d_out ? gr[4 * c4 + 2] : 0.0f;
@@ -950,15 +955,18 @@ static bool common_ok(const Common &C)
 /* One per-trial MLP forward.  x [B * N, d_in]; W1 [64, d_in (+ 64 with a context)], W2, W3 [64, 64]; mask [N] or NULL; inv_n: device
  * scalar or NULL (then inv_n_host); ctx_part [B, S_ctx, 64] or NULL.  Writes h1, h2 [B * N, 64], and y [B * N, 64] and / or
  * pool_part [B, S, 64] where not NULL.  S workgroups of up to rows_per_wg trials per set.  d_out: rows of W3 / b3 and width of y
- * (64 but for the last MLP of the network); x_part / S_x: see Common (NULL / 0: x is read). */
+ * (64 but for the last MLP of the network); x_part / S_x: see Common (NULL / 0: x is read).  ldy: row stride of y (0: d_out);
+ * extra / n_extra / extra_stride: columns [d_out, d_out + n_extra) of y are copied from extra[row * extra_stride + .] (NULL: none). */
 int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, float *h1, float *h2,
-                         float *y, float *pool_part, void *stream)
+                         float *y, float *pool_part, int ldy, const float *extra, int n_extra, int extra_stride, void *stream)
 {
     const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
-    if (!common_ok(C) || !h1 || !h2 || (pool_part && d_out != HS)) return 1;
-    const FwdOut O = {h1, h2, y, pool_part};
+    if (ldy <= 0) ldy = d_out;
+    if (!common_ok(C) || !h1 || !h2 || (pool_part && d_out != HS) || n_extra < 0 || (extra && (!y || d_out + n_extra > HS)) || ldy < d_out + (extra ? n_extra : 0))
+        return 1;
+    const FwdOut O = {h1, h2, y, pool_part, ldy, extra, extra ? n_extra : 0, extra_stride};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, O);
     else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, O);
@@ -966,19 +974,20 @@ int nddm_deepset_mlp_fwd(const float *x, int d_in, int B, int N, int S, int rows
 }
 
 /* The backward of nddm_deepset_mlp_fwd (same first arguments).  gy [B * N, 64] or NULL; gpool / gp_S / gp_W / gp_ldw: see BwdIO;
- * gx [B * N, d_in] or NULL (d_in == 64 only), gx_acc: accumulate; dctx_part [B, S, 64] or NULL; wpart: B * S rows, ld_part floats
+ * (ldgy: its row stride, 0: d_out); gx [B * N, d_in] or NULL (d_in == 64 only), gx_acc: accumulate; dctx_part [B, S, 64] or NULL; wpart: B * S rows, ld_part floats
  * apart, of 64 ldw1 + 64 + 2 (4096 + 64) weight-gradient partial sums each: reduce with nddm_deepset_reduce. */
 int nddm_deepset_mlp_bwd(const float *x, int d_in, int B, int N, int S, int rows_per_wg, const float *mask, int mask_is_count, const float *inv_n,
                          float inv_n_host, const float *ctx_part, int S_ctx, const float *W1, int ldw1, const float *b1, const float *W2,
                          const float *b2, const float *W3, const float *b3, int d_out, const float *x_part, int S_x, const float *h1,
-                         const float *h2, const float *gy, const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx,
+                         const float *h2, const float *gy, int ldgy, const float *gpool, int gp_S, const float *gp_W, int gp_ldw, float *gx,
                          int gx_acc, float *dctx_part, float *wpart, int ld_part, void *stream)
 {
+    if (ldgy <= 0) ldgy = d_out;
     const Common C = {x, d_in, B, N, S, rows_per_wg, mask, mask && mask_is_count, inv_n, inv_n_host, ctx_part, S_ctx, {W1, ldw1, b1, W2, b2, W3, b3}, d_out, x_part, S_x};
     if (!common_ok(C) || !h1 || !h2 || !wpart || ld_part < HS * ldw1 + HS + HS * HS + HS + d_out * HS + d_out || (gx && d_in != HS)
-        || (!gy && !gpool) || (gpool && d_out != HS))
+        || (!gy && !gpool) || (gpool && d_out != HS) || ldgy < d_out)
         return 1;
-    const BwdIO Q = {h1, h2, gy, gpool, gp_S, gp_W, gp_ldw, gx, gx_acc, dctx_part, wpart, ld_part};
+    const BwdIO Q = {h1, h2, gy, ldgy, gpool, gp_S, gp_W, gp_ldw, gx, gx_acc, dctx_part, wpart, ld_part};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, Q);
     else hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(B * S), dim3(NT), 0, st, C, Q);
@@ -999,7 +1008,7 @@ int nddm_deepset_mlp2_fwd(const float *x, int d_in, int B, int N, int S, int row
     if (!common_ok(C) || rows_per_wg != TM || d_out != HS || x_part || !h1 || !h2 || !y || !W1b || !b1b || !W2b || !b2b || !W3b || !b3b || !h1b || !h2b
         || !pool_part_b)
         return 1;
-    const FwdOut O = {h1, h2, y, nullptr}, O2 = {h1b, h2b, nullptr, pool_part_b};
+    const FwdOut O = {h1, h2, y, nullptr, HS, nullptr, 0, 0}, O2 = {h1b, h2b, nullptr, pool_part_b, HS, nullptr, 0, 0};
     const Mlp P2 = {W1b, HS, b1b, W2b, b2b, W3b, b3b};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d_in == HS) hipLaunchKernelGGL(mlp2_fwd_kernel<true>, dim3(B * S), dim3(NT), 0, st, C, O, P2, O2);

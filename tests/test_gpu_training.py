@@ -386,6 +386,19 @@ def test_fused_deepset_equals_the_pytorch_path():
                 g = torch.autograd.grad((out * w).sum(), list(net.parameters()))
                 for a, b in zip([out.detach()] + list(g), res[fused]):
                     assert torch.equal(a, b) if fused else torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        # the direct conditions appended by the kernels (no concatenation; the backward reads the condition's gradient with its stride):
+        # a [B, 1] broadcast of one device scalar (what the graph trainer passes: log N) and a dense [B, 3]
+        for direct in (torch.tensor([5.25], device="cuda").view(1, 1).expand(B, 1), torch.randn(B, 3, device="cuda")):
+            wd = torch.randn(B, net.summary_dim + direct.shape[1], device="cuda")
+            got = {}
+            for fused in (True, False):
+                net.fused = fused
+                out = net(x, mask, inv_n, direct=direct)
+                assert out.shape == (B, net.summary_dim + direct.shape[1]) and torch.equal(out[:, net.summary_dim:], direct)
+                got[fused] = [out.detach()] + [t.detach() for t in torch.autograd.grad((out * wd).sum(), list(net.parameters()))]
+            for k, (a, b) in enumerate(zip(got[True], got[False])):
+                mag = float(b.abs().max()) + 1e-6
+                assert float((a - b).abs().max()) <= 1e-4 * mag + 1e-6, ("direct", blocks, B, N, k, float((a - b).abs().max()), mag)
         if n_real is not None and n_real < N:                # padding is invisible: the unpadded batch gives the same summary
             net.fused = True
             assert torch.allclose(net(x[:, :n_real].contiguous()), res[True][0], rtol=1e-4, atol=1e-5)
