@@ -48,6 +48,8 @@ def lib():
     i64 = c.c_longlong
     L.nddm_train_adam_step.argtypes = [fp, fp, fp, fp, i64, fp, f32, f32, f32, f32, f32, f32, f32, fp, fp, fp, fp, i32, fp, vp]
     L.nddm_train_adam_step.restype = i32
+    L.nddm_train_stage.argtypes = [fp, fp, i64, fp, fp, i64, fp, f32, f32, vp]
+    L.nddm_train_stage.restype = i32
     L.nddm_train_set2.argtypes = [fp, f32, f32, vp]
     L.nddm_train_set2.restype = i32
     _lib = L

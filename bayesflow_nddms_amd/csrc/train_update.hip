@@ -101,6 +101,17 @@ __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, fl
 // dst[0] = a, dst[1] = b: the batch-shared number of trials and its logarithm (basic_ddm_dc.py:151-155) in ONE launch
 __global__ void set2_kernel(float *dst, float a, float b) { if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; } }
 
+// The head of a pipelined training iteration in ONE launch: the produced batch (parameter rows, trials) into the tensors the
+// training graph reads, and the batch's N and log N into their device scalars.  n_a, n_b: counts of float4.
+__global__ __launch_bounds__(256) void stage_kernel(float4 *dst_a, const float4 *src_a, long long n_a, float4 *dst_b, const float4 *src_b,
+                                                    long long n_b, float *n2, float nv, float lognv)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_b) dst_b[i] = src_b[i];
+    if (i < n_a) dst_a[i] = src_a[i];
+    if (i == 0 && n2) { n2[0] = nv; n2[1] = lognv; }
+}
+
 }  // namespace nddm_update
 
 using namespace nddm_update;
@@ -131,5 +142,20 @@ extern "C" int nddm_train_set2(float *dst, float a, float b, void *stream)
 {
     if (!dst) return 1;
     hipLaunchKernelGGL(set2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst, a, b);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+/* dst_a[0 .. n_a) = src_a, dst_b[0 .. n_b) = src_b (floats; counts multiples of 4, pointers 16-byte aligned), n2[0] = nv, n2[1] = lognv
+ * (n2 NULL: not written): one launch. */
+extern "C" int nddm_train_stage(float *dst_a, const float *src_a, long long n_a, float *dst_b, const float *src_b, long long n_b, float *n2,
+                                float nv, float lognv, void *stream)
+{
+    if (n_a < 0 || n_b < 0 || (n_a & 3) || (n_b & 3) || (n_a && (!dst_a || !src_a)) || (n_b && (!dst_b || !src_b))) return 1;
+    if ((reinterpret_cast<uintptr_t>(dst_a) | reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(dst_b) | reinterpret_cast<uintptr_t>(src_b)) & 15)
+        return 1;
+    const long long n = (n_a > n_b ? n_a : n_b) / 4;
+    hipLaunchKernelGGL(stage_kernel, dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<float4 *>(dst_a), reinterpret_cast<const float4 *>(src_a), n_a / 4, reinterpret_cast<float4 *>(dst_b),
+                       reinterpret_cast<const float4 *>(src_b), n_b / 4, n2, nv, lognv);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

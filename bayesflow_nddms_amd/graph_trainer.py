@@ -314,16 +314,28 @@ class GraphTrainer:
         else:
             dist.all_gather(list(bk.g_shard.unbind(0)), bk.shard)
 
-    def _stage(self, bk):
+    def _stage(self, bk, n_real=None):
         """The produced batch -- this rank's shard, or the gathered minibatch (rank-major strided views of the packed buffer)
-        -- into the contiguous tensors the training graph reads."""
+        -- into the contiguous tensors the training graph reads; with n_real also the batch's N and log N into their device
+        scalars (one launch for all of it where the sources are contiguous)."""
         if bk.staged:
             P, n = self.P, bk.n_top
+            src_p, src_t = (bk.g_params, bk.g_trials) if bk.g_shard is not None else (bk.params, bk.trials)
+            if (self._lib is not None and src_p.is_contiguous() and src_t.is_contiguous() and src_p.numel() % 4 == 0 and src_t.numel() % 4 == 0
+                    and not (src_p.data_ptr() | src_t.data_ptr() | bk.t_params.data_ptr() | bk.t_trials.data_ptr()) & 15):
+                if self._lib.nddm_train_stage(bk.t_params.data_ptr(), src_p.data_ptr(), src_p.numel(), bk.t_trials.data_ptr(), src_t.data_ptr(),
+                                              src_t.numel(), self._n2.data_ptr() if n_real is not None else None,
+                                              float(n_real or 1), math.log(float(n_real or 1)),
+                                              torch.cuda.current_stream(self.dev).cuda_stream) != 0:
+                    raise RuntimeError("nddm_train_stage failed")
+                return
             if bk.g_shard is not None:
                 bk.t_params.view(self.world, self.B, P).copy_(bk.g_params)
                 bk.t_trials.view(self.world, self.B, n, 2).copy_(bk.g_trials)
             else:
                 bk.t_params.copy_(bk.params); bk.t_trials.copy_(bk.trials)
+        if n_real is not None:
+            self._set_n(n_real)
 
     def _all_reduce_gradients(self):
         import torch.distributed as dist
@@ -524,7 +536,7 @@ class GraphTrainer:
                     T.wait_event(ev)
                     if stamps is not None:
                         stamps[-1][1].record(T)
-                    self._stage(bk)
+                    self._stage(bk, None if replay is not None else n)      # (+ N and log N of the batch; a replayed batch sets its own)
                     if replay is not None:
                         entry = (bk.t_params.clone(), bk.t_trials.clone(), n)
                     taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
@@ -537,7 +549,6 @@ class GraphTrainer:
                 with torch.cuda.stream(T):
                     self._keep_loss_ring()
                     if replay is None:
-                        self._set_n(n)
                         b, pre = bk, ""
                         fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
                     else:
