@@ -49,12 +49,11 @@ from .distributed import shared_prior_N
 _PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5, 5), "single": (engine.SINGLE_TRIAL, 8, 7)}
 
 
-# Cross-stream dependencies of the pipelined loop are TIMING events: such an event is a barrier packet with a completion signal of
-# its own at the point of the record.  A torch.cuda.Event() (hipEventDisableTiming) refers to the stream's last command instead, and
-# a waiter on another hardware queue then waits for whatever later packet of that queue next carries a signal -- the simulate graph
-# of batch i + 1, which only waits for batch i's staging copies, was seen starting 300-400 us into the training graph of batch i
-# (profiles/r4_train_timeline.md).
-_TIMED_EVENTS = True
+# Cross-stream dependencies of the pipelined loop: plain events.  (Timing events -- a barrier packet with a completion signal of its
+# own at the point of the record -- were tried when the simulate graph of batch i + 1 was seen starting 300-400 us into the training
+# graph of batch i: no difference, A/B on one box.  What decided that start was the ORDER in which the host enqueues the two
+# graphs: see _train_overlapped.)
+_TIMED_EVENTS = False
 
 
 class _Bucket:

@@ -604,7 +604,9 @@ def simulate_bench(a, ctx):
                                    "normals_per_s_fast_math": y["fast_math"]["rocrand_normal4_normals_per_s"],
                                    "normals_with_an_em_step_per_s_fast_math": y["fast_math"]["rocrand_normal4_plus_step_normals_per_s"],
                                    "raw_u32_per_s": y["rocrand4_u32_per_s"], "source": y["source"],
-                                   "this_kernel_over_vendor_with_step": achieved_steps / y["fast_math"]["rocrand_normal4_plus_step_normals_per_s"]}
+                                   # (one Gaussian per plain Euler-Maruyama step: comparable; a bridged step also draws crossing uniforms)
+                                   "this_kernel_over_vendor_with_step": None if bridge else
+                                   achieved_steps / y["fast_math"]["rocrand_normal4_plus_step_normals_per_s"]}
         except (OSError, KeyError, ValueError):
             pass
         res["roofline_valu"] = rv
