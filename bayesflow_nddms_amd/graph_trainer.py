@@ -313,27 +313,32 @@ class GraphTrainer:
         else:
             dist.all_gather(list(bk.g_shard.unbind(0)), bk.shard)
 
+    def _copy2(self, dst_p, src_p, dst_t, src_t, n_real=None):
+        """dst_p <- src_p, dst_t <- src_t and (n_real given) the N / log N scalars: ONE launch where the library's staging kernel
+        applies (contiguous, 16-byte aligned, multiples of four floats), else PyTorch copies."""
+        if (self._lib is not None and src_p.is_contiguous() and src_t.is_contiguous() and dst_p.is_contiguous() and dst_t.is_contiguous()
+                and src_p.numel() % 4 == 0 and src_t.numel() % 4 == 0
+                and not (src_p.data_ptr() | src_t.data_ptr() | dst_p.data_ptr() | dst_t.data_ptr()) & 15):
+            if self._lib.nddm_train_stage(dst_p.data_ptr(), src_p.data_ptr(), src_p.numel(), dst_t.data_ptr(), src_t.data_ptr(), src_t.numel(),
+                                          self._n2.data_ptr() if n_real is not None else None, float(n_real or 1),
+                                          math.log(float(n_real or 1)), torch.cuda.current_stream(self.dev).cuda_stream) != 0:
+                raise RuntimeError("nddm_train_stage failed")
+            return
+        dst_p.view(src_p.shape).copy_(src_p); dst_t.view(src_t.shape).copy_(src_t)
+        if n_real is not None:
+            self._set_n(n_real)
+
+    def _produced(self, bk):
+        """What the producer of a batch leaves: this rank's shard, or the gathered minibatch (rank-major views of the packed buffer)."""
+        return (bk.g_params, bk.g_trials) if bk.g_shard is not None else (bk.params, bk.trials)
+
     def _stage(self, bk, n_real=None):
         """The produced batch -- this rank's shard, or the gathered minibatch (rank-major strided views of the packed buffer)
         -- into the contiguous tensors the training graph reads; with n_real also the batch's N and log N into their device
         scalars (one launch for all of it where the sources are contiguous)."""
         if bk.staged:
-            P, n = self.P, bk.n_top
-            src_p, src_t = (bk.g_params, bk.g_trials) if bk.g_shard is not None else (bk.params, bk.trials)
-            if (self._lib is not None and src_p.is_contiguous() and src_t.is_contiguous() and src_p.numel() % 4 == 0 and src_t.numel() % 4 == 0
-                    and not (src_p.data_ptr() | src_t.data_ptr() | bk.t_params.data_ptr() | bk.t_trials.data_ptr()) & 15):
-                if self._lib.nddm_train_stage(bk.t_params.data_ptr(), src_p.data_ptr(), src_p.numel(), bk.t_trials.data_ptr(), src_t.data_ptr(),
-                                              src_t.numel(), self._n2.data_ptr() if n_real is not None else None,
-                                              float(n_real or 1), math.log(float(n_real or 1)),
-                                              torch.cuda.current_stream(self.dev).cuda_stream) != 0:
-                    raise RuntimeError("nddm_train_stage failed")
-                return
-            if bk.g_shard is not None:
-                bk.t_params.view(self.world, self.B, P).copy_(bk.g_params)
-                bk.t_trials.view(self.world, self.B, n, 2).copy_(bk.g_trials)
-            else:
-                bk.t_params.copy_(bk.params); bk.t_trials.copy_(bk.trials)
-        if n_real is not None:
+            self._copy2(bk.t_params, self._produced(bk)[0], bk.t_trials, self._produced(bk)[1], n_real)
+        elif n_real is not None:
             self._set_n(n_real)
 
     def _all_reduce_gradients(self):
@@ -535,9 +540,12 @@ class GraphTrainer:
                     T.wait_event(ev)
                     if stamps is not None:
                         stamps[-1][1].record(T)
-                    self._stage(bk, None if replay is not None else n)      # (+ N and log N of the batch; a replayed batch sets its own)
-                    if replay is not None:
-                        entry = (bk.t_params.clone(), bk.t_trials.clone(), n)
+                    if replay is None:
+                        self._stage(bk, n)                              # (+ N and log N of the batch)
+                    else:                                               # the fresh batch goes straight into the buffer: one launch
+                        src_p, src_t = self._produced(bk)
+                        entry = (torch.empty_like(bk.t_params), torch.empty_like(bk.t_trials), n)
+                        self._copy2(entry[0], src_p, entry[1], src_t)
                     taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     taken.record(T)
                 if produce_first and k + 1 < len(ns):
@@ -587,8 +595,7 @@ class GraphTrainer:
         bt = self._bucket(self.bucket_top(n_s))
         if bt.r_params is None:
             bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
-        bt.r_params.copy_(p_s); bt.r_trials.copy_(t_s)
-        self._set_n(n_s)
+        self._copy2(bt.r_params, p_s, bt.r_trials, t_s, n_s)            # (+ ITS N and log N: one launch)
         return bt
 
     def train_online(self, iterations):
