@@ -58,7 +58,7 @@ _TIMED_EVENTS = False
 
 class _Bucket:
     __slots__ = ("n_top", "shard", "params", "trials", "g_shard", "g_params", "g_trials", "t_params", "t_trials", "staged",
-                 "r_params", "r_trials", "graphs")
+                 "r_params", "r_trials", "graphs", "n2", "free_ev")
 
 
 class GraphTrainer:
@@ -89,6 +89,7 @@ class GraphTrainer:
         self.overlap = bool(overlap) and self.use_graph
         self.iteration = 0
         self._loss_host = []               # losses already read out of the device ring (_drain_losses)
+        self._uses = {}                    # pipelined loop, direct form: how often each bucket was produced into (-> its buffer set)
         with torch.cuda.device(self.dev):
             # ONE flat buffer each for the parameters (the modules' tensors become views of it), the gradients (+ 1 slot that
             # carries the loss through the all-reduce) and Adam's two moments: the optimizer step is then three launches of the
@@ -139,8 +140,6 @@ class GraphTrainer:
             self.offset = torch.tensor([self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
             self.step_i = torch.zeros(1, dtype=torch.int64, device=self.dev)
             self.step_f = torch.zeros(1, dtype=torch.float32, device=self.dev)
-            self._n2 = torch.tensor([float(self.n_max), math.log(float(self.n_max))], dtype=torch.float32, device=self.dev)
-            self.n_f, self.logn_f = self._n2[0:1], self._n2[1:2]       # the batch-shared N and log N (basic_ddm_dc.py:151-155): device scalars
             self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
             if self.optimizer is not None:
                 # Adam's state exists after a step: one with zero gradients changes no weight (update = lr * 0 / (0 + eps))
@@ -210,19 +209,20 @@ class GraphTrainer:
                         device=self.dev)
         self.offset += self.B * self.world
 
-    def _forward_backward(self, params, trials):
-        """configurator (basic_ddm_dc.py:139-160) on device scalars + maximum-likelihood loss + backward into the flat buffer."""
+    def _forward_backward(self, params, trials, n2):
+        """configurator (basic_ddm_dc.py:139-160) on device scalars (n2 = the batch-shared N and log N, :151-155) + maximum-likelihood
+        loss + backward into the flat buffer."""
         for net, sink in self._sinks:
             net.grad_sink = sink
         try:
-            self._forward_backward_body(params, trials)
+            self._forward_backward_body(params, trials, n2)
         finally:
             for net, _ in self._sinks:
                 net.grad_sink = None
 
-    def _forward_backward_body(self, params, trials):
-        conf = {"summary_conditions": trials, "summary_n": self.n_f,
-                "direct_conditions": self.logn_f.view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
+    def _forward_backward_body(self, params, trials, n2):
+        conf = {"summary_conditions": trials, "summary_n": n2[0:1],
+                "direct_conditions": n2[1:2].view(1, 1).expand(trials.shape[0], 1),     # log(N), :151-155
                 "parameters": params if self.P_net == self.P else params[:, :self.P_net]}
         loss = self.amortizer.compute_loss(conf)
         # gradients straight into the flat buffer with ONE concatenation (accumulating into pre-set .grad views costs one add
@@ -243,13 +243,14 @@ class GraphTrainer:
         if loss.data_ptr() != self._loss_slot.data_ptr():
             self._loss_slot.copy_(loss.detach().view(1))
 
-    def _set_n(self, n):
-        """The batch's number of real trials and its logarithm into their device scalars (one launch; eager, on the current stream)."""
+    def _set_n(self, bk, n):
+        """The batch's number of real trials and its logarithm into the bucket's device scalars -- every graph of a bucket reads its
+        bucket's pair -- in one launch (eager, on the current stream)."""
         if self._lib is not None:
-            if self._lib.nddm_train_set2(self._n2.data_ptr(), float(n), math.log(float(n)), torch.cuda.current_stream(self.dev).cuda_stream) != 0:
+            if self._lib.nddm_train_set2(bk.n2.data_ptr(), float(n), math.log(float(n)), torch.cuda.current_stream(self.dev).cuda_stream) != 0:
                 raise RuntimeError("nddm_train_set2 failed")
         else:
-            self.n_f.fill_(float(n)); self.logn_f.fill_(math.log(float(n)))
+            bk.n2[0:1].fill_(float(n)); bk.n2[1:2].fill_(math.log(float(n)))
 
     def _make_sinks(self):
         """Where the networks' fused backward (and the flow's loss) may write straight into this trainer's flat gradient buffer
@@ -313,20 +314,20 @@ class GraphTrainer:
         else:
             dist.all_gather(list(bk.g_shard.unbind(0)), bk.shard)
 
-    def _copy2(self, dst_p, src_p, dst_t, src_t, n_real=None):
+    def _copy2(self, dst_p, src_p, dst_t, src_t, n_real=None, bk=None):
         """dst_p <- src_p, dst_t <- src_t and (n_real given) the N / log N scalars: ONE launch where the library's staging kernel
         applies (contiguous, 16-byte aligned, multiples of four floats), else PyTorch copies."""
         if (self._lib is not None and src_p.is_contiguous() and src_t.is_contiguous() and dst_p.is_contiguous() and dst_t.is_contiguous()
                 and src_p.numel() % 4 == 0 and src_t.numel() % 4 == 0
                 and not (src_p.data_ptr() | src_t.data_ptr() | dst_p.data_ptr() | dst_t.data_ptr()) & 15):
             if self._lib.nddm_train_stage(dst_p.data_ptr(), src_p.data_ptr(), src_p.numel(), dst_t.data_ptr(), src_t.data_ptr(), src_t.numel(),
-                                          self._n2.data_ptr() if n_real is not None else None, float(n_real or 1),
+                                          bk.n2.data_ptr() if n_real is not None else None, float(n_real or 1),
                                           math.log(float(n_real or 1)), torch.cuda.current_stream(self.dev).cuda_stream) != 0:
                 raise RuntimeError("nddm_train_stage failed")
             return
         dst_p.view(src_p.shape).copy_(src_p); dst_t.view(src_t.shape).copy_(src_t)
         if n_real is not None:
-            self._set_n(n_real)
+            self._set_n(bk, n_real)
 
     def _produced(self, bk):
         """What the producer of a batch leaves: this rank's shard, or the gathered minibatch (rank-major views of the packed buffer)."""
@@ -337,9 +338,9 @@ class GraphTrainer:
         -- into the contiguous tensors the training graph reads; with n_real also the batch's N and log N into their device
         scalars (one launch for all of it where the sources are contiguous)."""
         if bk.staged:
-            self._copy2(bk.t_params, self._produced(bk)[0], bk.t_trials, self._produced(bk)[1], n_real)
+            self._copy2(bk.t_params, self._produced(bk)[0], bk.t_trials, self._produced(bk)[1], n_real, bk)
         elif n_real is not None:
-            self._set_n(n_real)
+            self._set_n(bk, n_real)
 
     def _all_reduce_gradients(self):
         import torch.distributed as dist
@@ -378,22 +379,25 @@ class GraphTrainer:
     # ------------------------------------------------------------------------------------------------ graphs
     def _mutable(self):
         # (the flat gradient buffer too: a stretch that starts with the update clips it in place)
-        ts = [self.flat_p, self.offset, self.step_i, self.step_f, self.lr_t, self._n2, self.flat, self.loss_buf]
+        ts = [self.flat_p, self.offset, self.step_i, self.step_f, self.lr_t, self.flat, self.loss_buf]
         if self.optimizer is None:
             return ts + [self.exp_avg, self.exp_avg_sq]
         for st in self.optimizer.state.values():
             ts += [st["step"], st["exp_avg"], st["exp_avg_sq"]]
         return ts
 
-    def _bucket(self, n_top):
+    def _bucket(self, n_top, parity=None):
         """The static tensors of one n_trials bucket: this rank's simulated shard, (world > 1, gather) the reassembled
         minibatch, and the training inputs `t_*` -- the shard, the gathered minibatch, or (experience replay) a staging
-        copy of a stored batch."""
-        bk = self._buckets.get(n_top)
+        copy of a stored batch.  parity 0 / 1: one of the TWO buffer sets of a bucket in the pipelined loop's direct form -- the
+        training graph reads what the simulate graph wrote, no staging copy; each set has graphs of its own."""
+        key = n_top if parity is None else (n_top, parity)
+        bk = self._buckets.get(key)
         if bk is not None:
             return bk
         bk = _Bucket()
         bk.n_top = n_top
+        bk.free_ev = None
         with torch.cuda.device(self.dev):
             # parameter rows and trials of this rank's shard live in ONE buffer (params padded to 16 bytes), so that the
             # exchange step is one collective
@@ -409,7 +413,8 @@ class GraphTrainer:
                 bk.g_trials = bk.g_shard[:, bp:].view(self.world, self.B, n_top, 2)
                 rows = self.world * self.B
             # staged: the producer (simulator, all-gather) refills its buffers while the training graph reads these
-            bk.staged = self.overlap or bk.g_shard is not None
+            bk.n2 = torch.tensor([float(n_top), math.log(float(n_top))], dtype=torch.float32, device=self.dev)   # N, log N of the batch in flight
+            bk.staged = (self.overlap and parity is None) or bk.g_shard is not None
             if bk.staged:
                 bk.t_params = torch.empty((rows, self.P), dtype=torch.float32, device=self.dev)
                 bk.t_trials = torch.empty((rows, n_top, 2), dtype=torch.float32, device=self.dev)
@@ -417,7 +422,7 @@ class GraphTrainer:
                 bk.t_params, bk.t_trials = bk.params, bk.trials
             bk.r_params = bk.r_trials = None          # staging of a replayed batch: allocated by the first replay iteration
             bk.graphs = {}
-        self._buckets[n_top] = bk
+        self._buckets[key] = bk
         return bk
 
     def _run(self, bk, key, fn, stream=None):
@@ -456,10 +461,10 @@ class GraphTrainer:
         gather = coll and not ddp
         self._keep_loss_ring()
         bk = self._bucket(self.bucket_top(n))
-        self._set_n(n)
+        self._set_n(bk, n)
         sim = lambda: self._simulate(bk)
         if replay is None:
-            fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
+            fb = lambda: self._forward_backward(bk.t_params, bk.t_trials, bk.n2)
             up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
             if not coll and not self.split:
                 self._run(bk, "sim+fb+up", lambda: (sim(), fb(), up()))
@@ -481,7 +486,7 @@ class GraphTrainer:
             self._on_comm_stream(lambda: self._gather(bk))
             self._stage(bk)
         bt = self._replay_stage((bk.t_params.clone(), bk.t_trials.clone(), n), replay)
-        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
+        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials, bt.n2)
         up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
         if coll and ddp:
             self._run(bt, "r:fb", fb)
@@ -515,9 +520,28 @@ class GraphTrainer:
         # HOST-blocking exchange (gloo) turns the order round: the host then waits in the collective while the device trains.
         produce_first = not (gather and self.backend != "nccl")
 
+        # The DIRECT form (online training without an all-gather): a bucket has TWO buffer sets (and graphs for each), used in
+        # turn, so the training graph of batch i reads exactly what the simulate graph of batch i wrote -- the producer of batch
+        # i + 1 writes the other set (or another bucket's) and also sets the batch's N / log N: nothing but the wait for the
+        # producer's event stands between two training graphs.  Otherwise (an all-gather's strided result, experience replay)
+        # the produced batch is staged into the training inputs by one launch on the training stream.
+        direct = replay is None and not gather
+
+        def bucket_of(n):
+            n_top = self.bucket_top(n)
+            if not direct:
+                return self._bucket(n_top)
+            use = self._uses.get(n_top, 0)
+            self._uses[n_top] = use + 1
+            return self._bucket(n_top, use & 1)
+
         def produce(n):
-            bk = self._bucket(self.bucket_top(n))
+            bk = bucket_of(n)
             with torch.cuda.stream(S):
+                if direct:
+                    if bk.free_ev is not None:
+                        S.wait_event(bk.free_ev)        # the training graph that read this buffer set last (two uses ago) is done
+                    self._set_n(bk, n)
                 self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
                 ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                 ev.record(S)
@@ -527,12 +551,12 @@ class GraphTrainer:
                     self._gather(bk)
                     ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     ev.record(C)
-            return ev
+            return ev, bk
 
         with torch.cuda.device(self.dev):
-            ev = produce(ns[0]) if ns else None
+            nxt = produce(ns[0]) if ns else None
             for k, n in enumerate(ns):
-                bk = self._bucket(self.bucket_top(n))
+                ev, bk = nxt
                 with torch.cuda.stream(T):
                     if stamps is not None:
                         stamps.append([torch.cuda.Event(enable_timing=True) for _ in range(4)])
@@ -540,28 +564,35 @@ class GraphTrainer:
                     T.wait_event(ev)
                     if stamps is not None:
                         stamps[-1][1].record(T)
-                    if replay is None:
-                        self._stage(bk, n)                              # (+ N and log N of the batch)
-                    else:                                               # the fresh batch goes straight into the buffer: one launch
-                        src_p, src_t = self._produced(bk)
-                        entry = (torch.empty_like(bk.t_params), torch.empty_like(bk.t_trials), n)
-                        self._copy2(entry[0], src_p, entry[1], src_t)
-                    taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
-                    taken.record(T)
+                    taken = None
+                    if not direct:
+                        if replay is None:
+                            self._stage(bk, n)                          # (+ N and log N of the batch)
+                        else:                                           # the fresh batch goes straight into the buffer: one launch
+                            src_p, src_t = self._produced(bk)
+                            entry = (torch.empty_like(bk.t_params), torch.empty_like(bk.t_trials), n)
+                            self._copy2(entry[0], src_p, entry[1], src_t)
+                        taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
+                        taken.record(T)
+
+                def produce_next():
+                    if taken is not None:
+                        S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers ...
+                        if gather:
+                            C.wait_event(taken)             # ... and its all-gather the reassembled minibatch
+                    return produce(ns[k + 1])
+
                 if produce_first and k + 1 < len(ns):
-                    S.wait_event(taken)
-                    if gather:
-                        C.wait_event(taken)
-                    ev = produce(ns[k + 1])
+                    nxt = produce_next()
                 with torch.cuda.stream(T):
                     self._keep_loss_ring()
                     if replay is None:
                         b, pre = bk, ""
-                        fb = lambda: self._forward_backward(bk.t_params, bk.t_trials)
+                        fb = lambda: self._forward_backward(bk.t_params, bk.t_trials, bk.n2)
                     else:
                         bt = self._replay_stage(entry, replay)
                         b, pre = bt, "r:"
-                        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials)
+                        fb = lambda: self._forward_backward(bt.r_params, bt.r_trials, bt.n2)
                     if two:
                         self._run(b, pre + "fb", fb)
                         if coll:
@@ -573,11 +604,11 @@ class GraphTrainer:
                         self._run(b, pre + "fb+up", lambda: (fb(), up()))
                         if stamps is not None:
                             stamps[-1][3].record(T)
+                    if direct:
+                        bk.free_ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
+                        bk.free_ev.record(T)
                 if not produce_first and k + 1 < len(ns):
-                    S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers ...
-                    if gather:
-                        C.wait_event(taken)             # ... and its all-gather the reassembled minibatch
-                    ev = produce(ns[k + 1])
+                    nxt = produce_next()
                 self.iteration += 1
         cur.wait_stream(T)
         cur.wait_stream(S)
@@ -595,7 +626,7 @@ class GraphTrainer:
         bt = self._bucket(self.bucket_top(n_s))
         if bt.r_params is None:
             bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
-        self._copy2(bt.r_params, p_s, bt.r_trials, t_s, n_s)            # (+ ITS N and log N: one launch)
+        self._copy2(bt.r_params, p_s, bt.r_trials, t_s, n_s, bt)        # (+ ITS N and log N: one launch)
         return bt
 
     def train_online(self, iterations):

@@ -86,8 +86,10 @@ def test_graph_trainer_equals_the_eager_iteration_and_tracks_the_classic_loop():
     h_ahead, n_ahead = run(use_graph=True)             # the default: simulate graph of batch i + 1 beside the training graph of i
     h_ahead3, n_ahead3 = run(use_graph=True, split=True)                  # pipelined: simulate (i + 1) || forward/backward | update (i)
     h_eager, _ = run(use_graph=False)
-    assert len(h_graph) == iters and n_graphs >= 5 and n_split == 2 * n_graphs == n_ahead      # several N buckets were hit
-    assert n_ahead3 == 3 * n_graphs
+    assert len(h_graph) == iters and n_graphs >= 5 and n_split == 2 * n_graphs                 # several N buckets were hit
+    # (the pipelined loop's direct form keeps TWO buffer sets per bucket, each with graphs of its own: a bucket that came up twice
+    #  has both captured)
+    assert 2 * n_graphs <= n_ahead <= 4 * n_graphs and n_ahead % 2 == 0 and 3 * n_graphs <= n_ahead3 <= 6 * n_graphs and n_ahead3 % 3 == 0
     assert np.allclose(h_graph, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h_graph) - np.array(h_eager)).max()
     assert np.allclose(h_split, h_eager, rtol=1e-4, atol=1e-4)
     assert np.allclose(h_ahead, h_eager, rtol=1e-4, atol=1e-4)
