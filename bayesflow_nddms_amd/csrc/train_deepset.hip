@@ -110,6 +110,27 @@ __device__ __forceinline__ void stage64(float (*dst)[LD], const float *src, int 
     }
 }
 
+// the same in two halves: the loads into registers now, the stores to LDS when the buffer's last readers are done / its first reader
+// is about to run -- a kernel that issues EVERY load up front and stores each operand just before the phase that needs it exposes
+// one load latency instead of one per operand
+__device__ __forceinline__ void fetch64(f32x4 (&v)[HS * HS / 4 / NT], const float *src, int ldw, int t, int rows = HS)
+{
+#pragma unroll
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        v[k] = *reinterpret_cast<const f32x4 *>(src + (long long)min(r, rows - 1) * ldw + 4 * c4);
+    }
+}
+__device__ __forceinline__ void store64(float (*dst)[LD], const f32x4 (&v)[HS * HS / 4 / NT], int t, int rows = HS)
+{
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
+        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+        *reinterpret_cast<f32x4 *>(&dst[r][4 * c4]) = r < rows ? v[k] : z;
+    }
+}
+
 // four columns of row `row` of the input of a 64-wide MLP: loaded, or (x_part) the mean of the pooled partial sums
 __device__ __forceinline__ float4 x_row4(const Common &C, long long row, int c4, float inv_n)
 {
@@ -198,11 +219,29 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             }
         }
     };
-    load_x_tile(n_begin);                            // (first: its latency runs beside the weights')
-    stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t, C.d_out);
-    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
-    else
+    // every global load first: W1 (needed first), W2, W3 into registers; W2 and W3 go to LDS behind layers 1 and 2 (the barriers
+    // that are there anyway), so their latency runs beside the input tile's, the context's and layer 1
+    // (the loads complete in issue order: the input tile and W1 first, they are stored first)
+    f32x4 r1[HS * HS / 4 / NT], r2[HS * HS / 4 / NT], r3[HS * HS / 4 / NT];
+    float4 rx[TM * HS / 4 / NT];
+    if (BIG) {
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            rx[k] = x_row4(C, row0 + min(n_begin + r, n_end - 1), c4, inv_n);       // (clamped: rows beyond the range are zeroed at the store)
+        }
+    } else load_x_tile(n_begin);
+    fetch64(r1, BIG ? C.P.W1 : C.P.W2, BIG ? C.P.ldw1 : HS, t);
+    fetch64(r2, C.P.W2, HS, t);
+    fetch64(r3, C.P.W3, HS, t, C.d_out);
+    if (BIG) {
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = n_begin + r < n_end ? rx[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        store64(w1s, r1, t);
+    } else
         for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
     context(C, b, pooled, cs, t);
     __syncthreads();
@@ -242,6 +281,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
             }
         }
+        if (n0 == n_begin) store64(w2s, r2, t);      // (its first reader is layer 2, behind the barrier)
         __syncthreads();
         STAMP(103);
         {                                            // layer 2
@@ -254,6 +294,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
             }
         }
+        if (n0 == n_begin) store64(w3s, r3, t, C.d_out);
         __syncthreads();
         STAMP(104);
         {                                            // layer 3 (no activation), and the masked sums of its output
@@ -289,24 +330,6 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
 // output are wanted).  B's rows are A's rows, so nothing crosses a workgroup between them: the y tile stays in LDS as B's input,
 // B's three weight matrices are fetched into registers while A computes and stored to LDS when A's readers are done -- one launch
 // and one exposed weight-staging latency instead of two of each.  One 64-row tile per workgroup (rows_per_wg == TM).
-__device__ __forceinline__ void fetch64(f32x4 (&v)[HS * HS / 4 / NT], const float *src, int ldw, int t, int rows = HS)
-{
-#pragma unroll
-    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
-        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
-        v[k] = *reinterpret_cast<const f32x4 *>(src + (long long)min(r, rows - 1) * ldw + 4 * c4);
-    }
-}
-__device__ __forceinline__ void store64(float (*dst)[LD], const f32x4 (&v)[HS * HS / 4 / NT], int t, int rows = HS)
-{
-    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < HS * HS / 4 / NT; ++k) {
-        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
-        *reinterpret_cast<f32x4 *>(&dst[r][4 * c4]) = r < rows ? v[k] : z;
-    }
-}
-
 template <bool BIG>        // of MLP A: d_in == 64 or d_in <= DS_MAX (B's input is A's 64-wide output)
 __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2, FwdOut O2)
 {
@@ -323,14 +346,15 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
     const int n0 = sp * C.rows_per_wg, n_end = min(C.N, n0 + C.rows_per_wg);
     const long long row0 = (long long)b * C.N;
     const float inv_n = inv_count(C);
-    // ---- A's input tile and weights -> LDS; B's weights -> registers
+    // ---- every global load up front, in the order of need: A's input tile and W1 (stored at once), A's W2 and W3 (stored behind
+    //      A's layers 1 and 2), B's three matrices (stored when A is done)
+    f32x4 r1[HS * HS / 4 / NT], r2[HS * HS / 4 / NT], r3[HS * HS / 4 / NT];
+    float4 rx[TM * HS / 4 / NT];
     if (BIG) {
 #pragma unroll
         for (int k = 0; k < TM * HS / 4 / NT; ++k) {
-            const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
-            float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (n < n_end) v = x_row4(C, row0 + n, c4, inv_n);
-            *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = v;
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            rx[k] = x_row4(C, row0 + min(n0 + r, n_end - 1), c4, inv_n);
         }
     } else {
         for (int p = t; p < TM * C.d_in; p += NT) {
@@ -338,15 +362,22 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
         }
     }
-    stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t);
-    if (BIG) stage64(w1s, C.P.W1, C.P.ldw1, t);
-    else
-        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
+    fetch64(r1, BIG ? C.P.W1 : C.P.W2, BIG ? C.P.ldw1 : HS, t);
+    fetch64(r2, C.P.W2, HS, t);
+    fetch64(r3, C.P.W3, HS, t);
     f32x4 q1[HS * HS / 4 / NT], q2[HS * HS / 4 / NT], q3[HS * HS / 4 / NT];
     fetch64(q1, P2.W1, HS, t);
     fetch64(q2, P2.W2, HS, t);
     fetch64(q3, P2.W3, HS, t);
+    if (BIG) {
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = n0 + r < n_end ? rx[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        store64(w1s, r1, t);
+    } else
+        for (int p = t; p < HS * C.d_in; p += NT) { const int r = p / C.d_in, c = p - r * C.d_in; w1small[r][c] = C.P.W1[(long long)r * C.P.ldw1 + c]; }
     context(C, b, pooled, cs, t);
     __syncthreads();
     const int u = 32 * ub + m;                       // this lane's column of every result tile
@@ -379,6 +410,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
         }
     }
+    store64(w2s, r2, t);
     __syncthreads();
     {
         const f32x16 acc = mma64<1, 1>(&h1s[32 * rb + m][32 * kk], &w2s[u][32 * kk], zero16());
@@ -390,6 +422,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
         }
     }
+    store64(w3s, r3, t);
     __syncthreads();
     {   // A's output: to global memory (the next equivariant MLP and the backward read it) and into xs as B's input
         const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
@@ -511,10 +544,16 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
             }
     };
-    load_tile(n_begin);                              // (first: its latency runs beside the weights')
-    stage64(w2s, C.P.W2, HS, t);
-    stage64(w3s, C.P.W3, HS, t, C.d_out);
-    if (BIG && Q.gx) stage64(w1s, C.P.W1, C.P.ldw1, t);
+    {   // every weight load in flight before the first store (three stage64 calls in a row waited for three load latencies in turn)
+        f32x4 r1[HS * HS / 4 / NT], r2[HS * HS / 4 / NT], r3[HS * HS / 4 / NT];
+        fetch64(r3, C.P.W3, HS, t, C.d_out);
+        fetch64(r2, C.P.W2, HS, t);
+        fetch64(r1, BIG ? C.P.W1 : C.P.W2, BIG ? C.P.ldw1 : HS, t);
+        load_tile(n_begin);
+        store64(w3s, r3, t, C.d_out);
+        store64(w2s, r2, t);
+        if (BIG && Q.gx) store64(w1s, r1, t);
+    }
     context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
     if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
         if (Q.gp_W) {
@@ -698,37 +737,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const long long row0 = (long long)b * C.N;
     const float inv_n = inv_count(C);
     const int u = 32 * ub + m, uu = t & 63, rg = t >> 6;
-    // ---- X's tile and weights -> LDS
+    // ---- every global load up front, in the order of need.  X: h2 and W3 (layer 3 runs first), then h1 and W2, then the input tile
+    //      and W1; they are stored to LDS just before the phase that reads them (behind the barriers that are there anyway), so
+    //      one load latency is exposed instead of one per operand.  Y's operands follow and stay in registers until X is done.
+    f32x4 xh2[TM * HS / 4 / NT], xw3[HS * HS / 4 / NT], xh1[TM * HS / 4 / NT], xw2[HS * HS / 4 / NT], xx[TM * HS / 4 / NT], xw1[HS * HS / 4 / NT];
+    auto fetch_tile = [&](f32x4 (&v)[TM * HS / 4 / NT], const float *src) {
 #pragma unroll
-    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
-        const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
-        float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vx = v1;
-        if (n < n_end) {
-            const long long o = (row0 + n) * HS + 4 * c4;
-            v1 = *reinterpret_cast<const float4 *>(Q.h1x + o);
-            v2 = *reinterpret_cast<const float4 *>(Q.h2x + o);
-            vx = *reinterpret_cast<const float4 *>(Q.x1 + o);
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            v[k] = *reinterpret_cast<const f32x4 *>(src + (row0 + min(n0 + r, n_end - 1)) * HS + 4 * c4);     // (clamped; zeroed at the store)
         }
-        *reinterpret_cast<float4 *>(&h1s[r][4 * c4]) = v1;
-        *reinterpret_cast<float4 *>(&h2s[r][4 * c4]) = v2;
-        *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = vx;
-        *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    stage64(w2s, Q.PX.W2, HS, t);
-    stage64(w3s, Q.PX.W3, HS, t);
-    stage64(w1s, Q.PX.W1, HS, t);
+    };
+    auto store_tile = [&](float (*dst)[LD], const f32x4 (&v)[TM * HS / 4 / NT]) {
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            *reinterpret_cast<f32x4 *>(&dst[r][4 * c4]) = n0 + r < n_end ? v[k] : z;
+        }
+    };
+    fetch_tile(xh2, Q.h2x);
+    fetch64(xw3, Q.PX.W3, HS, t);
+    fetch_tile(xh1, Q.h1x);
+    fetch64(xw2, Q.PX.W2, HS, t);
+    fetch_tile(xx, Q.x1);
+    fetch64(xw1, Q.PX.W1, HS, t);
     // ---- Y's operands -> registers (stored to LDS when X's readers are done)
     f32x4 q1[HS * HS / 4 / NT], q2[HS * HS / 4 / NT], q3[HS * HS / 4 / NT], th1[TM * HS / 4 / NT], th2[TM * HS / 4 / NT], tx[TM * HS / 4 / NT];
     fetch64(q2, C.P.W2, HS, t);
     fetch64(q3, C.P.W3, HS, t);
     fetch64(q1, BIG ? C.P.W1 : C.P.W2, BIG ? C.P.ldw1 : HS, t);          // (unconditional: a guarded fetch is a branch around every load)
+    fetch_tile(th1, Q.h1y);
+    fetch_tile(th2, Q.h2y);
+    if (BIG) fetch_tile(tx, C.x);
+    else {
 #pragma unroll
-    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
-        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
-        const long long o = (row0 + min(n0 + r, n_end - 1)) * HS + 4 * c4;          // (clamped: rows beyond the set are zeroed at the store)
-        th1[k] = *reinterpret_cast<const f32x4 *>(Q.h1y + o);
-        th2[k] = *reinterpret_cast<const f32x4 *>(Q.h2y + o);
-        tx[k] = BIG ? *reinterpret_cast<const f32x4 *>(C.x + o) : th1[k];
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) tx[k] = th1[k];
     }
     if (!BIG)
         for (int p = t; p < TM * C.d_in; p += NT) {
@@ -753,14 +797,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     } else if (t < HS) {
         gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
     }
+    store_tile(h2s, xh2);
+    store64(w3s, xw3, t);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TM * HS / 4 / NT; ++k) {     // the pooled output's gradient, spread over the set's real trials
+    for (int k = 0; k < TM * HS / 4 / NT; ++k) {     // the pooled output's gradient, spread over the set's real trials (rows beyond: zero)
         const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
-        if (n < n_end) {
-            const float mk = mask_of(C, n);
-            *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = make_float4(mk * gp[4 * c4], mk * gp[4 * c4 + 1], mk * gp[4 * c4 + 2], mk * gp[4 * c4 + 3]);
-        }
+        const float mk = n < n_end ? mask_of(C, n) : 0.0f;
+        *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = make_float4(mk * gp[4 * c4], mk * gp[4 * c4 + 1], mk * gp[4 * c4 + 2], mk * gp[4 * c4 + 3]);
     }
     __syncthreads();
     // ================================================================================ X
@@ -778,6 +822,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 d2s[r][u] = h2s[r][u] > 0.0f ? acc[v] : 0.0f;
             }
         }
+        store_tile(h1s, xh1);                        // (layer 2's operands: first read behind the barrier)
+        store64(w2s, xw2, t);
         __syncthreads();
         aW2 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &h1s[32 * kk][u], zero16());
 #pragma unroll 8
@@ -790,6 +836,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 gs[r][u] = h1s[r][u] > 0.0f ? acc[v] : 0.0f;
             }
         }
+        store_tile(xs, xx);                          // (layer 1's)
+        store64(w1s, xw1, t);
         __syncthreads();
 #pragma unroll 8
         for (int q = 0; q < 16; ++q) db[0] += gs[16 * rg + q][uu];
@@ -825,15 +873,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     store64(w2s, q2, t);
     store64(w3s, q3, t);
     if (BIG) store64(w1s, q1, t);
-#pragma unroll
-    for (int k = 0; k < TM * HS / 4 / NT; ++k) {
-        const int p = t + NT * k, r = p >> 4, c4 = p & 15;
-        const bool ok = n0 + r < n_end;
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        *reinterpret_cast<f32x4 *>(&h1s[r][4 * c4]) = ok ? th1[k] : z;
-        *reinterpret_cast<f32x4 *>(&h2s[r][4 * c4]) = ok ? th2[k] : z;
-        if (BIG) *reinterpret_cast<f32x4 *>(&xs[r][4 * c4]) = ok ? tx[k] : z;
-    }
+    store_tile(h1s, th1);
+    store_tile(h2s, th2);
+    if (BIG) store_tile(xs, tx);
     __syncthreads();                                 // (and the readers of red[] above are done before Y's epilogue writes it)
     {
         f32x16 aW1 = zero16(), aW2, aW3;
