@@ -520,12 +520,13 @@ class GraphTrainer:
         # HOST-blocking exchange (gloo) turns the order round: the host then waits in the collective while the device trains.
         produce_first = not (gather and self.backend != "nccl")
 
-        # The DIRECT form (online training without an all-gather): a bucket has TWO buffer sets (and graphs for each), used in
-        # turn, so the training graph of batch i reads exactly what the simulate graph of batch i wrote -- the producer of batch
-        # i + 1 writes the other set (or another bucket's) and also sets the batch's N / log N: nothing but the wait for the
-        # producer's event stands between two training graphs.  Otherwise (an all-gather's strided result, experience replay)
-        # the produced batch is staged into the training inputs by one launch on the training stream.
-        direct = replay is None and not gather
+        # The DIRECT form (online training): a bucket has TWO buffer sets (and graphs for each), used in turn, so that the
+        # PRODUCER of batch i + 1 fills the training graph's inputs while the training graph of batch i reads the other set (or
+        # another bucket's): the simulate graph writes them itself, or -- with an all-gather, whose result is rank-major and
+        # strided -- the communication stream stages them right behind the collective; the producer also sets the batch's N /
+        # log N.  Nothing but the wait for the producer's event stands between two training graphs.  Experience replay stages on
+        # the training stream (the fresh batch goes into the buffer, a drawn one into the graph's inputs).
+        direct = replay is None
 
         def bucket_of(n):
             n_top = self.bucket_top(n)
@@ -541,7 +542,8 @@ class GraphTrainer:
                 if direct:
                     if bk.free_ev is not None:
                         S.wait_event(bk.free_ev)        # the training graph that read this buffer set last (two uses ago) is done
-                    self._set_n(bk, n)
+                    if not gather:
+                        self._set_n(bk, n)
                 self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
                 ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                 ev.record(S)
@@ -549,6 +551,10 @@ class GraphTrainer:
                 C.wait_event(ev)
                 with torch.cuda.stream(C):
                     self._gather(bk)
+                    if direct:                          # ... and the gathered minibatch into the training graph's inputs
+                        if bk.free_ev is not None:
+                            C.wait_event(bk.free_ev)
+                        self._stage(bk, n)
                     ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     ev.record(C)
             return ev, bk
