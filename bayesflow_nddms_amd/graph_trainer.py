@@ -536,9 +536,13 @@ class GraphTrainer:
             self._uses[n_top] = use + 1
             return self._bucket(n_top, use & 1)
 
+        last_c = [None]                                 # the event behind the previous producer's work on the communication stream
+
         def produce(n):
             bk = bucket_of(n)
             with torch.cuda.stream(S):
+                if gather and last_c[0] is not None:
+                    S.wait_event(last_c[0])             # the previous all-gather has read the shard this simulate may overwrite
                 if direct:
                     if bk.free_ev is not None:
                         S.wait_event(bk.free_ev)        # the training graph that read this buffer set last (two uses ago) is done
@@ -557,12 +561,22 @@ class GraphTrainer:
                         self._stage(bk, n)
                     ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                     ev.record(C)
-            return ev, bk
+            entry = None
+            if replay is not None:                      # experience replay: the fresh batch is copied out for the buffer by its producer
+                with torch.cuda.stream(C if gather else S):
+                    src_p, src_t = self._produced(bk)
+                    entry = (torch.empty_like(bk.t_params), torch.empty_like(bk.t_trials), n)
+                    self._copy2(entry[0], src_p, entry[1], src_t)
+                    ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
+                    ev.record(C if gather else S)
+            if gather:
+                last_c[0] = ev
+            return ev, bk, entry
 
         with torch.cuda.device(self.dev):
             nxt = produce(ns[0]) if ns else None
             for k, n in enumerate(ns):
-                ev, bk = nxt
+                ev, bk, entry = nxt
                 with torch.cuda.stream(T):
                     if stamps is not None:
                         stamps.append([torch.cuda.Event(enable_timing=True) for _ in range(4)])
@@ -570,26 +584,10 @@ class GraphTrainer:
                     T.wait_event(ev)
                     if stamps is not None:
                         stamps[-1][1].record(T)
-                    taken = None
-                    if not direct:
-                        if replay is None:
-                            self._stage(bk, n)                          # (+ N and log N of the batch)
-                        else:                                           # the fresh batch goes straight into the buffer: one launch
-                            src_p, src_t = self._produced(bk)
-                            entry = (torch.empty_like(bk.t_params), torch.empty_like(bk.t_trials), n)
-                            self._copy2(entry[0], src_p, entry[1], src_t)
-                        taken = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
-                        taken.record(T)
-
-                def produce_next():
-                    if taken is not None:
-                        S.wait_event(taken)                 # the next batch may overwrite this bucket's buffers ...
-                        if gather:
-                            C.wait_event(taken)             # ... and its all-gather the reassembled minibatch
-                    return produce(ns[k + 1])
-
+                # (the producer's own buffers are read on the producer's streams only -- by the all-gather, the staging, the copy for
+                #  the replay buffer -- so the next producer, which follows on the same streams, needs no event from this one)
                 if produce_first and k + 1 < len(ns):
-                    nxt = produce_next()
+                    nxt = produce(ns[k + 1])
                 with torch.cuda.stream(T):
                     self._keep_loss_ring()
                     if replay is None:
@@ -614,7 +612,7 @@ class GraphTrainer:
                         bk.free_ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                         bk.free_ev.record(T)
                 if not produce_first and k + 1 < len(ns):
-                    nxt = produce_next()
+                    nxt = produce(ns[k + 1])
                 self.iteration += 1
         cur.wait_stream(T)
         cur.wait_stream(S)
@@ -633,6 +631,8 @@ class GraphTrainer:
         if bt.r_params is None:
             bt.r_params, bt.r_trials = torch.empty_like(p_s), torch.empty_like(t_s)
         self._copy2(bt.r_params, p_s, bt.r_trials, t_s, n_s, bt)        # (+ ITS N and log N: one launch)
+        cur = torch.cuda.current_stream(self.dev)                       # (stored batches are allocated on their producer's stream and read
+        p_s.record_stream(cur); t_s.record_stream(cur)                  #  here: the allocator must not hand them out again before this copy)
         return bt
 
     def train_online(self, iterations):
