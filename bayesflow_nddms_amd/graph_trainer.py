@@ -161,6 +161,10 @@ class GraphTrainer:
         self._comm = self._independent_stream([self._stream] + ([self._sim_stream] if self.overlap else [])) \
             if (self.overlap and self.world > 1) or self.split else torch.cuda.Stream(device=self.dev)
         self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
+        # every graph is CAPTURED on this stream and replayed on the stream of its stretch (training / simulate): the streams that
+        # carry collectives never capture, so the process group's watchdog never queries an event of a capturing stream -- and the
+        # gradient all-reduce of `ddp` can sit on the training stream itself, between its two graphs, without a cross-queue hop
+        self._cap = torch.cuda.Stream(device=self.dev) if self.use_graph else None
         # the library's memory behind THIS trainer's captured launches (include/nddm.h: nddm_graph_arena_*): close() frees
         # it and nothing else -- a second trainer, or a user's own captured graph, keeps replaying
         self._arena = engine.GraphArena() if self.use_graph else None
@@ -298,9 +302,10 @@ class GraphTrainer:
         self.step_f += 1.0
 
     def _on_comm_stream(self, fn):
-        """An exchange step between two graphs -- on a communication stream of its own, never on the stream that captures:
-        the process group's watchdog thread polls the events of its collectives (recorded on the stream they were issued
-        on), and HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent aborts the process)."""
+        """An exchange step on the communication stream (the sequential loop's all-gather).  Collectives never go to a stream
+        that captures: the process group's watchdog thread polls the events of its collectives (recorded on the stream they
+        were issued on), and HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent aborts the
+        process) -- which is why every graph is captured on a stream of its own (self._cap)."""
         self._comm.wait_stream(self._stream)
         with torch.cuda.stream(self._comm):
             fn()
@@ -432,7 +437,6 @@ class GraphTrainer:
         if not self.use_graph:
             fn()
             return
-        stream = stream or self._stream             # (the caller has made it the current stream)
         g = bk.graphs.get(key)
         if g is None:
             if self.overlap:
@@ -447,7 +451,7 @@ class GraphTrainer:
             g = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread polls its events while this thread captures, which the
             # default (global) capture mode turns into an error that kills the process
-            with self._arena.bound(), torch.cuda.graph(g, pool=self._pool, stream=stream, capture_error_mode="thread_local"):
+            with self._arena.bound(), torch.cuda.graph(g, pool=self._pool, stream=self._cap, capture_error_mode="thread_local"):
                 fn()
             bk.graphs[key] = g
         g.replay()
@@ -476,7 +480,7 @@ class GraphTrainer:
             else:                                   # ddp, or the two-graph form forced at one rank without a process group
                 self._run(bk, "sim+fb", lambda: (sim(), fb()))
                 if coll:
-                    self._on_comm_stream(self._all_reduce_gradients)
+                    self._all_reduce_gradients()                # (on the training stream itself: it never captures)
                 self._run(bk, "up", up)
             return
         # experience replay (basic_ddm_dc.py:199-202 calls trainer.train_experience_replay): the fresh batch goes into the
@@ -490,7 +494,7 @@ class GraphTrainer:
         up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
         if coll and ddp:
             self._run(bt, "r:fb", fb)
-            self._on_comm_stream(self._all_reduce_gradients)
+            self._all_reduce_gradients()                # (on the training stream itself: it never captures)
             self._run(bt, "up", up)
         else:
             self._run(bt, "r:fb+up", lambda: (fb(), up()))
@@ -600,7 +604,7 @@ class GraphTrainer:
                     if two:
                         self._run(b, pre + "fb", fb)
                         if coll:
-                            self._on_comm_stream(self._all_reduce_gradients)
+                            self._all_reduce_gradients()                # (on the training stream itself: it never captures)
                         self._run(b, "up", up)
                     else:
                         if stamps is not None:
