@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The reference's WHOLE training run of basic_ddm_dc.py:199-202 -- trainer.train_experience_replay(epochs=500, batch_size=32,
+iterations_per_epoch=1000): 500,000 iterations, 1.6e7 simulated data sets, 2.9e9 trials at dt=.01 / 400 (the job the reference gives a
+30-hour SLURM slot: bayesflow_nddms.sh:6) -- on one MI355X with graph_trainer.GraphTrainer, followed by the recovery loop of :218-250 in
+the reference's size (500 fresh data sets, posterior means against the true parameters; 2000 posterior draws each instead of 10000).
+Prints the time and loss per 50 epochs.   usage: python tools/full_training_run.py [epochs=500]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesflow_nddms_amd import basic_ddm_dc                                                                    # noqa: E402
+from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, posterior_recovery   # noqa: E402
+from bayesflow_nddms_amd.graph_trainer import GraphTrainer                                                      # noqa: E402
+
+
+def main():
+    epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    per_epoch, chunk = 1000, 50
+    torch.manual_seed(0)
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+    t0 = time.time()
+    with GraphTrainer(am, batch_size=32, total_steps=epochs * per_epoch, seed=2023) as gt:
+        for e0 in range(0, epochs, chunk):
+            n = min(chunk, epochs - e0) * per_epoch
+            gt.train_experience_replay(n)
+            torch.cuda.synchronize()
+            h = gt.loss_history()
+            print(f"epochs {e0 + 1:3d}-{e0 + n // per_epoch:3d}: {time.time() - t0:6.1f} s elapsed, {gt.iteration / (time.time() - t0):6.0f} it/s overall, "
+                  f"loss over the last 1000 iterations {np.mean(h[-1000:]):8.3f}, rate {float(gt.lr_t):.2e}", flush=True)
+        h = np.array(gt.loss_history())
+    total = time.time() - t0
+    print(f"{len(h)} iterations ({len(h) * 32:.3g} data sets) in {total:.1f} s = {len(h) / total:.0f} it/s; nan {int(np.isnan(h).sum())}; "
+          f"loss first 1000 {h[:1000].mean():.3f}, last 1000 {h[-1000:].mean():.3f}", flush=True)
+    np.random.seed(2023)
+    gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+    t1 = time.time()
+    rho = posterior_recovery(am, gm, basic_ddm_dc.configurator, n_datasets=500, n_samples=2000)
+    print(f"recovery over 500 fresh data sets ({time.time() - t1:.1f} s): posterior-mean vs truth correlation per parameter "
+          f"(drift, boundary, beta, tau, dc): {np.round(rho, 3)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
