@@ -60,8 +60,10 @@ KERNEL_NAME = {"basic": "nddm::sim_kernel<0 (basic_ddm_dc), %s>", "single": "ndd
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults: 6.6 s of GPU time at the headline shape -- 32 ms per step -- so that the timed region is long against launch
+    #  jitter and visible to a coarse utilisation sampler; the CPU-baseline legs beside it take ~55 s)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sets", type=int, default=1_000_000, help="parameter sets per GPU per step")
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--dt", type=float, default=0.001)

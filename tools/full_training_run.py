@@ -3,7 +3,8 @@
 iterations_per_epoch=1000): 500,000 iterations, 1.6e7 simulated data sets, 2.9e9 trials at dt=.01 / 400 (the job the reference gives a
 30-hour SLURM slot: bayesflow_nddms.sh:6) -- on one MI355X with graph_trainer.GraphTrainer, followed by the recovery loop of :218-250 in
 the reference's size (500 fresh data sets, posterior means against the true parameters; 2000 posterior draws each instead of 10000).
-Prints the time and loss per 50 epochs.   usage: python tools/full_training_run.py [epochs=500]"""
+Prints the time and loss per 50 epochs.  `single`: the same for single_trial_alpha_not_scaled.py:284-287 (7 parameters, data (choicert, z1)).
+usage: python tools/full_training_run.py [epochs=500] [basic|single]"""
 import os
 import sys
 import time
@@ -19,11 +20,12 @@ from bayesflow_nddms_amd.graph_trainer import GraphTrainer                      
 
 def main():
     epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    model = sys.argv[2] if len(sys.argv) > 2 else "basic"
     per_epoch, chunk = 1000, 50
     torch.manual_seed(0)
-    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5 if model == "basic" else 7), InvariantNetwork())
     t0 = time.time()
-    with GraphTrainer(am, batch_size=32, total_steps=epochs * per_epoch, seed=2023) as gt:
+    with GraphTrainer(am, model=model, batch_size=32, total_steps=epochs * per_epoch, seed=2023) as gt:
         for e0 in range(0, epochs, chunk):
             n = min(chunk, epochs - e0) * per_epoch
             gt.train_experience_replay(n)
@@ -36,11 +38,16 @@ def main():
     print(f"{len(h)} iterations ({len(h) * 32:.3g} data sets) in {total:.1f} s = {len(h) / total:.0f} it/s; nan {int(np.isnan(h).sum())}; "
           f"loss first 1000 {h[:1000].mean():.3f}, last 1000 {h[-1000:].mean():.3f}", flush=True)
     np.random.seed(2023)
-    gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+    if model == "basic":
+        mod, names = basic_ddm_dc, "drift, boundary, beta, tau, dc"
+    else:
+        from bayesflow_nddms_amd import single_trial_alpha_not_scaled as mod
+        names = "drift, mu_alpha, beta, ter, std_alpha, dc, sigma1"
+    gm = mod.make_generative_model(batched=True, device_prior=True, as_numpy=False)
     t1 = time.time()
-    rho = posterior_recovery(am, gm, basic_ddm_dc.configurator, n_datasets=500, n_samples=2000)
+    rho = posterior_recovery(am, gm, mod.configurator, n_datasets=500, n_samples=2000)
     print(f"recovery over 500 fresh data sets ({time.time() - t1:.1f} s): posterior-mean vs truth correlation per parameter "
-          f"(drift, boundary, beta, tau, dc): {np.round(rho, 3)}", flush=True)
+          f"({names}): {np.round(rho, 3)}", flush=True)
 
 
 if __name__ == "__main__":
