@@ -70,8 +70,47 @@ int main(int argc, char **argv)
 
     /* error convention: a bad shape is a status code + message, not a crash */
     int rc = nddm_basic_ddm_dc_simulate(d_p, B, 0, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)st);
+
+    /* ABI 3 from C: the same launch captured into a hipGraph under a GRAPH ARENA (the owner of the memory the library pins
+     * behind a captured launch), replayed into zeroed outputs, compared with the direct launch; then the graph is destroyed and
+     * the arena -- and only the arena -- released. */
+    uint64_t arena = 0, prev = 0, bytes = 0;
+    int32_t n_alloc = 0;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    NDDM_CHECK(nddm_graph_arena_create(&arena));
+    NDDM_CHECK(nddm_graph_arena_bind(arena, &prev));
+    HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    NDDM_CHECK(nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)st));
+    HIP_OK(hipStreamEndCapture(st, &graph));
+    NDDM_CHECK(nddm_graph_arena_bind(prev, NULL));
+    NDDM_CHECK(nddm_graph_arena_info(arena, &bytes, &n_alloc));
+    HIP_OK(hipGraphInstantiate(&exec, graph, NULL, NULL, 0));
+    int replay_equal = 1;
+    float *t2 = (float *)malloc(nt * sizeof(float));
+    for (int rep = 0; rep < 3; rep++) {
+        HIP_OK(hipMemsetAsync(d_t, 0, nt * sizeof(float), st));
+        HIP_OK(hipGraphLaunch(exec, st));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(t2, d_t, nt * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nt; i++) if (((uint32_t *)t2)[i] != ((uint32_t *)t)[i]) { replay_equal = 0; break; }
+    }
+    free(t2);
+    HIP_OK(hipGraphExecDestroy(exec));
+    HIP_OK(hipGraphDestroy(graph));
+    NDDM_CHECK(nddm_graph_arena_release(arena));
+    const int released_twice = nddm_graph_arena_release(arena);           /* NDDM_ERR_PARAM: the handle is gone */
+
+    /* a stream handle the runtime does not know is refused (HIP itself would dereference it) */
+    hipStream_t dead;
+    HIP_OK(hipStreamCreate(&dead));
+    HIP_OK(hipStreamDestroy(dead));
+    const int dead_stream_status = nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)dead);
+
     printf("{\"sets\": %lld, \"n_trials\": %d, \"seconds\": %.6f, \"trials_per_s\": %.4e, \"first_rt\": %.6f, \"first_choice\": %.0f, "
-           "\"bad_shape_status\": %d}\n", (long long)B, N, t1 - t0, (double)B * N / (t1 - t0), t[0], t[1], rc);
+           "\"bad_shape_status\": %d, \"graph_replay_equal\": %d, \"arena_bytes\": %llu, \"arena_allocations\": %d, "
+           "\"arena_released_twice_status\": %d, \"dead_stream_status\": %d}\n", (long long)B, N, t1 - t0, (double)B * N / (t1 - t0), t[0], t[1], rc,
+           replay_equal, (unsigned long long)bytes, (int)n_alloc, released_twice, dead_stream_status);
     HIP_OK(hipFree(d_p)); HIP_OK(hipFree(d_t)); HIP_OK(hipFree(d_s)); HIP_OK(hipStreamDestroy(st));
     free(p); free(t); free(s);
     return 0;

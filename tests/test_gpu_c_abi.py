@@ -26,6 +26,10 @@ def test_c_host_program_matches_oracle(tmp_path, flags):
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["sets"] == B and info["bad_shape_status"] == 2          # NDDM_ERR_SHAPE for n_trials = 0
+    # ABI 3 from plain C: a launch captured under a graph arena replays bit-identically, the arena held its memory and is released
+    # exactly once, and a destroyed stream's handle is an error code (NDDM_ERR_HIP), not a fault
+    assert info["graph_replay_equal"] == 1 and info["arena_allocations"] == 1 and info["arena_bytes"] >= 256
+    assert info["arena_released_twice_status"] == 3 and info["dead_stream_status"] == 4
     raw = np.fromfile(out, dtype=np.float32)
     p, t, s = np.split(raw, [B * 5, B * 5 + B * N * 2])
     p, t, s = p.reshape(B, 5), t.reshape(B, N, 2), s.reshape(B, 10)
