@@ -282,6 +282,30 @@ def test_pipelined_feed_over_rccl_at_world_1_equals_the_sequential_loop(tmp_path
             assert r[f"{parallel}/{form}"]["offset"] == iters * 32
 
 
+def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
+    """Integrity soak of the pipelined loop (tests/train_soak_worker.py): learning rate 0, so the loss of iteration k depends on
+    batch k alone -- 1200 online + 400 experience-replay iterations at dt=.001 (a 200 us simulate launch beside every training
+    graph) in the one-rank form, with the all-gather (RCCL, world 1) and with the gradient all-reduce: the pipelined history
+    equals the sequential loop's at EVERY iteration, and the random stream ends at the same position."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_soak_worker.py"), "1200", "400"], capture_output=True, text=True,
+                       timeout=1200, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for name in ("one rank", "gather", "ddp"):
+        o = out[name]
+        assert o["iterations"] == 1600 and o["finite"] and o["offsets_equal"], (name, o)
+        assert o["n_mismatch"] == 0, (name, o)
+        assert o["spread"] > 0.05, (name, o)                 # (the batches DO differ: equal histories are not equal constants)
+
+
 def test_graph_trainer_single_trial_model():
     """The same loop for single_trial_alpha_not_scaled (its script trains the same way, :193-230): 7 target parameters, data
     (choicert, z1); the graph-replayed history equals the eager one and the loss goes down."""
