@@ -88,6 +88,7 @@ class GraphTrainer:
         self.split = (self.world > 1) if split is None else bool(split)
         self.overlap = bool(overlap) and self.use_graph
         self.iteration = 0
+        self._warned_past_end = False
         self._loss_host = []               # losses already read out of the device ring (_drain_losses)
         self._uses = {}                    # pipelined loop, direct form: how often each bucket was produced into (-> its buffer set)
         with torch.cuda.device(self.dev):
@@ -641,6 +642,7 @@ class GraphTrainer:
 
     def train_online(self, iterations):
         """`iterations` training steps, every batch fresh; returns nothing -- losses stay on the device until loss_history()."""
+        self._note_schedule_end(iterations)
         if self.overlap:
             return self._train_overlapped(iterations, None)
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -657,6 +659,7 @@ class GraphTrainer:
         import numpy as np
         if self._replay is None:
             self._replay = ([], np.random.default_rng(replay_seed), int(capacity_in_batches))
+        self._note_schedule_end(iterations)
         if self.overlap:
             return self._train_overlapped(iterations, self._replay)
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -665,6 +668,15 @@ class GraphTrainer:
                 self._iteration(shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max), self._replay)
                 self.iteration += 1
         torch.cuda.current_stream(self.dev).wait_stream(self._stream)
+
+    def _note_schedule_end(self, iterations):
+        """A run that goes past `total_steps` trains on at the schedule's final rate (0 for the cosine): legal, and what
+        BayesFlow's decay does past `decay_steps`, but almost never what was meant -- say so once."""
+        if self.iteration + int(iterations) > self.T and not self._warned_past_end:
+            import warnings
+            self._warned_past_end = True
+            warnings.warn(f"GraphTrainer: iteration {self.iteration} + {int(iterations)} goes past total_steps={self.T}; the cosine schedule "
+                          "holds its final learning rate (0) from there on", RuntimeWarning, stacklevel=3)
 
     def _drain_losses(self):
         """Read the losses the host does not hold yet out of the device ring (one synchronisation of the training stream)."""

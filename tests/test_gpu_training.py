@@ -212,11 +212,13 @@ def test_graph_trainer_past_total_steps_holds_the_rate_and_keeps_every_loss():
                 weights.append(gt.flat_p.clone())
             return gt.loss_history(), rates, weights
 
-    h, rates, w = run(True, (T, 15, 2 * T + 7))
+    with pytest.warns(RuntimeWarning, match="past total_steps"):                             # said once, not an error
+        h, rates, w = run(True, (T, 15, 2 * T + 7))
     assert len(h) == 3 * T + 22 and np.all(np.isfinite(h))
     assert 0 < rates[0] < 0.02 * lr0 and rates[1] == 0.0 and rates[2] == 0.0, rates      # (lr_t: the rate the LAST step used)
     assert torch.equal(w[0], w[1]) and torch.equal(w[1], w[2])                            # rate 0: nothing moves after step T
-    h_eager, rates_e, _ = run(False, (T, 15, 2 * T + 7))
+    with pytest.warns(RuntimeWarning, match="past total_steps"):
+        h_eager, rates_e, _ = run(False, (T, 15, 2 * T + 7))
     assert rates_e[1] == 0.0 and np.allclose(h, h_eager, rtol=1e-4, atol=1e-4), np.abs(np.array(h) - np.array(h_eager)).max()
     h_short, _, _ = run(True, (T,))
     assert np.allclose(h[:T], h_short, rtol=1e-6, atol=1e-6)
