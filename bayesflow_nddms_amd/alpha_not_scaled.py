@@ -56,7 +56,7 @@ def generate_data(test_num=2, nparts=100, ntrials=100, seed=2021, dt=.001, max_s
                         seed=seed if sim_seed is None else sim_seed, set_offset=0 if set_offset is None else set_offset,
                         fast=fast, bridge=bridge, ext_sigma=sigma, ext_mode=1 if test_num == 4 else 0, want_ext=True,
                         want_summary=False)
-    y = r["trials"][..., 0].cpu().numpy().astype(np.float64).reshape(-1)
+    y = engine.to_host(r["trials"][..., 0]).astype(np.float64).reshape(-1)
     N = nparts * ntrials
     var_alpha = (1 / 12) * (1.4 - .8) ** 2
     genparam = dict(par)

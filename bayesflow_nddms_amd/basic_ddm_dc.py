@@ -37,14 +37,13 @@ def simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_off
 def batch_simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None,
                           as_numpy=True, with_summary=True):
     """Whole batch in one launch: params [B, 5] (numpy or device tensor) -> {'sim_data': [B, n_trials, 2] float32,
-    'summary_stats': [B, 10]} (numpy by default; device tensors with as_numpy=False)."""
-    r = engine.simulate(MODEL, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset,
-                        fast=fast, want_summary=with_summary)
+    'summary_stats': [B, 10]} (numpy by default -- large batches then travel to pinned host memory chunk by chunk beside the
+    simulation of the next chunk, engine.simulate_to_host; device tensors with as_numpy=False)."""
+    run = engine.simulate_to_host if as_numpy else engine.simulate
+    r = run(MODEL, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=with_summary)
     out = {"sim_data": r["trials"]}
     if with_summary:
         out["summary_stats"] = r["summary"]
-    if as_numpy:
-        out = {k: v.cpu().numpy() for k, v in out.items()}
     return out
 
 

@@ -262,6 +262,112 @@ def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device
     return out
 
 
+PINNED_FROM_BYTES = 1 << 20
+
+
+def to_host(t):
+    """Device tensor -> NumPy array (what the adapters' `as_numpy` forms return).  A result of a megabyte or more goes through
+    PINNED host memory: the copy then runs at the link's rate (53 GB/s measured on the MI355X box against 6.4 GB/s into pageable
+    memory -- 2.4 GB of trials in 45 ms instead of 380, `profiles/r4_pcie_rate.txt`).  The array owns its block (it returns to
+    PyTorch's pinned-memory cache when the array is dropped)."""
+    torch = _torch()
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.numpy()
+    if t.numel() * t.element_size() < PINNED_FROM_BYTES:
+        return t.cpu().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy()
+
+
+HOST_CHUNK_BYTES = 128 << 20
+
+
+def simulate_to_host(model, params, n_trials, seed=None, set_offset=None, stream_state=None, bounds=None, want_trials=True,
+                     want_summary=True, want_ext=False, device=None, chunk_bytes=None, **kw):
+    """simulate() for a caller who wants NumPy arrays back (the adapters' `as_numpy` forms): {'trials', 'summary', 'ext'} as
+    float32 arrays in pinned host memory, plus 'seed' / 'set_offset'.
+
+    A small batch is one launch and one copy.  A large one (more than `chunk_bytes` of trials, default 128 MB) is simulated in
+    CHUNKS of parameter sets, and every chunk's results travel to the host on a second stream while the next chunk is simulated:
+    the sets' random streams are keyed by their global index (set_offset + row), so the chunks reproduce the one launch bit for
+    bit, the device holds two chunks instead of the whole result, and the 2.4 GB of the 1M x 300 workload are on the host
+    47 ms after the call instead of 77 (one launch, then the copy) or 400 (`.cpu()`): profiles/r4_pcie_rate.txt."""
+    torch = require_device()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    on_host = not (isinstance(params, torch.Tensor) and params.is_cuda)
+    if on_host:
+        p_np = np.ascontiguousarray(params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else params, dtype=np.float64)
+        if p_np.ndim == 1:
+            p_np = p_np[None]
+        if p_np.ndim != 2 or p_np.shape[1] != NPARAMS[model]:
+            raise ValueError(f"params must have shape [B, {NPARAMS[model]}] for this model, got {p_np.shape}")
+        validate_params_host(model, p_np)
+        params = torch.as_tensor(p_np, dtype=torch.float32).contiguous().to(dev)
+    elif params.ndim == 1:
+        params = params[None]
+    B, n_trials = int(params.shape[0]), int(n_trials)
+    if seed is None or set_offset is None:
+        s_seed, s_off = (stream_state or GLOBAL_STREAM).take(B)
+        seed = s_seed if seed is None else seed
+        set_offset = s_off if set_offset is None else set_offset
+    seed, set_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(set_offset) & 0xFFFFFFFFFFFFFFFF
+    if model == EXPLICIT_BOUNDARY and bounds is not None and not (isinstance(bounds, torch.Tensor) and bounds.is_cuda):
+        b_np = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(B, n_trials))
+        if np.any(b_np < 0) or not np.all(np.isfinite(b_np)):
+            raise ValueError("Trial-level boundary cannot be less than zero")
+        bounds = torch.as_tensor(b_np, dtype=torch.float32).contiguous().to(dev)
+    elif bounds is not None and isinstance(bounds, torch.Tensor):
+        bounds = bounds.reshape(B, n_trials)
+    want_ext = bool(want_ext and model == ALPHA_NOT_SCALED)
+    row_bytes = n_trials * 8 if want_trials else 4 * SUMMARY_K
+    chunk_bytes = HOST_CHUNK_BYTES if chunk_bytes is None else int(chunk_bytes)
+    rows = B if B * row_bytes <= chunk_bytes or not want_trials else max(1, chunk_bytes // row_bytes)
+    common = dict(seed=seed, want_trials=want_trials, want_summary=want_summary, want_ext=want_ext, device=dev, **kw)
+    res = {"seed": seed, "set_offset": set_offset}
+    if rows >= B:                                            # one launch, one copy per output
+        r = simulate(model, params, n_trials, set_offset=set_offset, bounds=bounds, **common)
+        for k in ("trials", "summary", "ext"):
+            if k in r:
+                res[k] = to_host(r[k])
+        return res
+    with torch.cuda.device(dev):
+        pin = lambda *shape: torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        host = {"trials": pin(B, n_trials, 2) if want_trials else None, "summary": pin(B, SUMMARY_K) if want_summary else None,
+                "ext": pin(B) if want_ext else None}
+        cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+        bufs, copied = [None, None], [None, None]
+        for c, lo in enumerate(range(0, B, rows)):
+            hi, b = min(B, lo + rows), c & 1
+            if copied[b] is not None:
+                cur.wait_event(copied[b])                   # this buffer set's previous chunk is on the host
+            if bufs[b] is None:
+                bufs[b] = {"trials": torch.empty((rows, n_trials, 2), dtype=torch.float32, device=dev) if want_trials else None,
+                           "summary": torch.empty((rows, SUMMARY_K), dtype=torch.float32, device=dev) if want_summary else None}
+            n = hi - lo
+            tr = bufs[b]["trials"][:n] if want_trials else None
+            sm = bufs[b]["summary"][:n] if want_summary else None
+            r = simulate(model, params[lo:hi], n_trials, set_offset=(set_offset + lo) & 0xFFFFFFFFFFFFFFFF,
+                         bounds=None if bounds is None else bounds[lo:hi], out_trials=tr, out_summary=sm, **common)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for k in ("trials", "summary", "ext"):
+                    if host[k] is not None:
+                        host[k][lo:hi].copy_(r[k], non_blocking=True)
+                        r[k].record_stream(side)
+                copied[b] = torch.cuda.Event()
+                copied[b].record(side)
+        side.synchronize()
+    for k, h in host.items():
+        if h is not None:
+            res[k] = h.numpy()
+    return res
+
+
 def debug_normals(counters, k0, k1, fast=False):
     """4 normals per Philox counter row (tests compare these with the oracle's)."""
     torch = require_device()

@@ -31,5 +31,5 @@ def impute_choicert(drift, bounds, beta, ter, dc, dt=.01, max_steps=400., seed=N
         raise ValueError("Trial-level boundary cannot be less than zero")
     r = engine.simulate(engine.EXPLICIT_BOUNDARY, P, b.shape[1], dt=dt, max_steps=max_steps, seed=seed,
                         set_offset=set_offset, fast=fast, bounds=b, want_summary=False)
-    out = r["trials"][..., 0].cpu().numpy().astype(np.float64)
+    out = engine.to_host(r["trials"][..., 0]).astype(np.float64)
     return out[0] if one else out

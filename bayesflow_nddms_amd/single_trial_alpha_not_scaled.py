@@ -33,9 +33,10 @@ def _with_gamma(params, gamma):
     return p
 
 
-def _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=False):
-    return engine.simulate(model, _with_gamma(params, gamma), n_trials, dt=dt, max_steps=max_steps, seed=seed,
-                           set_offset=set_offset, fast=fast, want_summary=want_summary)
+def _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=False, to_host=False):
+    run = engine.simulate_to_host if to_host else engine.simulate
+    return run(model, _with_gamma(params, gamma), n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast,
+               want_summary=want_summary)
 
 
 def diffusion_trial(drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, dt=.01, max_steps=400., seed=None,
@@ -81,14 +82,13 @@ def simulate_trials_scale2(params, n_trials, dt=.01, max_steps=400., seed=None, 
 def batch_simulate_trials(params, n_trials, dt=.01, max_steps=400., gamma=1.0, variant="single", seed=None,
                           set_offset=None, fast=None, as_numpy=True, with_summary=True):
     """Whole batch in one launch: params [B, 7] (or [B, 8] with gamma) -> {'sim_data': [B, n_trials, 2],
-    'summary_stats': [B, 10]}.  variant: 'single' | 'alt'."""
+    'summary_stats': [B, 10]}.  variant: 'single' | 'alt'.  as_numpy: pinned host arrays, large batches chunk by chunk beside
+    the simulation (engine.simulate_to_host)."""
     model = engine.SINGLE_TRIAL if variant == "single" else engine.SINGLE_TRIAL_ALT
-    r = _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=with_summary)
+    r = _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=with_summary, to_host=as_numpy)
     out = {"sim_data": r["trials"]}
     if with_summary:
         out["summary_stats"] = r["summary"]
-    if as_numpy:
-        out = {k: v.cpu().numpy() for k, v in out.items()}
     return out
 
 

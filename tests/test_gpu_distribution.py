@@ -365,6 +365,66 @@ def test_full_size_alpha_not_scaled(bridge):
         assert torch.equal(r2["trials"], t[lo:hi]) and torch.equal(r2["ext"], ext[lo:hi])
 
 
+def test_numpy_results_go_through_pinned_memory_and_equal_the_device_tensors():
+    """`as_numpy` results of a megabyte or more are staged through pinned host memory (engine.to_host: the link's rate instead of
+    the pageable copy's): same bits as the device tensors, ordinary writeable arrays that own their memory (a later call does not
+    overwrite an earlier result), strided sources included."""
+    import gc
+    import torch
+    from bayesflow_nddms_amd import basic_ddm_dc, engine
+    p = prior_util.basic_prior(2000, 11)
+    dev = basic_ddm_dc.batch_simulate_trials(p, 300, seed=9, set_offset=0, as_numpy=False)
+    host = basic_ddm_dc.batch_simulate_trials(p, 300, seed=9, set_offset=0)                   # 4.8 MB of trials: the pinned route
+    assert dev["sim_data"].numel() * 4 >= engine.PINNED_FROM_BYTES
+    assert isinstance(host["sim_data"], np.ndarray) and host["sim_data"].dtype == np.float32 and host["sim_data"].flags.writeable
+    assert np.array_equal(host["sim_data"].view(np.uint32), dev["sim_data"].cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.nan_to_num(host["summary_stats"]), np.nan_to_num(dev["summary_stats"].cpu().numpy()))
+    keep = host["sim_data"].copy()
+    other = basic_ddm_dc.batch_simulate_trials(p, 300, seed=10, set_offset=0)["sim_data"]       # a second result: its own block
+    gc.collect()
+    assert np.array_equal(host["sim_data"], keep) and not np.array_equal(other, keep)
+    col = engine.to_host(dev["sim_data"][..., 0])                                              # a strided view
+    assert col.shape == (2000, 300) and np.array_equal(col, keep[..., 0])
+    assert np.array_equal(engine.to_host(dev["sim_data"][:3]), keep[:3])                        # (small: the plain route)
+    assert engine.to_host(torch.arange(4)).tolist() == [0, 1, 2, 3] and engine.to_host([1, 2]).tolist() == [1, 2]
+
+
+def test_chunked_results_to_the_host_equal_one_launch():
+    """engine.simulate_to_host: a large batch is simulated in chunks of sets whose results travel to pinned host memory beside the
+    simulation of the next chunk.  Every output of every model equals the one launch's, every bit (the sets' random streams are
+    keyed by their global index), with a ragged last chunk, and the package-level stream moves by the batch once."""
+    import torch
+    import bayesflow_nddms_amd as nd
+    from bayesflow_nddms_amd import engine
+    B, N = 1003, 120
+    rng = np.random.default_rng(5)
+    cases = [(engine.BASIC_DDM_DC, prior_util.basic_prior(B, 1), dict()),
+             (engine.SINGLE_TRIAL, prior_util.single_prior(B, 2, gamma=1.0), dict()),
+             (engine.ALPHA_NOT_SCALED, prior_util.alpha_ns_prior(B, 3), dict(bridge=True, ext_sigma=0.1, want_ext=True)),
+             (engine.EXPLICIT_BOUNDARY, prior_util.basic_prior(B, 4)[:, [0, 2, 3, 4]],
+              dict(bounds=np.abs(rng.normal(1.2, 0.4, size=(B, N))).astype(np.float32)))]
+    for model, p, kw in cases:
+        one = engine.simulate(model, p, N, dt=0.001, max_steps=4000, seed=77, set_offset=2**32 - 500, **kw)
+        for chunk_bytes in (150 * N * 8, 1 << 40):                     # 7 chunks (the last of 103 sets) | one launch
+            got = engine.simulate_to_host(model, p, N, dt=0.001, max_steps=4000, seed=77, set_offset=2**32 - 500, chunk_bytes=chunk_bytes, **kw)
+            for k in ("trials", "summary") + (("ext",) if "want_ext" in kw else ()):
+                assert isinstance(got[k], np.ndarray)
+                assert np.array_equal(np.nan_to_num(got[k]).view(np.uint32), np.nan_to_num(one[k].cpu().numpy()).view(np.uint32)), (model, k, chunk_bytes)
+    # summary-only: nothing to chunk; the global stream: one take of B sets per call, chunked or not
+    s_only = engine.simulate_to_host(engine.BASIC_DDM_DC, cases[0][1], N, seed=1, set_offset=0, want_trials=False, chunk_bytes=1000)
+    assert "trials" not in s_only and s_only["summary"].shape == (B, 10)
+    nd.seed(31)
+    a = engine.simulate_to_host(engine.BASIC_DDM_DC, cases[0][1], N, chunk_bytes=150 * N * 8)
+    b = engine.simulate_to_host(engine.BASIC_DDM_DC, cases[0][1], N, chunk_bytes=150 * N * 8)
+    nd.seed(31)
+    a2 = engine.simulate(engine.BASIC_DDM_DC, cases[0][1], N)
+    b2 = engine.simulate(engine.BASIC_DDM_DC, cases[0][1], N)
+    assert a["set_offset"] == a2["set_offset"] and b["set_offset"] == b2["set_offset"] == a["set_offset"] + B
+    assert np.array_equal(a["trials"], a2["trials"].cpu().numpy()) and np.array_equal(b["trials"], b2["trials"].cpu().numpy())
+    with pytest.raises(ValueError):
+        engine.simulate_to_host(engine.BASIC_DDM_DC, -np.abs(cases[0][1]), N)                  # validation as in simulate()
+
+
 def test_drop_in_api_on_device(kat):
     """The reference's call shapes end to end on the GPU: per-set simulator_fun, batched generative model, dict keys,
     configurator, alpha_not_scaled generator, imputation loop."""

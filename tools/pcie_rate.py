@@ -56,11 +56,17 @@ def main():
                 pinned[sl].copy_(out[sl], non_blocking=True)
         torch.cuda.current_stream().wait_stream(side)
 
-    tk, tp, tg, tc = timed(kernel_only), timed(to_pinned), timed(to_pageable, 2), timed(chunked)
+    from bayesflow_nddms_amd import basic_ddm_dc
+
+    def adapter():                                   # the drop-in's batched form returning NumPy (chunks of 128 MB, pinned, copy beside compute)
+        return basic_ddm_dc.batch_simulate_trials(p, N, dt=0.001, max_steps=4000, seed=1, set_offset=0, with_summary=False)["sim_data"]
+
+    tk, tp, tg, tc, ta = timed(kernel_only), timed(to_pinned), timed(to_pageable, 2), timed(chunked), timed(adapter)
     gb = B * N * 8 / 1e9
     print(f"{B} sets x {N} trials, dt=.001 (basic_ddm_dc, fast), {gb:.2f} GB of (rt, choice) pairs")
     for name, t in (("device only (the bench line's form)", tk), ("+ copy to pinned host memory", tp), ("+ copy to pageable host memory (.cpu())", tg),
-                    (f"{chunks} chunks, copy of chunk i beside the simulation of chunk i + 1 (pinned)", tc)):
+                    (f"{chunks} chunks, copy of chunk i beside the simulation of chunk i + 1 (pinned)", tc),
+                    ("basic_ddm_dc.batch_simulate_trials(..., as_numpy=True): the adapter (engine.simulate_to_host)", ta)):
         print(f"  {name:82s} {t * 1e3:8.1f} ms   {B * N / t:.3e} trials/s" + ("" if t is tk else f"   copy alone ~ {gb / max(t - tk, 1e-9):.1f} GB/s"))
     chk = np.array_equal(pinned.numpy()[:1000], out[:1000].cpu().numpy())
     print("  chunked output == one-launch output (first 1000 sets):", chk)
