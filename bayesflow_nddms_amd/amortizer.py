@@ -565,7 +565,14 @@ class Trainer:
     simulator's (seed, offset) stream state, so a resumed run continues the random stream."""
 
     def __init__(self, amortizer, generative_model, configurator=None, checkpoint_path=None, learning_rate=5e-4,
-                 device=None, stream_state=None):
+                 device=None, stream_state=None, graph=False):
+        """graph=True: train_online / train_experience_replay keep the reference's call shape (basic_ddm_dc.py:199-202) and
+        run as hipGraph replays (graph_trainer.GraphTrainer: device prior -> simulate -> forward/backward -> clip -> Adam, one
+        batch ahead) when the generative model says how it is made (`graph_spec`, set by the model modules'
+        make_generative_model): ~25 x the eager loop at batch 32.  The batches then come from the library's on-device prior
+        and simulator keyed by `graph_spec['seed']` -- the same distributions, another random stream than the generative
+        model's own -- and a ValueError says so if the model cannot be run that way."""
+        self.graph = bool(graph)
         self.amortizer, self.generative_model = amortizer, generative_model
         self.configurator = configurator or (lambda d: d)
         self.checkpoint_path = checkpoint_path
@@ -644,8 +651,38 @@ class Trainer:
                 nxt = launch()
             yield conf
 
+    def _graph_loop(self, replay, epochs, iterations_per_epoch, batch_size, capacity_in_batches, validation_sims, save_checkpoint,
+                    optimizer):
+        """The call as graph replays: one GraphTrainer for THIS call (its cosine schedule spans epochs x iterations, a fresh Adam:
+        _setup_schedule's semantics), an epoch = one train_* call of it, validation loss and checkpoint between epochs."""
+        spec = getattr(self.generative_model, "graph_spec", None)
+        if spec is None or self.device.type != "cuda" or optimizer is not None:
+            raise ValueError("Trainer(graph=True) needs a generative model made by a model module's make_generative_model "
+                             "(it carries `graph_spec`), a ROCm device, and no caller-supplied optimizer")
+        from .graph_trainer import GraphTrainer
+        val = []
+        with GraphTrainer(self.amortizer, batch_size=batch_size, total_steps=epochs * iterations_per_epoch, learning_rate=self.lr,
+                          device=self.device, **spec) as gt:
+            for _ in range(epochs):
+                if replay:
+                    gt.train_experience_replay(iterations_per_epoch, capacity_in_batches=capacity_in_batches)
+                else:
+                    gt.train_online(iterations_per_epoch)
+                if validation_sims is not None:
+                    val.append(gt.validation_loss(self.configurator(validation_sims)))
+                if save_checkpoint and self.checkpoint_path:
+                    self.loss_history_graph = gt.loss_history()
+                    gt.save_checkpoint(os.path.join(self.checkpoint_path, "graph_ckpt.pt"))
+                    self.save_checkpoint(extra_losses=self.loss_history_graph)
+            self.loss_history += gt.loss_history()
+        self._optimizer_spent = True
+        return val
+
     def train_online(self, epochs, iterations_per_epoch, batch_size, save_checkpoint=True, prefetch=True, reuse_optimizer=False,
                      optimizer=None, scheduler=None, **_):
+        if self.graph:
+            self._graph_loop(False, epochs, iterations_per_epoch, batch_size, 0, None, save_checkpoint, optimizer)
+            return self.loss_history
         self._setup_schedule(epochs * iterations_per_epoch, optimizer, scheduler)
         for ep in range(epochs):
             batches = (self._prefetcher(batch_size, iterations_per_epoch) if prefetch
@@ -663,6 +700,10 @@ class Trainer:
         """Each iteration simulates one fresh batch into a ring buffer of `capacity_in_batches` batches and trains on
         a randomly chosen stored batch (BayesFlow's experience replay, used at basic_ddm_dc.py:199-202).  Batches keep
         their own N (the non-batchable context), as in BayesFlow's buffer."""
+        if self.graph:
+            val = self._graph_loop(True, epochs, iterations_per_epoch, batch_size, capacity_in_batches, validation_sims, save_checkpoint,
+                                   optimizer)
+            return {"train_losses": self.loss_history, "val_losses": val}
         self._setup_schedule(epochs * iterations_per_epoch, optimizer, scheduler)
         rng = np.random.default_rng(0)
         val = []
@@ -684,17 +725,17 @@ class Trainer:
         return {"train_losses": self.loss_history, "val_losses": val}
 
     # ---- checkpoint / resume -----------------------------------------------------------------------
-    def save_checkpoint(self):
+    def save_checkpoint(self, extra_losses=()):
         if not self.checkpoint_path:
             return
         os.makedirs(self.checkpoint_path, exist_ok=True)
         state = {"model": self.amortizer.state_dict(), "optimizer": self.optimizer.state_dict(),
-                 "loss_history": self.loss_history}
+                 "loss_history": self.loss_history + list(extra_losses)}
         if self.stream_state is not None:
             state["stream_state"] = self.stream_state.get_state()
         torch.save(state, os.path.join(self.checkpoint_path, "ckpt.pt"))
         with open(os.path.join(self.checkpoint_path, "history.pkl"), "wb") as f:
-            pickle.dump({"loss_history": self.loss_history}, f)
+            pickle.dump({"loss_history": state["loss_history"]}, f)
 
     def load_pretrained_network(self):
         path = os.path.join(self.checkpoint_path or "", "ckpt.pt")

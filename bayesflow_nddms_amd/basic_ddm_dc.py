@@ -84,4 +84,7 @@ def make_generative_model(batched=True, device_prior=False, dt=.01, max_steps=40
     else:
         fun = lambda p, n: simulate_trials(p, n, dt=dt, max_steps=max_steps, fast=fast)
         simulator = Simulator(simulator_fun=fun, context_generator=experimental_context)
-    return GenerativeModel(prior, simulator, skip_test=skip_test, name="basic_ddm_dc")
+    gm = GenerativeModel(prior, simulator, skip_test=skip_test, name="basic_ddm_dc")
+    # how a graph loop re-creates this model on the device (amortizer.Trainer(graph=True) -> graph_trainer.GraphTrainer)
+    gm.graph_spec = dict(model="basic", dt=dt, max_steps=max_steps, seed=2023 if seed is None else seed, n_min=60, n_max=300)
+    return gm

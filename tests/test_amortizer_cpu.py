@@ -1,6 +1,7 @@
 """CPU tests of the PyTorch stand-in for the BayesFlow side (SURVEY f-4): shapes, exact invertibility of the flow,
 the Trainer loops driven through the generative-model dictionary contract, checkpoint/resume."""
 import numpy as np
+import pytest
 import torch
 
 from bayesflow_nddms_amd.amortizer import (AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer,
@@ -159,3 +160,17 @@ def test_flow_state_dict_accepts_the_earlier_layout():
     zb, lb = b(x, c)
     assert torch.equal(za, zb) and torch.equal(la, lb) and b._perm_host == a._perm_host
     assert torch.allclose(b.inverse(zb, c), x, atol=1e-4)
+
+
+def test_graph_route_of_the_classic_trainer_is_refused_without_a_device_or_a_recipe():
+    """Trainer(graph=True) hands train_* to graph replays on the GPU; without a ROCm device, or for a generative model that does
+    not say how it is made, the call raises -- it never falls back to the eager loop silently."""
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+    gm = lambda b: None
+    tr = Trainer(am, gm, graph=True, device="cpu")
+    with pytest.raises(ValueError, match="graph_spec"):
+        tr.train_online(1, 2, 4)
+    with pytest.raises(ValueError, match="graph_spec"):
+        tr.train_experience_replay(1, 2, 4)
+

@@ -284,6 +284,44 @@ def test_pipelined_feed_over_rccl_at_world_1_equals_the_sequential_loop(tmp_path
             assert r[f"{parallel}/{form}"]["offset"] == iters * 32
 
 
+def test_classic_trainer_call_shape_runs_as_graph_replays(tmp_path):
+    """The reference's call (basic_ddm_dc.py:172-176, 199-207) -- Trainer(amortizer, generative_model, configurator, checkpoint_path),
+    train_experience_replay(epochs, iterations_per_epoch, batch_size, validation_sims), load_pretrained_network -- with
+    graph=True: the same return shapes, every loss kept, validation loss and checkpoint per epoch, the loss goes down, a fresh
+    Trainer loads what was saved; a generative model the graph loop cannot re-create is refused by name."""
+    import os
+    import torch
+    from bayesflow_nddms_amd import basic_ddm_dc, single_trial_alpha_not_scaled as st
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    from bayesflow_nddms_amd.simulation import GenerativeModel
+    for mod, P in ((basic_ddm_dc, 5), (st, 7)):
+        torch.manual_seed(0)
+        gm = mod.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+        assert gm.graph_spec["model"] in ("basic", "single")
+        am = AmortizedPosterior(InvertibleNetwork(num_params=P), InvariantNetwork())
+        ck = str(tmp_path / f"ck{P}")
+        tr = Trainer(am, gm, mod.configurator, checkpoint_path=ck, graph=True)
+        val_sims = gm(64)
+        out = tr.train_experience_replay(epochs=3, iterations_per_epoch=80, batch_size=32, validation_sims=val_sims)
+        tl, vl = np.array(out["train_losses"]), out["val_losses"]
+        assert tl.shape == (240,) and len(vl) == 3 and np.all(np.isfinite(tl)) and np.all(np.isfinite(vl))
+        assert tl[-40:].mean() < tl[:40].mean() - 0.5 and vl[-1] < vl[0]
+        assert os.path.exists(os.path.join(ck, "ckpt.pt")) and os.path.exists(os.path.join(ck, "graph_ckpt.pt"))
+        h = tr.train_online(epochs=1, iterations_per_epoch=20, batch_size=32)                   # a second call: a run of its own
+        assert len(h) == 260 and len(tr.loss_history) == 260
+        am2 = AmortizedPosterior(InvertibleNetwork(num_params=P), InvariantNetwork())
+        tr2 = Trainer(am2, gm, mod.configurator, checkpoint_path=ck)
+        assert tr2.load_pretrained_network() and len(tr2.loss_history) == 260
+        with torch.no_grad():
+            conf = mod.configurator(val_sims)
+            a, b = float(am.compute_loss(conf)), float(am2.compute_loss(conf))
+        assert abs(a - b) < 1e-4 * (1 + abs(a)), (a, b)
+    plain = GenerativeModel(basic_ddm_dc.draw_prior, lambda p, n: basic_ddm_dc.simulate_trials(p, 50), simulator_is_batched=False, skip_test=True)
+    with pytest.raises(ValueError, match="graph_spec"):
+        Trainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), plain, basic_ddm_dc.configurator,
+                graph=True).train_online(1, 2, 4)
+
+
 def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
     """Integrity soak of the pipelined loop (tests/train_soak_worker.py): learning rate 0, so the loss of iteration k depends on
     batch k alone -- 1200 online + 400 experience-replay iterations at dt=.001 (a 200 us simulate launch beside every training
