@@ -173,11 +173,15 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
         STAMP(2);
         {   // layer 2: wave w owns units [32 w, 32 w + 32) as two 16 x 16 tiles (two independent accumulators);
             // lane l: A[row l & 15][k] = h1[row][k], B[k][unit l & 15] = W2[unit][k] for the k's 32 (l >> 4) + s, s = 0 .. 31
-            const int n = lane & 15, kk = lane >> 4;
+            // (which 32 k's a lane group takes is free -- the MFMA sums over all four groups -- and it decides the LDS banks: ds_read_b128
+            //  serves lanes {0-3, 12-15, 20-27} together, i.e. rows n of group 0 with rows n' of group 1, on 64 banks = 16 slots of 16
+            //  bytes; with a row stride of 33 slots, groups 0 and 1 must start a multiple of 16 slots = 64 floats apart, not 32, or
+            //  every read is a 2-way conflict: groups 0, 1, 2, 3 take the k blocks 0, 2, 1, 3)
+            const int n = lane & 15, kk = lane >> 4, kb = ((kk & 1) << 1) | (kk >> 1);
             f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-            const float4 *ap = reinterpret_cast<const float4 *>(&h1r[n][32 * kk]);
-            const float4 *bp0 = reinterpret_cast<const float4 *>(&w2s[32 * w + n][32 * kk]);
-            const float4 *bp1 = reinterpret_cast<const float4 *>(&w2s[32 * w + 16 + n][32 * kk]);
+            const float4 *ap = reinterpret_cast<const float4 *>(&h1r[n][32 * kb]);
+            const float4 *bp0 = reinterpret_cast<const float4 *>(&w2s[32 * w + n][32 * kb]);
+            const float4 *bp1 = reinterpret_cast<const float4 *>(&w2s[32 * w + 16 + n][32 * kb]);
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
                 const float4 a = ap[q4], b0 = bp0[q4], b1 = bp1[q4];
@@ -374,9 +378,10 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         {   // d h1 = da2 W2 -> d(pre-activation 1).  Lane l: A[row l & 15][k] = da2[row][k], B[k][i = l & 15] = W2[k][i] = w2t[i][k] for the
             // out units k = 32 (l >> 4) + s, s = 0 .. 31 (two accumulators: the even and the odd groups of four, a shorter dependent chain)
             const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
+            const int kb = ((kk & 1) << 1) | (kk >> 1);      // lane groups 0, 1, 2, 3 take the k blocks 0, 2, 1, 3: see the forward's layer 2
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc;
-            const float4 *ap = reinterpret_cast<const float4 *>(&da2r[16 * rb + n][32 * kk]);
-            const float4 *bp = reinterpret_cast<const float4 *>(&w2t[16 * ib + n][32 * kk]);
+            const float4 *ap = reinterpret_cast<const float4 *>(&da2r[16 * rb + n][32 * kb]);
+            const float4 *bp = reinterpret_cast<const float4 *>(&w2t[16 * ib + n][32 * kb]);
 #pragma unroll
             for (int q4 = 0; q4 < 8; q4 += 2) {
                 const float4 a0 = ap[q4], b0 = bp[q4], a1 = ap[q4 + 1], b1 = bp[q4 + 1];
