@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 // Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
 // are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of the original 33).
 constexpr int NTB = 1024;
+#ifndef NDDM_DGRAD_ROWS
+#define NDDM_DGRAD_ROWS 16
+#endif
 constexpr int LDT = H + 4;       // row stride of W2 TRANSPOSED in LDS, w2t[in unit][out unit]: d(h1) = d(a2) W2 sums over the OUT units, and
                                  // with the out units along a row both MFMA operands are read 16 bytes at a time (as in the forward:
                                  // the order of the sum is free, lane group k takes the k's [32 k, 32 k + 32)) instead of a dword at a
@@ -277,45 +280,48 @@ struct FlowBwdBuf {
 // What a row carries from half-layer to half-layer (the gradients of the layer's output, of its permuted ActNorm output, of the
 // condition) stays in LDS, the next half-layer's weights and saved activations are fetched into registers a half-layer ahead, and
 // the barriers order LDS traffic only (nothing here reads global memory that the kernel wrote): as in the forward.
-__global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, FlowBwdBuf U)
+template <int TRD, int NTD>      // rows per workgroup, threads: 32 x 1024 (one CU takes all of batch 32) or 16 x 512 (two CUs: full 16-row MFMA tiles each)
+__global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, FlowBwdBuf U)
 {
-    __shared__ __attribute__((aligned(16))) float h1r[TR][LDR];        // [row][unit]
-    __shared__ __attribute__((aligned(16))) float h2r[TR][LDR];        // later: d(pre-activation 1)
-    __shared__ __attribute__((aligned(16))) float da2r[TR][LDR];       // d(pre-activation 2); later: partial tiles of the input gradient
-    __shared__ float do_s[TR][M_MAX];
+    constexpr int G = NTD / H;        // thread t = (unit j = t % H, group g = t / H): a group takes rows 4 g .. 4 g + 3 in the VALU phases
+    static_assert(TRD == 4 * G && TRD % 16 == 0 && NTD / 64 == 8 * (TRD / 16), "one wave per 16 x 16 tile of the [TRD, H] MFMA phase");
+    __shared__ __attribute__((aligned(16))) float h1r[TRD][LDR];        // [row][unit]
+    __shared__ __attribute__((aligned(16))) float h2r[TRD][LDR];        // later: d(pre-activation 1)
+    __shared__ __attribute__((aligned(16))) float da2r[TRD][LDR];       // d(pre-activation 2); later: partial tiles of the input gradient
+    __shared__ float do_s[TRD][M_MAX];
     __shared__ __attribute__((aligned(16))) float w2t[H][LDT];
     __shared__ float w1s[H][DI_MAX + 1];
     __shared__ float w3s[M_MAX][H];
-    __shared__ float gout_s[TR][D_MAX], gz_s[TR][D_MAX], gy2_s[TR][D_MAX], gcond_s[TR][DI_MAX];
+    __shared__ float gout_s[TRD][D_MAX], gz_s[TRD][D_MAX], gy2_s[TRD][D_MAX], gcond_s[TRD][DI_MAX];
     const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D, d1 = Q.d1, d2 = D - d1;
-    const int r0 = blockIdx.x * TR;
-    // this thread's (row, column) of the affine phase: rows 0 .. TR - 1 x up to M_MAX / 2 columns
+    const int r0 = blockIdx.x * TRD;
+    // this thread's (row, column) of the affine phase: rows 0 .. TRD - 1 x up to M_MAX / 2 columns
     float gld_sc = 0.0f;                                     // nll form: the uniform gradient of log|det|
     if (U.g_nll) gld_sc = -*U.g_nll / (float)Q.R;
-    if (t < TR * D) {
+    if (t < TRD * D) {
         const int r = t / D, c = t - r * D, row = r0 + r;
         float v = 0.0f;
         if (row < Q.R) v = U.g_nll ? U.z_last[(long long)row * D + c] * (-gld_sc) : U.g_z[(long long)row * D + c];
         gout_s[r][c] = v;
     }
-    if (U.g_nll && t < TR && r0 + t < Q.R) U.w_gld[r0 + t] = gld_sc;
-    for (int p = t; p < TR * DI_MAX; p += NTB) (&gcond_s[0][0])[p] = 0.0f;
+    if (U.g_nll && t < TRD && r0 + t < Q.R) U.w_gld[r0 + t] = gld_sc;
+    for (int p = t; p < TRD * DI_MAX; p += NTD) (&gcond_s[0][0])[p] = 0.0f;
     // one thread's share of the next half-layer's operands
-    f32x4 nw2[H * H / 4 / NTB];       // thread (in unit j, g): out units 32 k4 + 4 g .. + 3, k4 = 0 .. 3, of column j
-    float nw1[H * DI_MAX / NTB], nw3[M_MAX * H / NTB], nh1[TR * H / NTB], nh2[TR * H / NTB], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
+    f32x4 nw2[H * H / 4 / NTD];       // thread (in unit j, g): out units 4 (g + G k4) .. + 3 of column j
+    float nw1[H * DI_MAX / NTD], nw3[M_MAX * H / NTD], nh1[TRD * H / NTD], nh2[TRD * H / NTD], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
 #define NDDM_FETCH_HALF(X) do {                                                                                               \
         const int DIn_ = (X).Dh + Q.C, Mn_ = 2 * (X).Dt;                                                                       \
-        _Pragma("unroll") for (int k4 = 0; k4 < H * H / 4 / NTB; ++k4) {          /* (a wave: 64 consecutive floats of a row) */      \
-            const float *w_ = (X).W2 + (long long)(32 * k4 + 4 * g) * H + j;                                                    \
+        _Pragma("unroll") for (int k4 = 0; k4 < H * H / 4 / NTD; ++k4) {          /* (a wave: 64 consecutive floats of a row) */      \
+            const float *w_ = (X).W2 + (long long)(4 * (g + G * k4)) * H + j;                                                    \
             nw2[k4] = f32x4{w_[0], w_[H], w_[2 * H], w_[3 * H]}; }                                                              \
-        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NTB; ++k) nw1[k] = (X).W1[min(t + NTB * k, H * DIn_ - 1)];          \
-        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTB; ++k) nw3[k] = (X).W3[min(t + NTB * k, Mn_ * H - 1)];            \
-        _Pragma("unroll") for (int k = 0; k < TR * H / NTB; ++k) {                                                             \
-            const long long o_ = (long long)min(r0 + g + 8 * k, Q.R - 1) * H + j;                                              \
+        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NTD; ++k) nw1[k] = (X).W1[min(t + NTD * k, H * DIn_ - 1)];          \
+        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTD; ++k) nw3[k] = (X).W3[min(t + NTD * k, Mn_ * H - 1)];            \
+        _Pragma("unroll") for (int k = 0; k < TRD * H / NTD; ++k) {                                                             \
+            const long long o_ = (long long)min(r0 + g + G * k, Q.R - 1) * H + j;                                              \
             nh1[k] = (X).h1[o_]; nh2[k] = (X).h2[o_];                                                                          \
         }                                                                                                                      \
-        {   const int r_ = t / (X).Dt, d_ = t - r_ * (X).Dt; const long long o_ = (long long)min(r0 + min(r_, TR - 1), Q.R - 1) * D + d_; \
-            ns = (X).s[o_]; nx = (X).xtr[o_]; ngl = U.g_nll ? gld_sc : U.g_ld[min(r0 + min(r_, TR - 1), Q.R - 1)]; }           \
+        {   const int r_ = t / (X).Dt, d_ = t - r_ * (X).Dt; const long long o_ = (long long)min(r0 + min(r_, TRD - 1), Q.R - 1) * D + d_; \
+            ns = (X).s[o_]; nx = (X).xtr[o_]; ngl = U.g_nll ? gld_sc : U.g_ld[min(r0 + min(r_, TRD - 1), Q.R - 1)]; }           \
     } while (0)
     NDDM_FETCH_HALF(T.half[2 * Q.L - 1]);
     for (int hl = 2 * Q.L - 1; hl >= 0; --hl) {
@@ -325,22 +331,22 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         lds_barrier();                    // the previous half-layer's readers are done
         STAMP(10);
 #pragma unroll
-        for (int k4 = 0; k4 < H * H / 4 / NTB; ++k4) *reinterpret_cast<f32x4 *>(&w2t[j][32 * k4 + 4 * g]) = nw2[k4];
+        for (int k4 = 0; k4 < H * H / 4 / NTD; ++k4) *reinterpret_cast<f32x4 *>(&w2t[j][4 * (g + G * k4)]) = nw2[k4];
 #pragma unroll
-        for (int k = 0; k < H * DI_MAX / NTB; ++k) {
-            const int p = t + NTB * k, jj = p / DI;
+        for (int k = 0; k < H * DI_MAX / NTD; ++k) {
+            const int p = t + NTD * k, jj = p / DI;
             if (p < H * DI) w1s[jj][p - jj * DI] = nw1[k];
         }
 #pragma unroll
-        for (int k = 0; k < M_MAX * H / NTB; ++k) (&w3s[0][0])[t + NTB * k] = nw3[k];
+        for (int k = 0; k < M_MAX * H / NTD; ++k) (&w3s[0][0])[t + NTD * k] = nw3[k];
 #pragma unroll
-        for (int k = 0; k < TR * H / NTB; ++k) {         // saved activations (rows beyond R: zero)
-            const int r = g + 8 * k;
+        for (int k = 0; k < TRD * H / NTD; ++k) {         // saved activations (rows beyond R: zero)
+            const int r = g + G * k;
             const bool ok = r0 + r < Q.R;
             h1r[r][j] = ok ? nh1[k] : 0.0f;
             h2r[r][j] = ok ? nh2[k] : 0.0f;
         }
-        if (t < TR * Dt) {                               // through the affine transform and the soft clamp
+        if (t < TRD * Dt) {                               // through the affine transform and the soft clamp
             const int r = t / Dt, d = t - r * Dt, row = r0 + r;
             // second: the gradient of out[:, :d1]; first: of out[:, d1:] plus what came through net 2's conditioning input
             const float gg = second ? gout_s[r][d] : gout_s[r][d1 + d] + gy2_s[r][d];
@@ -406,11 +412,12 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         }
         lds_barrier();
         STAMP(13);
-        {   // d in = d(a1) W1, [TR x DI] with k over the H units: wave -> (row block, column block, a quarter of the k's), 8 MFMAs;
+        {   // d in = d(a1) W1, [TRD x DI] with k over the H units: wave -> (row block, column block, a quarter of the k's), 8 MFMAs;
             // the four partial tiles are summed through LDS in fixed order.  Lane l: A[row l & 15][k], B[k][column l & 15] for
             // k = 32 q + 8 (l >> 4) + s, s = 0 .. 7.  (Columns >= DI of w1s are never written: they only reach columns >= DI.)
-            const int n = lane & 15, kk = lane >> 4, rb = wave & 1, cb = (wave >> 1) & 1, q = wave >> 2;
-            float (*part)[TR][DI_MAX + 1] = reinterpret_cast<float (*)[TR][DI_MAX + 1]>(&da2r[0][0]);    // (da2r's readers are done)
+            constexpr int RB = TRD / 16;
+            const int n = lane & 15, kk = lane >> 4, rb = wave % RB, cb = (wave / RB) & 1, q = wave / (2 * RB);
+            float (*part)[TRD][DI_MAX + 1] = reinterpret_cast<float (*)[TRD][DI_MAX + 1]>(&da2r[0][0]);    // (da2r's readers are done)
             if (16 * cb < DI) {
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 const float *ap = &h2r[16 * rb + n][32 * q + 8 * kk], *bp = &w1s[32 * q + 8 * kk][16 * cb + n];
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 for (int v = 0; v < 4; ++v) part[q][16 * rb + 4 * kk + v][16 * cb + n] = acc[v];
             }
             lds_barrier();
-            if (t < TR * DI) {
+            if (t < TRD * DI) {
                 const int r = t / DI, c = t - r * DI;
                 const float acc = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
                 if (c >= X.Dh) gcond_s[r][c - X.Dh] += acc;
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         lds_barrier();
         // back through the permutation and the ActNorm (the parameters' gradients: kernel (2))
         const NormD &N = T.norm[hl >> 1];
-        if (t < TR * D) {
+        if (t < TRD * D) {
             const int r = t / D, c = t - r * D, row = r0 + r, p = N.perm[c];
             const float gv = gz_s[r][c];
             gout_s[r][p] = gv * expf(N.scale[p]);
@@ -444,8 +451,8 @@ __global__ __launch_bounds__(NTB) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     }
 #undef NDDM_FETCH_HALF
     lds_barrier();
-    if (t < TR * D) { const int r = t / D, c = t - r * D; if (r0 + r < Q.R) U.gx[(long long)(r0 + r) * D + c] = gout_s[r][c]; }
-    for (int p = t; p < TR * Q.C; p += NTB) {
+    if (t < TRD * D) { const int r = t / D, c = t - r * D; if (r0 + r < Q.R) U.gx[(long long)(r0 + r) * D + c] = gout_s[r][c]; }
+    for (int p = t; p < TRD * Q.C; p += NTD) {
         const int r = p / Q.C, c = p - r * Q.C;
         if (r0 + r < Q.R) U.gcond[(long long)(r0 + r) * Q.C + c] = gcond_s[r][c];
     }
@@ -702,7 +709,10 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowBwdBuf U = {g_z, g_ld, gx, gcond, g_nll, g_ld, out_all + (long long)(L - 1) * RD};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(flow_dgrad_kernel, dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
+    if (NDDM_DGRAD_ROWS == 16)
+        hipLaunchKernelGGL((flow_dgrad_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, st, Q, TD, U);
+    else
+        hipLaunchKernelGGL((flow_dgrad_kernel<TR, NTB>), dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
     hipLaunchKernelGGL(flow_wgrad_kernel, dim3(2 * L), dim3(NTB), 0, st, Q, TW, cond, static_cast<const float *>(g_ld));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
