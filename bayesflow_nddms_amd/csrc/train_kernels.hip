@@ -17,6 +17,7 @@
 // gfx950 only.  tests/test_gpu_training.py compares with the PyTorch composition.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace nddm_train {
 
@@ -65,41 +66,45 @@ struct FlowP { LayerP layer[L_MAX]; unsigned char perm[L_MAX][D_MAX]; };
 struct FlowDims { int L, R, D, d1, C; float clamp; };
 struct FlowSaved { float *z_all, *out_all, *s_all, *h_all; };    // [L, R, D] permuted ActNorm outputs, layer outputs, clamped
                                                                   // log-scales; [L, 4, R, H] activations of the sub-networks
-__global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
+template <int TF, int NT>        // rows per workgroup, threads: 8 x 256 (four CUs at batch 32) or 16 x 512 (two CUs, full 16-row MFMA tiles)
+__global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
 {
-    __shared__ __attribute__((aligned(16))) float in_s[TRF][DI_MAX];
-    __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TRF..15 stay zero (the MFMA tile has 16 rows)
-    __shared__ __attribute__((aligned(16))) float h2r[TRF][LDR];
-    __shared__ float o_s[TRF][M_MAX];
+    constexpr int RP = TF / (NT / H);          // rows per thread in layer 1: thread t = (unit j = t % H, row group rh = t / H)
+    constexpr int UW = H / (NT / 64);          // units per wave in layer 2: 32 (two 16 x 16 tiles) or 16 (one)
+    static_assert(TF % 4 == 0 && TF <= 16 && (UW == 32 || UW == 16) && 2 * TF * M_MAX <= NT && TF * D_MAX <= NT, "tile shape");
+    __shared__ __attribute__((aligned(16))) float in_s[TF][DI_MAX];
+    __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TF..15 stay zero (the MFMA tile has 16 rows)
+    __shared__ __attribute__((aligned(16))) float h2r[TF][LDR];
+    __shared__ float o_s[TF][M_MAX];
     __shared__ float w3s[M_MAX][H + 1];       // (+ 1: the rows' readers are lanes m)
     __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
-    __shared__ float xs[2][TRF][D_MAX];       // the layer's input / output rows (alternating), zs: its permuted ActNorm output
-    __shared__ float zs[TRF][D_MAX], cs[TRF][DI_MAX];
+    __shared__ float xs[2][TF][D_MAX];       // the layer's input / output rows (alternating), zs: its permuted ActNorm output
+    __shared__ float zs[TF][D_MAX], cs[TF][DI_MAX];
     __shared__ float w1f[H * DI_MAX];         // W1 as it lies in memory: [unit][DI]
     const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7, lane = t & 63, w = t >> 6;
-    const int r0 = blockIdx.x * TRF, D = Q.D, d1 = Q.d1, d2 = D - d1;
+    const int r0 = blockIdx.x * TF, D = Q.D, d1 = Q.d1, d2 = D - d1;
     const long long RD = (long long)Q.R * D, RH = (long long)Q.R * H;
-    float ld_acc = 0.0f;                                     // threads t < TRF: log|det| of row r0 + t, summed as the layers go
+    float ld_acc = 0.0f;                                     // threads t < TF: log|det| of row r0 + t, summed as the layers go
     STAMP(0);
     // one thread's share of the next half-layer's weights (plain local arrays indexed by unrolled constants: registers)
-    f32x4 nw2[H * H / 4 / 256];           // (the compiler's own vector type: HIP's float4 struct kept the array in memory)
-    float nw1[H * DI_MAX / 256], nw3[M_MAX * H / 256], nb1, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
+    f32x4 nw2[H * H / 4 / NT];           // (the compiler's own vector type: HIP's float4 struct kept the array in memory)
+    float nw1[H * DI_MAX / NT], nw3[M_MAX * H / NT], nb1, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
 #define NDDM_FETCH_WEIGHTS(Wn, DIn, Mn) do {                                                                                  \
         const f32x4 *src_ = reinterpret_cast<const f32x4 *>((Wn).W2);                                                         \
-        _Pragma("unroll") for (int k = 0; k < H * H / 4 / 256; ++k) nw2[k] = src_[t + 256 * k];                                \
+        _Pragma("unroll") for (int k = 0; k < H * H / 4 / NT; ++k) nw2[k] = src_[t + NT * k];                                \
         /* (coalesced; every load unconditional, from a clamped address: a guarded load is a branch and a block of its own) */     \
-        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / 256; ++k) nw1[k] = (Wn).W1[min(t + 256 * k, H * (DIn) - 1)];          \
-        _Pragma("unroll") for (int k = 0; k < M_MAX * H / 256; ++k) {                                                          \
-            const int p_ = t + 256 * k; const float v_ = (Wn).W3[min(p_, (Mn) * H - 1)]; nw3[k] = p_ < (Mn) * H ? v_ : 0.0f; } \
-        nb1 = (Wn).b1[j]; nb20 = (Wn).b2[32 * w + (lane & 15)]; nb21 = (Wn).b2[32 * w + 16 + (lane & 15)];                     \
+        _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NT; ++k) nw1[k] = (Wn).W1[min(t + NT * k, H * (DIn) - 1)];          \
+        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NT; ++k) {                                                          \
+            const int p_ = t + NT * k; const float v_ = (Wn).W3[min(p_, (Mn) * H - 1)]; nw3[k] = p_ < (Mn) * H ? v_ : 0.0f; } \
+        nb1 = (Wn).b1[j]; nb20 = (Wn).b2[UW * w + (lane & 15)]; nb21 = (Wn).b2[min(UW * w + 16, H - 16) + (lane & 15)];                     \
         nb3 = (Wn).b3[(t >> 1) % (Mn)];                                                                                         \
     } while (0)
     NDDM_FETCH_WEIGHTS(P.layer[0].a, d1 + Q.C, 2 * d2);
-    if (t < TRF * D) { const int p = P.perm[0][t % D]; nsc = P.layer[0].scale[p]; nbi = P.layer[0].bias[p]; }
-    for (int p = t; p < (16 - TRF) * H; p += 256) h1r[TRF + (p >> 7)][p & (H - 1)] = 0.0f;
-    for (int p = t; p < TRF * DI_MAX; p += 256) (&in_s[0][0])[p] = 0.0f;
-    if (t < TRF * D) { const int r = t / D, c = t - r * D; xs[0][r][c] = r0 + r < Q.R ? theta[(long long)(r0 + r) * D + c] : 0.0f; }
-    if (t < TRF * Q.C) { const int r = t / Q.C, c = t - r * Q.C; cs[r][c] = r0 + r < Q.R ? cond[(long long)(r0 + r) * Q.C + c] : 0.0f; }
+    if (t < TF * D) { const int p = P.perm[0][t % D]; nsc = P.layer[0].scale[p]; nbi = P.layer[0].bias[p]; }
+    for (int p = t; p < (16 - TF) * H; p += NT) h1r[TF + (p >> 7)][p & (H - 1)] = 0.0f;
+    for (int p = t; p < TF * DI_MAX; p += NT) (&in_s[0][0])[p] = 0.0f;
+    if (t < TF * D) { const int r = t / D, c = t - r * D; xs[0][r][c] = r0 + r < Q.R ? theta[(long long)(r0 + r) * D + c] : 0.0f; }
+    if (t < TF * Q.C) { const int r = t / Q.C, c = t - r * Q.C; cs[r][c] = r0 + r < Q.R ? cond[(long long)(r0 + r) * Q.C + c] : 0.0f; }
     for (int hl = 0; hl < 2 * Q.L; ++hl) {
         const int l = hl >> 1;
         const bool second = hl & 1;
@@ -112,25 +117,25 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
         // this half-layer's weights: out of the registers (fetched a half-layer ago) into LDS / this thread's W1 row
         lds_barrier();                                     // (the previous half-layer's readers of w2s, w3s, xs are done)
 #pragma unroll
-        for (int k = 0; k < H * H / 4 / 256; ++k) { const int p4 = t + 256 * k; *reinterpret_cast<f32x4 *>(&w2s[p4 >> 5][4 * (p4 & 31)]) = nw2[k]; }
+        for (int k = 0; k < H * H / 4 / NT; ++k) { const int p4 = t + NT * k; *reinterpret_cast<f32x4 *>(&w2s[p4 >> 5][4 * (p4 & 31)]) = nw2[k]; }
 #pragma unroll
-        for (int k = 0; k < M_MAX * H / 256; ++k) { const int p = t + 256 * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
+        for (int k = 0; k < M_MAX * H / NT; ++k) { const int p = t + NT * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
 #pragma unroll
-        for (int k = 0; k < H * DI_MAX / 256; ++k) w1f[t + 256 * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, unread)
+        for (int k = 0; k < H * DI_MAX / NT; ++k) w1f[t + NT * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, unread)
         const float b1v = nb1, b20 = nb20, b21 = nb21, b3v = nb3, scv = nsc, biv = nbi;
         if (hl + 1 < 2 * Q.L) {                              // ... and the next one's into the registers
             const HalfP &Wn = second ? P.layer[l + 1].a : Y.b;
             NDDM_FETCH_WEIGHTS(Wn, (second ? d1 : d2) + Q.C, 2 * (second ? d2 : d1));
-            if (second && t < TRF * D) { const int p = P.perm[l + 1][t % D]; nsc = P.layer[l + 1].scale[p]; nbi = P.layer[l + 1].bias[p]; }
+            if (second && t < TF * D) { const int p = P.perm[l + 1][t % D]; nsc = P.layer[l + 1].scale[p]; nbi = P.layer[l + 1].bias[p]; }
         }
         if (!second) {
-            if (t < TRF * D) {                               // ActNorm, then the permutation: z[:, c] = u[:, perm[c]]
+            if (t < TF * D) {                               // ActNorm, then the permutation: z[:, c] = u[:, perm[c]]
                 const int r = t / D, c = t - r * D, p = P.perm[l][c];
                 const float v = fmaf(xin[r][p], expf(scv), biv);
                 zs[r][c] = v;
                 if (r0 + r < Q.R) z_g[(long long)(r0 + r) * D + c] = v;
             }
-            if (t < TRF) {
+            if (t < TF) {
 #pragma unroll
                 for (int d = 0; d < D_MAX; ++d) if (d < D) ld_acc += Y.scale[d];
             }
@@ -138,16 +143,16 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
         }
         // first:  conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s[:, :d2]
         // second: conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s[:, d2:]
-        for (int p = t; p < TRF * DI; p += 256) {
+        for (int p = t; p < TF * DI; p += NT) {
             const int r = p / DI, c = p - r * DI;
             in_s[r][c] = c < Dh ? (second ? xout[r][d1 + c] : zs[r][c]) : cs[r][c - Dh];
         }
         lds_barrier();
         STAMP(1);
         {   // layer 1 (register arrays are only ever indexed by unrolled constants: no private scratch)
-            float acc[RPT];
+            float acc[RP];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) acc[q] = b1v;
+            for (int q = 0; q < RP; ++q) acc[q] = b1v;
 #pragma unroll
             for (int c0 = 0; c0 < DI_MAX; c0 += 4) {         // (columns beyond DI: a zero weight against a finite -- zeroed or old -- input)
                 if (c0 < DI) {
@@ -155,15 +160,15 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 #pragma unroll
                     for (int u = 0; u < 4; ++u) wv[u] = c0 + u < DI ? w1f[j * DI + c0 + u] : 0.0f;
 #pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&in_s[rh * RPT + q][c0]);
+                    for (int q = 0; q < RP; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&in_s[rh * RP + q][c0]);
                         acc[q] = fmaf(wv[3], v.w, fmaf(wv[2], v.z, fmaf(wv[1], v.y, fmaf(wv[0], v.x, acc[q]))));
                     }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = rh * RPT + q;
+            for (int q = 0; q < RP; ++q) {
+                const int r = rh * RP + q;
                 const float v = elu(acc[q]);
                 h1r[r][j] = v;
                 if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + j] = v;
@@ -180,41 +185,58 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
             const int n = lane & 15, kk = lane >> 4, kb = ((kk & 1) << 1) | (kk >> 1);
             f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
             const float4 *ap = reinterpret_cast<const float4 *>(&h1r[n][32 * kb]);
-            const float4 *bp0 = reinterpret_cast<const float4 *>(&w2s[32 * w + n][32 * kb]);
-            const float4 *bp1 = reinterpret_cast<const float4 *>(&w2s[32 * w + 16 + n][32 * kb]);
+            const float4 *bp0 = reinterpret_cast<const float4 *>(&w2s[UW * w + n][32 * kb]);
+            const float4 *bp1 = reinterpret_cast<const float4 *>(&w2s[min(UW * w + 16, H - 16) + n][32 * kb]);
+            if constexpr (UW == 32) {
 #pragma unroll
-            for (int q4 = 0; q4 < 8; ++q4) {
-                const float4 a = ap[q4], b0 = bp0[q4], b1 = bp1[q4];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const float4 a = ap[q4], b0 = bp0[q4], b1 = bp1[q4];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+                }
+            } else {                                         // one tile per wave: the even and the odd groups of four k's in two accumulators
+#pragma unroll
+                for (int q4 = 0; q4 < 8; q4 += 2) {
+                    const float4 a0 = ap[q4], b0 = bp0[q4], a1 = ap[q4 + 1], b1 = bp0[q4 + 1];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+                }
+                acc0 += acc1;
             }
-            // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register: rows < TRF live in lanes 0..31
-            if (kk < TRF / 4) {
-                const int u0 = 32 * w + n, u1 = u0 + 16;
+            // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register: rows < TF live in lanes 0..31
+            if (kk < TF / 4) {
+                const int u0 = UW * w + n, u1 = u0 + 16;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 4 * kk + q;
-                    const float v0 = elu(acc0[q] + b20), v1 = elu(acc1[q] + b21);
+                    const float v0 = elu(acc0[q] + b20);
                     h2r[r][u0] = v0;
-                    h2r[r][u1] = v1;
-                    if (r0 + r < Q.R) {
-                        h2_out[(long long)(r0 + r) * H + u0] = v0;
-                        h2_out[(long long)(r0 + r) * H + u1] = v1;
+                    if (r0 + r < Q.R) h2_out[(long long)(r0 + r) * H + u0] = v0;
+                    if constexpr (UW == 32) {
+                        const float v1 = elu(acc1[q] + b21);
+                        h2r[r][u1] = v1;
+                        if (r0 + r < Q.R) h2_out[(long long)(r0 + r) * H + u1] = v1;
                     }
                 }
             }
         }
         lds_barrier();
         STAMP(3);
-        for (int p = t; p < 2 * TRF * M; p += 256) {      // layer 3: two threads (adjacent lanes) per output, half the units each
+        for (int p = t; p < 2 * TF * M; p += NT) {      // layer 3: two threads (adjacent lanes) per output, half the units each
             const int pr = p >> 1, half = p & 1, r = pr / M, m = pr - r * M;
-            float acc = half ? 0.0f : b3v;                   // (one pass: 2 TRF M <= 256 threads)
+            float acc = half ? 0.0f : b3v;                   // (one pass: 2 TF M <= NT threads)
 #pragma unroll 8
             for (int i = half * (H / 2); i < (half + 1) * (H / 2); ++i) acc = fmaf(w3s[m][i], h2r[r][i], acc);
             acc += __shfl_xor(acc, 1);
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
         }
         lds_barrier();
         STAMP(4);
-        if (t < TRF * Dt) {                                  // soft clamp + affine transform
+        if (t < TF * Dt) {                                  // soft clamp + affine transform
             const int r = t / Dt, d = t - r * Dt, row = r0 + r;
             const float sv = Q.clamp * tanhf(o_s[r][d] / Q.clamp);
             const float yv = fmaf(second ? zs[r][d] : zs[r][d1 + d], expf(sv), o_s[r][Dt + d]);
@@ -234,13 +256,13 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
             }
         }
         lds_barrier();
-        if (t < TRF) {
+        if (t < TF) {
 #pragma unroll
             for (int d = 0; d < M_MAX / 2; ++d) if (d < Dt) ld_acc += o_s[t][d];
         }
         STAMP(5);
     }
-    if (t < TRF && r0 + t < Q.R) ld[r0 + t] = ld_acc;        // log|det| of the row: every log-scale, and the ActNorms'
+    if (t < TF && r0 + t < Q.R) ld[r0 + t] = ld_acc;        // log|det| of the row: every log-scale, and the ActNorms'
     STAMP(6);
 }
 
@@ -253,6 +275,9 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(FlowDims Q, FlowP P, cons
 // Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
 // are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of the original 33).
 constexpr int NTB = 1024;
+#ifndef NDDM_FWD_ROWS
+#define NDDM_FWD_ROWS 16
+#endif
 #ifndef NDDM_DGRAD_ROWS
 #define NDDM_DGRAD_ROWS 16
 #endif
@@ -632,6 +657,14 @@ __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *l
 
 using namespace nddm_train;
 
+// Developer aid: the tile shape of the two chain kernels can be switched per process (A/B on one box) -- NDDM_TRAIN_FWD_ROWS = 8 | 16,
+// NDDM_TRAIN_DGRAD_ROWS = 16 | 32; read at every call (a getenv beside two kernel launches), defaults compiled in.
+static int tile_rows(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 extern "C" {
 
 // 1 for the shapes the fused flow covers (the caller takes the PyTorch path otherwise)
@@ -666,8 +699,12 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowSaved S = {z_all, out_all, s_all, h_all};
     hipLaunchKernelGGL(warm_l2_kernel, dim3(8 * 2 * L * WARM_PARTS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, ld);
-    hipLaunchKernelGGL(flow_fwd_kernel, dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta,
-                       cond, S, ld);
+    if (tile_rows("NDDM_TRAIN_FWD_ROWS", NDDM_FWD_ROWS) == 16)
+        hipLaunchKernelGGL((flow_fwd_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta,
+                           cond, S, ld);
+    else
+        hipLaunchKernelGGL((flow_fwd_kernel<TRF, 256>), dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P,
+                           theta, cond, S, ld);
     if (nll)
         hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out_all + (long long)(L - 1) * R * D,
                            ld, R, D, nll);
@@ -709,7 +746,7 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowBwdBuf U = {g_z, g_ld, gx, gcond, g_nll, g_ld, out_all + (long long)(L - 1) * RD};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (NDDM_DGRAD_ROWS == 16)
+    if (tile_rows("NDDM_TRAIN_DGRAD_ROWS", NDDM_DGRAD_ROWS) == 16)
         hipLaunchKernelGGL((flow_dgrad_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, st, Q, TD, U);
     else
         hipLaunchKernelGGL((flow_dgrad_kernel<TR, NTB>), dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
