@@ -69,10 +69,10 @@ struct FlowSaved { float *z_all, *out_all, *s_all, *h_all; };    // [L, R, D] pe
 template <int TF, int NT>        // rows per workgroup, threads: 8 x 256 (four CUs at batch 32) or 16 x 512 (two CUs, full 16-row MFMA tiles)
 __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
 {
-    constexpr int RP = TF / (NT / H);          // rows per thread in layer 1: thread t = (unit j = t % H, row group rh = t / H)
     constexpr int UW = H / (NT / 64);          // units per wave in layer 2: 32 (two 16 x 16 tiles) or 16 (one)
-    static_assert(TF % 4 == 0 && TF <= 16 && (UW == 32 || UW == 16) && 2 * TF * M_MAX <= NT && TF * D_MAX <= NT, "tile shape");
-    __shared__ __attribute__((aligned(16))) float in_s[TF][DI_MAX];
+    static_assert(TF % 4 == 0 && TF <= 16 && (UW == 32 || UW == 16) && 2 * TF * M_MAX <= NT && TF * D_MAX <= NT && DI_MAX == 32, "tile shape");
+    __shared__ float in_s[16 * (DI_MAX + 2)];   // the sub-network's input rows, an MFMA operand read a dword at a time down 16 rows: row stride 33 or 34 by
+                                                // the parity of DI (see layer 1); columns >= DI zero; rows TF.. stay zero
     __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TF..15 stay zero (the MFMA tile has 16 rows)
     __shared__ __attribute__((aligned(16))) float h2r[TF][LDR];
     __shared__ float o_s[TF][M_MAX];
@@ -80,15 +80,15 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
     __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
     __shared__ float xs[2][TF][D_MAX];       // the layer's input / output rows (alternating), zs: its permuted ActNorm output
     __shared__ float zs[TF][D_MAX], cs[TF][DI_MAX];
-    __shared__ float w1f[H * DI_MAX];         // W1 as it lies in memory: [unit][DI]
-    const int t = threadIdx.x, j = t & (H - 1), rh = t >> 7, lane = t & 63, w = t >> 6;
+    __shared__ float w1f[H * DI_MAX + DI_MAX];  // W1 as it lies in memory, [unit][DI]: the other MFMA operand of layer 1 (+ DI_MAX: the last unit's reads past its row)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int r0 = blockIdx.x * TF, D = Q.D, d1 = Q.d1, d2 = D - d1;
     const long long RD = (long long)Q.R * D, RH = (long long)Q.R * H;
     float ld_acc = 0.0f;                                     // threads t < TF: log|det| of row r0 + t, summed as the layers go
     STAMP(0);
     // one thread's share of the next half-layer's weights (plain local arrays indexed by unrolled constants: registers)
     f32x4 nw2[H * H / 4 / NT];           // (the compiler's own vector type: HIP's float4 struct kept the array in memory)
-    float nw1[H * DI_MAX / NT], nw3[M_MAX * H / NT], nb1, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
+    float nw1[H * DI_MAX / NT], nw3[M_MAX * H / NT], nb10, nb11, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
 #define NDDM_FETCH_WEIGHTS(Wn, DIn, Mn) do {                                                                                  \
         const f32x4 *src_ = reinterpret_cast<const f32x4 *>((Wn).W2);                                                         \
         _Pragma("unroll") for (int k = 0; k < H * H / 4 / NT; ++k) nw2[k] = src_[t + NT * k];                                \
@@ -96,13 +96,15 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
         _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NT; ++k) nw1[k] = (Wn).W1[min(t + NT * k, H * (DIn) - 1)];          \
         _Pragma("unroll") for (int k = 0; k < M_MAX * H / NT; ++k) {                                                          \
             const int p_ = t + NT * k; const float v_ = (Wn).W3[min(p_, (Mn) * H - 1)]; nw3[k] = p_ < (Mn) * H ? v_ : 0.0f; } \
-        nb1 = (Wn).b1[j]; nb20 = (Wn).b2[UW * w + (lane & 15)]; nb21 = (Wn).b2[min(UW * w + 16, H - 16) + (lane & 15)];                     \
+        nb10 = (Wn).b1[UW * w + (lane & 15)]; nb11 = (Wn).b1[min(UW * w + 16, H - 16) + (lane & 15)];                                \
+        nb20 = (Wn).b2[UW * w + (lane & 15)]; nb21 = (Wn).b2[min(UW * w + 16, H - 16) + (lane & 15)];                     \
         nb3 = (Wn).b3[(t >> 1) % (Mn)];                                                                                         \
     } while (0)
     NDDM_FETCH_WEIGHTS(P.layer[0].a, d1 + Q.C, 2 * d2);
     if (t < TF * D) { const int p = P.perm[0][t % D]; nsc = P.layer[0].scale[p]; nbi = P.layer[0].bias[p]; }
     for (int p = t; p < (16 - TF) * H; p += NT) h1r[TF + (p >> 7)][p & (H - 1)] = 0.0f;
-    for (int p = t; p < TF * DI_MAX; p += NT) (&in_s[0][0])[p] = 0.0f;
+    for (int p = t; p < 16 * (DI_MAX + 2); p += NT) in_s[p] = 0.0f;
+    for (int p = H * DI_MAX + t; p < H * DI_MAX + DI_MAX; p += NT) w1f[p] = 0.0f;
     if (t < TF * D) { const int r = t / D, c = t - r * D; xs[0][r][c] = r0 + r < Q.R ? theta[(long long)(r0 + r) * D + c] : 0.0f; }
     if (t < TF * Q.C) { const int r = t / Q.C, c = t - r * Q.C; cs[r][c] = r0 + r < Q.R ? cond[(long long)(r0 + r) * Q.C + c] : 0.0f; }
     for (int hl = 0; hl < 2 * Q.L; ++hl) {
@@ -121,13 +123,15 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
 #pragma unroll
         for (int k = 0; k < M_MAX * H / NT; ++k) { const int p = t + NT * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
 #pragma unroll
-        for (int k = 0; k < H * DI_MAX / NT; ++k) w1f[t + NT * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, unread)
-        const float b1v = nb1, b20 = nb20, b21 = nb21, b3v = nb3, scv = nsc, biv = nbi;
+        for (int k = 0; k < H * DI_MAX / NT; ++k) w1f[t + NT * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, finite)
+        const float b10 = nb10, b11 = nb11, b20 = nb20, b21 = nb21, b3v = nb3, scv = nsc, biv = nbi;
+        STAMP(7);
         if (hl + 1 < 2 * Q.L) {                              // ... and the next one's into the registers
             const HalfP &Wn = second ? P.layer[l + 1].a : Y.b;
             NDDM_FETCH_WEIGHTS(Wn, (second ? d1 : d2) + Q.C, 2 * (second ? d2 : d1));
             if (second && t < TF * D) { const int p = P.perm[l + 1][t % D]; nsc = P.layer[l + 1].scale[p]; nbi = P.layer[l + 1].bias[p]; }
         }
+        STAMP(8);
         if (!second) {
             if (t < TF * D) {                               // ActNorm, then the permutation: z[:, c] = u[:, perm[c]]
                 const int r = t / D, c = t - r * D, p = P.perm[l][c];
@@ -141,37 +145,54 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
             }
             lds_barrier();
         }
+        STAMP(9);
         // first:  conditioned on z[:, :d1], transforms z[:, d1:] -> out[:, d1:], log-scales -> s[:, :d2]
         // second: conditioned on out[:, d1:], transforms z[:, :d1] -> out[:, :d1], log-scales -> s[:, d2:]
-        for (int p = t; p < TF * DI; p += NT) {
-            const int r = p / DI, c = p - r * DI;
-            in_s[r][c] = c < Dh ? (second ? xout[r][d1 + c] : zs[r][c]) : cs[r][c - Dh];
+        const int ild = DI_MAX + 1 + (~DI & 1);           // in_s row stride: 33 (DI odd) or 34 (DI even)
+        for (int p = t; p < TF * DI_MAX; p += NT) {        // (every column: those >= DI are zeros -- they meet the next unit's weights in layer 1)
+            const int r = p >> 5, c = p & (DI_MAX - 1);
+            in_s[r * ild + c] = c < Dh ? (second ? xout[r][d1 + c] : zs[r][c]) : c < DI ? cs[r][c - Dh] : 0.0f;
         }
         lds_barrier();
         STAMP(1);
-        {   // layer 1 (register arrays are only ever indexed by unrolled constants: no private scratch)
-            float acc[RP];
+        {   // layer 1, [16 rows x 32 inputs] x [32 x H] as v_mfma_f32_16x16x4_f32 on LDS operands read a dword at a time; W1 stays as
+            // it lies in memory (row stride DI: a linear copy) and the inputs >= DI are zeros.  Which input a lane group takes in
+            // which of the eight MFMAs is free, and it decides the banks (lanes 0-31 = groups 0 and 1 are served together, rows n = 0 ..
+            // 15 each): DI odd -- group kk takes 8 kb + i (kb = 0, 2, 1, 3): W1 banks DI n + 16 kk + i, inputs (stride 33) n + 16 kk + i, all
+            // 32 distinct; DI even -- group kk takes 4 i + kk: W1 banks DI n + kk + 4 i, inputs (stride 34) 2 n + kk + 4 i, all distinct
+            const int n = lane & 15, kk = lane >> 4, odd = DI & 1;
+            const int k0 = odd ? 8 * (((kk & 1) << 1) | (kk >> 1)) : kk;
+            const float *ap = &in_s[n * ild + k0], *bp0 = &w1f[(UW * w + n) * DI + k0], *bp1 = &w1f[(min(UW * w + 16, H - 16) + n) * DI + k0];
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+            if (odd) {                                       // (two copies: the reads' offsets are then immediates)
 #pragma unroll
-            for (int q = 0; q < RP; ++q) acc[q] = b1v;
+                for (int i = 0; i < 8; ++i) {
+                    const float a = ap[i];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[i], acc0, 0, 0, 0);
+                    if constexpr (UW == 32) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[i], acc1, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-            for (int c0 = 0; c0 < DI_MAX; c0 += 4) {         // (columns beyond DI: a zero weight against a finite -- zeroed or old -- input)
-                if (c0 < DI) {
-                    float wv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) wv[u] = c0 + u < DI ? w1f[j * DI + c0 + u] : 0.0f;
-#pragma unroll
-                    for (int q = 0; q < RP; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&in_s[rh * RP + q][c0]);
-                        acc[q] = fmaf(wv[3], v.w, fmaf(wv[2], v.z, fmaf(wv[1], v.y, fmaf(wv[0], v.x, acc[q]))));
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    const float a = ap[4 * i];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[4 * i], acc0, 0, 0, 0);
+                    if constexpr (UW == 32) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[4 * i], acc1, 0, 0, 0);
                 }
             }
+            if (kk < TF / 4) {                               // D: unit = tile base + (l & 15), row = 4 (l >> 4) + register
+                const int u0 = UW * w + n, u1 = u0 + 16;
 #pragma unroll
-            for (int q = 0; q < RP; ++q) {
-                const int r = rh * RP + q;
-                const float v = elu(acc[q]);
-                h1r[r][j] = v;
-                if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + j] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * kk + q;
+                    const float v0 = elu(acc0[q] + b10);
+                    h1r[r][u0] = v0;
+                    if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + u0] = v0;
+                    if constexpr (UW == 32) {
+                        const float v1 = elu(acc1[q] + b11);
+                        h1r[r][u1] = v1;
+                        if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + u1] = v1;
+                    }
+                }
             }
         }
         lds_barrier();
@@ -275,12 +296,6 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
 // Every weight is staged in LDS once per half-layer (64 + 4 + 17 + 8 KB of gfx950's 160 KB): read from global memory where they
 // are used, their latency was the kernel's time (columns of W2: 10 us, W1 in the input gradient: 13 us of the original 33).
 constexpr int NTB = 1024;
-#ifndef NDDM_FWD_ROWS
-#define NDDM_FWD_ROWS 16
-#endif
-#ifndef NDDM_DGRAD_ROWS
-#define NDDM_DGRAD_ROWS 16
-#endif
 constexpr int LDT = H + 4;       // row stride of W2 TRANSPOSED in LDS, w2t[in unit][out unit]: d(h1) = d(a2) W2 sums over the OUT units, and
                                  // with the out units along a row both MFMA operands are read 16 bytes at a time (as in the forward:
                                  // the order of the sum is free, lane group k takes the k's [32 k, 32 k + 32)) instead of a dword at a
@@ -371,6 +386,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
             h1r[r][j] = ok ? nh1[k] : 0.0f;
             h2r[r][j] = ok ? nh2[k] : 0.0f;
         }
+        STAMP(15);
         if (t < TRD * Dt) {                               // through the affine transform and the soft clamp
             const int r = t / Dt, d = t - r * Dt, row = r0 + r;
             // second: the gradient of out[:, :d1]; first: of out[:, d1:] plus what came through net 2's conditioning input
@@ -385,7 +401,9 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 X.dos[(long long)row * M_MAX + Dt + d] = d_t;
             }
         }
+        STAMP(16);
         if (hl > 0) NDDM_FETCH_HALF(T.half[hl - 1]);     // (the loads' results are not waited for before the next half-layer)
+        STAMP(17);
         lds_barrier();
         STAMP(11);
         {   // d h2 -> d(pre-activation 2): thread (unit j, rows 4 g .. 4 g + 3)
@@ -657,14 +675,6 @@ __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *l
 
 using namespace nddm_train;
 
-// Developer aid: the tile shape of the two chain kernels can be switched per process (A/B on one box) -- NDDM_TRAIN_FWD_ROWS = 8 | 16,
-// NDDM_TRAIN_DGRAD_ROWS = 16 | 32; read at every call (a getenv beside two kernel launches), defaults compiled in.
-static int tile_rows(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 extern "C" {
 
 // 1 for the shapes the fused flow covers (the caller takes the PyTorch path otherwise)
@@ -699,12 +709,7 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowSaved S = {z_all, out_all, s_all, h_all};
     hipLaunchKernelGGL(warm_l2_kernel, dim3(8 * 2 * L * WARM_PARTS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, ld);
-    if (tile_rows("NDDM_TRAIN_FWD_ROWS", NDDM_FWD_ROWS) == 16)
-        hipLaunchKernelGGL((flow_fwd_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta,
-                           cond, S, ld);
-    else
-        hipLaunchKernelGGL((flow_fwd_kernel<TRF, 256>), dim3((R + TRF - 1) / TRF), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P,
-                           theta, cond, S, ld);
+    hipLaunchKernelGGL((flow_fwd_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta, cond, S, ld);
     if (nll)
         hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out_all + (long long)(L - 1) * R * D,
                            ld, R, D, nll);
@@ -746,10 +751,7 @@ int nddm_train_flow_bwd(int L, int R, int D, int d1, int C, float clamp, const v
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowBwdBuf U = {g_z, g_ld, gx, gcond, g_nll, g_ld, out_all + (long long)(L - 1) * RD};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (tile_rows("NDDM_TRAIN_DGRAD_ROWS", NDDM_DGRAD_ROWS) == 16)
-        hipLaunchKernelGGL((flow_dgrad_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, st, Q, TD, U);
-    else
-        hipLaunchKernelGGL((flow_dgrad_kernel<TR, NTB>), dim3((R + TR - 1) / TR), dim3(NTB), 0, st, Q, TD, U);
+    hipLaunchKernelGGL((flow_dgrad_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, st, Q, TD, U);
     hipLaunchKernelGGL(flow_wgrad_kernel, dim3(2 * L), dim3(NTB), 0, st, Q, TW, cond, static_cast<const float *>(g_ld));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
