@@ -70,13 +70,14 @@ template <int TF, int NT>        // rows per workgroup, threads: 8 x 256 (four C
 __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const float *theta, const float *cond, FlowSaved S, float *ld)
 {
     constexpr int UW = H / (NT / 64);          // units per wave in layer 2: 32 (two 16 x 16 tiles) or 16 (one)
-    static_assert(TF % 4 == 0 && TF <= 16 && (UW == 32 || UW == 16) && 2 * TF * M_MAX <= NT && TF * D_MAX <= NT && DI_MAX == 32, "tile shape");
+    static_assert(TF % 4 == 0 && TF <= 16 && (UW == 32 || UW == 16) && M_MAX == 16 && TF * D_MAX <= NT && DI_MAX == 32, "tile shape");
     __shared__ float in_s[16 * (DI_MAX + 2)];   // the sub-network's input rows, an MFMA operand read a dword at a time down 16 rows: row stride 33 or 34 by
                                                 // the parity of DI (see layer 1); columns >= DI zero; rows TF.. stay zero
     __shared__ __attribute__((aligned(16))) float h1r[16][LDR];        // rows TF..15 stay zero (the MFMA tile has 16 rows)
     __shared__ __attribute__((aligned(16))) float h2r[TF][LDR];
     __shared__ float o_s[TF][M_MAX];
-    __shared__ float w3s[M_MAX][H + 1];       // (+ 1: the rows' readers are lanes m)
+    __shared__ float w3s[16][H + 2];          // W3 [output][unit], rows >= M zero: an MFMA operand read a dword at a time down its 16 rows (+ 2: banks 2 n + k)
+    __shared__ float part3[NT / 64][16][16];  // layer 3's partial tiles, one per wave
     __shared__ __attribute__((aligned(16))) float w2s[H][LDR];
     __shared__ float xs[2][TF][D_MAX];       // the layer's input / output rows (alternating), zs: its permuted ActNorm output
     __shared__ float zs[TF][D_MAX], cs[TF][DI_MAX];
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
     STAMP(0);
     // one thread's share of the next half-layer's weights (plain local arrays indexed by unrolled constants: registers)
     f32x4 nw2[H * H / 4 / NT];           // (the compiler's own vector type: HIP's float4 struct kept the array in memory)
-    float nw1[H * DI_MAX / NT], nw3[M_MAX * H / NT], nb10, nb11, nb20, nb21, nb3, nsc = 0.0f, nbi = 0.0f;
+    float nw1[H * DI_MAX / NT], nw3[M_MAX * H / NT], nb10, nb11, nb20, nb21, nb3s, nb3t, nsc = 0.0f, nbi = 0.0f;
 #define NDDM_FETCH_WEIGHTS(Wn, DIn, Mn) do {                                                                                  \
         const f32x4 *src_ = reinterpret_cast<const f32x4 *>((Wn).W2);                                                         \
         _Pragma("unroll") for (int k = 0; k < H * H / 4 / NT; ++k) nw2[k] = src_[t + NT * k];                                \
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
             const int p_ = t + NT * k; const float v_ = (Wn).W3[min(p_, (Mn) * H - 1)]; nw3[k] = p_ < (Mn) * H ? v_ : 0.0f; } \
         nb10 = (Wn).b1[UW * w + (lane & 15)]; nb11 = (Wn).b1[min(UW * w + 16, H - 16) + (lane & 15)];                                \
         nb20 = (Wn).b2[UW * w + (lane & 15)]; nb21 = (Wn).b2[min(UW * w + 16, H - 16) + (lane & 15)];                     \
-        nb3 = (Wn).b3[(t >> 1) % (Mn)];                                                                                         \
+        {   const int Dt_ = (Mn) / 2, d_ = t % Dt_; nb3s = (Wn).b3[d_]; nb3t = (Wn).b3[Dt_ + d_]; }    /* thread (row t / Dt, column t % Dt) of the affine phase */ \
     } while (0)
     NDDM_FETCH_WEIGHTS(P.layer[0].a, d1 + Q.C, 2 * d2);
     if (t < TF * D) { const int p = P.perm[0][t % D]; nsc = P.layer[0].scale[p]; nbi = P.layer[0].bias[p]; }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
         for (int k = 0; k < M_MAX * H / NT; ++k) { const int p = t + NT * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
 #pragma unroll
         for (int k = 0; k < H * DI_MAX / NT; ++k) w1f[t + NT * k] = nw1[k];    // (entries beyond H * DI: copies of the last one, finite)
-        const float b10 = nb10, b11 = nb11, b20 = nb20, b21 = nb21, b3v = nb3, scv = nsc, biv = nbi;
+        const float b10 = nb10, b11 = nb11, b20 = nb20, b21 = nb21, b3s = nb3s, b3t = nb3t, scv = nsc, biv = nbi;
         STAMP(7);
         if (hl + 1 < 2 * Q.L) {                              // ... and the next one's into the registers
             const HalfP &Wn = second ? P.layer[l + 1].a : Y.b;
@@ -255,22 +256,28 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
         }
         lds_barrier();
         STAMP(3);
-        for (int p = t; p < 2 * TF * M; p += NT) {      // layer 3: two threads (adjacent lanes) per output, half the units each
-            const int pr = p >> 1, half = p & 1, r = pr / M, m = pr - r * M;
-            float acc = half ? 0.0f : b3v;                   // (one pass: 2 TF M <= NT threads)
-#pragma unroll 8
-            for (int i = half * (H / 2); i < (half + 1) * (H / 2); ++i) acc = fmaf(w3s[m][i], h2r[r][i], acc);
-            acc += __shfl_xor(acc, 1);
-            if (!half) o_s[r][m] = acc;
+        {   // layer 3, [16 rows x H] x [H x 16 outputs] as MFMAs with the H units split over the waves (16 each: four MFMAs, lane group
+            // kk takes the units 16 w + 4 i + kk); the waves' partial tiles are summed, in fixed order, by the affine phase's threads
+            constexpr int KW = H / (NT / 64);
+            const int n = lane & 15, kk = lane >> 4;
+            const float *ap = &h2r[n][KW * w + kk], *bp = &w3s[n][KW * w + kk];
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < KW / 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bp[4 * i], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part3[w][4 * kk + q][n] = acc[q];      // D: output = l & 15, row = 4 (l >> 4) + register
         }
         lds_barrier();
         STAMP(4);
-        if (t < TF * Dt) {                                  // soft clamp + affine transform
+        if (t < TF * Dt) {                                  // the outputs' sums, soft clamp + affine transform
             const int r = t / Dt, d = t - r * Dt, row = r0 + r;
-            const float sv = Q.clamp * tanhf(o_s[r][d] / Q.clamp);
-            const float yv = fmaf(second ? zs[r][d] : zs[r][d1 + d], expf(sv), o_s[r][Dt + d]);
+            float os = b3s, ot = b3t;
+#pragma unroll
+            for (int v = 0; v < NT / 64; ++v) { os += part3[v][r][d]; ot += part3[v][r][Dt + d]; }
+            const float sv = Q.clamp * tanhf(os / Q.clamp);
+            const float yv = fmaf(second ? zs[r][d] : zs[r][d1 + d], expf(sv), ot);
             xout[r][second ? d : d1 + d] = yv;
-            o_s[r][d] = sv;                                  // (its reader, this thread, is done with it)
+            o_s[r][d] = sv;                                  // (for the rows' log|det| below)
             if (row < Q.R) {
                 sl[(long long)row * D + d] = sv;
                 out_g[(long long)row * D + (second ? d : d1 + d)] = yv;
