@@ -335,10 +335,10 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     __shared__ __attribute__((aligned(16))) float h1r[TRD][LDR];        // [row][unit]
     __shared__ __attribute__((aligned(16))) float h2r[TRD][LDR];        // later: d(pre-activation 1)
     __shared__ __attribute__((aligned(16))) float da2r[TRD][LDR];       // d(pre-activation 2); later: partial tiles of the input gradient
-    __shared__ float do_s[TRD][M_MAX];
+    __shared__ float do_s[TRD][M_MAX + 1];      // d(outputs): an MFMA operand read a dword at a time down the rows (+ 1: banks)
     __shared__ __attribute__((aligned(16))) float w2t[H][LDT];
-    __shared__ float w1s[H][DI_MAX + 1];
-    __shared__ float w3s[M_MAX][H];
+    __shared__ float w1f[H * DI_MAX + DI_MAX];  // W1 as it lies in memory, [unit][DI] (+ DI_MAX: the last units' reads past their rows)
+    __shared__ float w3s[M_MAX][H + 16];        // W3 [output][unit], rows >= M zero (+ 16: lane groups 0 and 1 read rows m, m + 1: banks 16 apart)
     __shared__ float gout_s[TRD][D_MAX], gz_s[TRD][D_MAX], gy2_s[TRD][D_MAX], gcond_s[TRD][DI_MAX];
     const int t = threadIdx.x, j = t & (H - 1), g = t >> 7, lane = t & 63, wave = t >> 6, D = Q.D, d1 = Q.d1, d2 = D - d1;
     const int r0 = blockIdx.x * TRD;
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
     }
     if (U.g_nll && t < TRD && r0 + t < Q.R) U.w_gld[r0 + t] = gld_sc;
     for (int p = t; p < TRD * DI_MAX; p += NTD) (&gcond_s[0][0])[p] = 0.0f;
+    for (int p = t; p < TRD * (M_MAX + 1); p += NTD) (&do_s[0][0])[p] = 0.0f;      // (columns >= M are never written: they meet zero rows of w3s)
     // one thread's share of the next half-layer's operands
     f32x4 nw2[H * H / 4 / NTD];       // thread (in unit j, g): out units 4 (g + G k4) .. + 3 of column j
     float nw1[H * DI_MAX / NTD], nw3[M_MAX * H / NTD], nh1[TRD * H / NTD], nh2[TRD * H / NTD], ns = 0.0f, nx = 0.0f, ngl = 0.0f;
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
             const float *w_ = (X).W2 + (long long)(4 * (g + G * k4)) * H + j;                                                    \
             nw2[k4] = f32x4{w_[0], w_[H], w_[2 * H], w_[3 * H]}; }                                                              \
         _Pragma("unroll") for (int k = 0; k < H * DI_MAX / NTD; ++k) nw1[k] = (X).W1[min(t + NTD * k, H * DIn_ - 1)];          \
-        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTD; ++k) nw3[k] = (X).W3[min(t + NTD * k, Mn_ * H - 1)];            \
+        _Pragma("unroll") for (int k = 0; k < M_MAX * H / NTD; ++k) {                                                          \
+            const int p_ = t + NTD * k; const float v_ = (X).W3[min(p_, Mn_ * H - 1)]; nw3[k] = p_ < Mn_ * H ? v_ : 0.0f; }      \
         _Pragma("unroll") for (int k = 0; k < TRD * H / NTD; ++k) {                                                             \
             const long long o_ = (long long)min(r0 + g + G * k, Q.R - 1) * H + j;                                              \
             nh1[k] = (X).h1[o_]; nh2[k] = (X).h2[o_];                                                                          \
@@ -380,12 +382,9 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
 #pragma unroll
         for (int k4 = 0; k4 < H * H / 4 / NTD; ++k4) *reinterpret_cast<f32x4 *>(&w2t[j][4 * (g + G * k4)]) = nw2[k4];
 #pragma unroll
-        for (int k = 0; k < H * DI_MAX / NTD; ++k) {
-            const int p = t + NTD * k, jj = p / DI;
-            if (p < H * DI) w1s[jj][p - jj * DI] = nw1[k];
-        }
+        for (int k = 0; k < H * DI_MAX / NTD; ++k) w1f[t + NTD * k] = nw1[k];      // (a linear copy; entries beyond H * DI: copies of the last one)
 #pragma unroll
-        for (int k = 0; k < M_MAX * H / NTD; ++k) (&w3s[0][0])[t + NTD * k] = nw3[k];
+        for (int k = 0; k < M_MAX * H / NTD; ++k) { const int p = t + NTD * k; w3s[p >> 7][p & (H - 1)] = nw3[k]; }
 #pragma unroll
         for (int k = 0; k < TRD * H / NTD; ++k) {         // saved activations (rows beyond R: zero)
             const int r = g + G * k;
@@ -413,20 +412,19 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         STAMP(17);
         lds_barrier();
         STAMP(11);
-        {   // d h2 -> d(pre-activation 2): thread (unit j, rows 4 g .. 4 g + 3)
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
-            for (int m = 0; m < M; ++m) {
-                const float w = w3s[m][j];
+        {   // d h2 = d(outputs) W3 -> d(pre-activation 2), [TRD x 16] x [16 x H] as MFMAs (outputs >= M: zero rows of w3s): wave ->
+            // (row block, 16 units), lane group kk takes the outputs 4 i + kk
+            const int n = lane & 15, kk = lane >> 4, rb = wave >> 3, ib = wave & 7;
+            const float *ap = &do_s[16 * rb + n][kk], *bp = &w3s[kk][16 * ib + n];
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, do_s[4 * g + q][m], acc[q]);
-            }
+            for (int i = 0; i < M_MAX / 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bp[4 * i * (H + 16)], acc, 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * g + q;
-                const float v = acc[q] * elu_grad_from_out(h2r[r][j]);
-                da2r[r][j] = v;
-                if (r0 + r < Q.R) X.da2[(long long)(r0 + r) * H + j] = v;
+            for (int q = 0; q < 4; ++q) {                    // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register
+                const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
+                const float v = acc[q] * elu_grad_from_out(h2r[r][i]);
+                da2r[r][i] = v;
+                if (r0 + r < Q.R) X.da2[(long long)(r0 + r) * H + i] = v;
             }
         }
         lds_barrier();
@@ -464,17 +462,17 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         STAMP(13);
         {   // d in = d(a1) W1, [TRD x DI] with k over the H units: wave -> (row block, column block, a quarter of the k's), 8 MFMAs;
             // the four partial tiles are summed through LDS in fixed order.  Lane l: A[row l & 15][k], B[k][column l & 15] for
-            // k = 32 q + 8 (l >> 4) + s, s = 0 .. 7.  (Columns >= DI of w1s are never written: they only reach columns >= DI.)
+            // k = 32 q + 8 (l >> 4) + s, s = 0 .. 7.  (Columns >= DI read the next unit's weights: they only reach columns >= DI of the result, which nobody reads.)
             constexpr int RB = TRD / 16;
             const int n = lane & 15, kk = lane >> 4, rb = wave % RB, cb = (wave / RB) & 1, q = wave / (2 * RB);
             float (*part)[TRD][DI_MAX + 1] = reinterpret_cast<float (*)[TRD][DI_MAX + 1]>(&da2r[0][0]);    // (da2r's readers are done)
             if (16 * cb < DI) {
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float *ap = &h2r[16 * rb + n][32 * q + 8 * kk], *bp = &w1s[32 * q + 8 * kk][16 * cb + n];
+                const float *ap = &h2r[16 * rb + n][32 * q + 8 * kk], *bp = &w1f[(32 * q + 8 * kk) * DI + 16 * cb + n];
                 const float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = *reinterpret_cast<const float4 *>(ap + 4);
                 const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int s_ = 0; s_ < 8; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], bp[s_ * (DI_MAX + 1)], acc, 0, 0, 0);
+                for (int s_ = 0; s_ < 8; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], bp[s_ * DI], acc, 0, 0, 0);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) part[q][16 * rb + 4 * kk + v][16 * cb + n] = acc[v];
             }
