@@ -17,7 +17,6 @@
 // gfx950 only.  tests/test_gpu_training.py compares with the PyTorch composition.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 namespace nddm_train {
 
@@ -41,17 +40,19 @@ __device__ __forceinline__ float elu(float v) { return v > 0.0f ? v : expm1f(v);
 __device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }   // alpha = 1
 
 // ------------------------------------------------------------------------------------------------ forward
-// grid = ceil(R / TRF) workgroups of 256 threads over tiles of TRF = 8 rows (four workgroups at batch 32: the work is latency,
-// not arithmetic, so it is spread), each taking its rows through every layer.  What a row carries from half-layer to half-layer
-// (the permuted ActNorm output z, the layer's output, the condition) stays in LDS; global memory only receives what the
-// backward needs.  Layers 1 and 3 are plain FMAs (thread t: hidden unit j = t % 128, row half rh = t / 128); layer 2, the
-// 128 x 128 product, is v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain) on operands read from LDS with 16-byte loads
-// (the order of the sum is free: lane group k takes the k's [32 k, 32 k + 32) of both operands).  The NEXT half-layer's weights
-// are fetched into registers at the top of a half-layer and written to LDS once their buffers' last readers are done: a
-// half-layer is a chain of five short phases, and a cold load at the head of each was 3.3 of its 8.4 microseconds.
+// grid = ceil(R / 16) workgroups of 512 threads over tiles of 16 rows (two workgroups at batch 32: every product then fills the
+// 16 rows of an MFMA tile, and a SIMD holds two waves -- one wave's LDS reads and epilogue run under the other's MFMAs; four
+// workgroups of 8 rows x 256 threads were 11 % slower, one of 32 x 1024 more), each taking its rows through every layer.  What a
+// row carries from half-layer to half-layer (the permuted ActNorm output z, the layer's output, the condition) stays in LDS;
+// global memory only receives what the backward needs.  All three layers are v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered
+// fmaf chain) on LDS operands: layer 2, the 128 x 128 product, with 16-byte reads (one 16 x 16 tile per wave); layer 1 (K = the
+// <= 32 inputs, zero-padded) and layer 3 (K = the 128 units split over the waves, partial tiles summed by the affine phase) with
+// dword reads.  Which k a lane group takes in which MFMA is free (the instruction sums over the four groups) and is chosen per
+// operand so that the lanes an LDS instruction serves together fall on different banks.  The NEXT half-layer's weights are
+// fetched into registers at the top of a half-layer and written to LDS once their buffers' last readers are done: a half-layer
+// is a chain of short phases, and a cold load at the head of each was 3.3 of its 8.4 microseconds (now 5.2 in all).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TRF = 8, RPT = TRF / 2;
 constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2 in LDS: 16-byte aligned rows whose operand reads
                                 // (16 rows x 4 column groups per wave instruction) spread evenly over the banks
 // A barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the thread has in flight
@@ -296,7 +297,9 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
 
 // ------------------------------------------------------------------------------------------------ backward
 // Two kernels.  (1) The chain of ACTIVATION gradients, half-layers last to first -- the critical path: every row is independent,
-// so workgroup w takes rows [32 w, 32 w + 32) through all of it (1024 threads; d(h1) = d(a2) W2 is v_mfma_f32_16x16x4_f32 on LDS
+// so workgroup w takes rows [16 w, 16 w + 16) through all of it (512 threads, two workgroups at batch 32: as one workgroup of
+// 32 rows x 1024 threads the 128 x 128 product ran four waves per SIMD deep on ONE CU's matrix pipe and the kernel took 72.6 us
+// against 57; every product -- d(h2) = d(out) W3, d(h1) = d(a2) W2, d(in) = d(a1) W1 -- is v_mfma_f32_16x16x4_f32 on LDS
 // operands) and leaves d(pre-activation 1, 2) and d(output) of every half-layer in global memory.  (2) The WEIGHT gradients of all
 // half-layers at once, one workgroup per half-layer (dW2 = d(a2)^T h1 as v_mfma_f32_32x32x2_f32, a 32 x 32 tile per wave): they
 // are off the critical path, and as one kernel with (1) they were 60 % of a half-layer's 19 microseconds.
@@ -638,25 +641,6 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
     }
 }
 
-// Pull every weight of the flow into every XCD's L2 before the forward kernel walks them: in the training loop the optimizer has
-// just rewritten them (through other L2s), and the forward's once-per-half-layer staging loads -- latency the kernel cannot
-// hide -- then went to memory: 137 us in the loop against 100 us back to back.  Workgroup b: XCD b % 8 (workgroups are dealt
-// round-robin over the eight XCDs), a quarter of one half-layer's matrices.
-constexpr int WARM_PARTS = 4;
-__global__ __launch_bounds__(256) void warm_l2_kernel(FlowDims Q, FlowP P, float *sink)
-{
-    const int rest = blockIdx.x / 8, hl = rest % (2 * Q.L), part = rest / (2 * Q.L), t = threadIdx.x;      // one memory latency each
-    const HalfP &W = (hl & 1) ? P.layer[hl >> 1].b : P.layer[hl >> 1].a;
-    const int Dh = (hl & 1) ? Q.D - Q.d1 : Q.d1, Dt = Q.D - Dh;
-    const int n2 = H * H / 4 / WARM_PARTS, n1 = H * (Dh + Q.C) / WARM_PARTS, n3 = 2 * Dt * H / WARM_PARTS;
-    const float4 *w2 = reinterpret_cast<const float4 *>(W.W2) + part * n2;
-    float acc = 0.0f;
-    for (int i = t; i < n2; i += 256) { const float4 v = w2[i]; acc += v.x + v.w; }
-    for (int i = t; i < n1; i += 256) acc += W.W1[part * n1 + i];
-    for (int i = t; i < n3; i += 256) acc += W.W3[part * n3 + i];
-    if (acc == 1.2345e-33f) *sink = acc;                     // (never: keeps the loads)
-}
-
 // mean over the rows of |z|^2 / 2 - log|det| (fixed summation order)
 __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *ld, int R, int D, float *out)
 {
@@ -713,7 +697,6 @@ int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const v
     fill(P, L, D, params, perm);
     const FlowDims Q = {L, R, D, d1, C, clamp};
     const FlowSaved S = {z_all, out_all, s_all, h_all};
-    hipLaunchKernelGGL(warm_l2_kernel, dim3(8 * 2 * L * WARM_PARTS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Q, P, ld);
     hipLaunchKernelGGL((flow_fwd_kernel<16, 512>), dim3((R + 15) / 16), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), Q, P, theta, cond, S, ld);
     if (nll)
         hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out_all + (long long)(L - 1) * R * D,
