@@ -325,7 +325,7 @@ def test_classic_trainer_call_shape_runs_as_graph_replays(tmp_path):
 def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
     """Integrity soak of the pipelined loop (tests/train_soak_worker.py): learning rate 0, so the loss of iteration k depends on
     batch k alone -- 1200 online + 400 experience-replay iterations at dt=.001 (a 200 us simulate launch beside every training
-    graph) in the one-rank form, with the all-gather (RCCL, world 1) and with the gradient all-reduce: the pipelined history
+    graph) in the one-rank form (both models), with the all-gather (RCCL, world 1) and with the gradient all-reduce: the pipelined history
     equals the sequential loop's at EVERY iteration, and the random stream ends at the same position."""
     import json
     import os
@@ -339,7 +339,7 @@ def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
                        timeout=1200, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    for name in ("one rank", "gather", "ddp"):
+    for name in ("one rank", "gather", "ddp", "one rank, single-trial model"):
         o = out[name]
         assert o["iterations"] == 1600 and o["finite"] and o["offsets_equal"], (name, o)
         assert o["n_mismatch"] == 0, (name, o)

@@ -26,14 +26,15 @@ def main():
 
         def run(overlap, **kw):
             torch.manual_seed(0)
-            am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+            am = AmortizedPosterior(InvertibleNetwork(num_params=7 if kw.get("model") == "single" else 5), InvariantNetwork())
             with GraphTrainer(am, batch_size=32, total_steps=n_online + n_replay, seed=2023, learning_rate=0.0, dt=0.001, max_steps=4000.0,
                               overlap=overlap, **kw) as gt:
                 gt.train_online(n_online)
                 gt.train_experience_replay(n_replay, capacity_in_batches=16)
                 return np.array(gt.loss_history()), int(gt.offset.item())
 
-        for name, kw in (("one rank", dict()), ("gather", dict(split=True, parallel="gather")), ("ddp", dict(split=True, parallel="ddp"))):
+        for name, kw in (("one rank", dict()), ("gather", dict(split=True, parallel="gather")), ("ddp", dict(split=True, parallel="ddp")),
+                         ("one rank, single-trial model", dict(model="single"))):
             (hp, op), (hs, os_) = run(True, **kw), run(False, **kw)
             d = np.abs(hp - hs)
             out[name] = {"iterations": int(len(hp)), "max_abs_diff": float(d.max()), "n_mismatch": int((d > 1e-5 * (1 + np.abs(hs))).sum()),
