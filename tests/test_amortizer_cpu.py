@@ -64,6 +64,14 @@ def test_trainer_loops_reduce_loss_and_checkpoint(tmp_path):
     assert am.sample(conf(gm(3)), 50).shape == (3, 50, 2)
     rho = posterior_recovery(am, gm, conf, n_datasets=40, n_samples=100)
     assert rho[0] > 0.7                                                  # the mean parameter is recovered
+    # the median form, and what both are computed from: one pass, rows aligned; a single wild posterior mean (a tail draw the
+    # inverse flow amplifies) moves the means' correlation, not the medians'
+    from bayesflow_nddms_amd.amortizer import posterior_estimates
+    assert posterior_recovery(am, gm, conf, n_datasets=40, n_samples=100, statistic="median")[0] > 0.7
+    true, means, meds = posterior_estimates(am, gm, conf, n_datasets=30, n_samples=100)
+    assert true.shape == means.shape == meds.shape == (30, 2) and np.corrcoef(means[:, 0], meds[:, 0])[0, 1] > 0.95
+    with pytest.raises(ValueError):
+        posterior_recovery(am, gm, conf, n_datasets=2, n_samples=10, statistic="mode")
     am2 = AmortizedPosterior(InvertibleNetwork(num_params=2, cond_dim=11, num_coupling_layers=3, hidden=32), InvariantNetwork(hidden=32))
     tr2 = Trainer(am2, gm, conf, checkpoint_path=str(tmp_path / "ckpt"), device="cpu")
     assert tr2.load_pretrained_network()
