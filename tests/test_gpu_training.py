@@ -376,7 +376,7 @@ def test_fused_flow_equals_the_pytorch_path():
     from bayesflow_nddms_amd.amortizer import InvertibleNetwork
     assert _train_lib.lib() is not None, "libnddm_train.so did not build / load"
     torch.manual_seed(3)
-    for layers, R, D in ((1, 32, 5), (1, 5, 5), (2, 77, 5), (6, 256, 5), (6, 32, 8), (3, 40, 2), (6, 32, 7), (2, 19, 3), (2, 33, 4), (2, 16, 6)):
+    for layers, R, D in ((1, 32, 5), (1, 5, 5), (2, 77, 5), (6, 256, 5), (6, 32, 8), (3, 40, 2), (6, 32, 7), (2, 19, 3), (2, 33, 4), (2, 16, 6), (1, 1, 5), (2, 4001, 5)):
         net = InvertibleNetwork(num_params=D, num_coupling_layers=layers, seed=layers).cuda()
         with torch.no_grad():
             for p in net.parameters():                   # larger weights than the initialisation, ActNorms away from identity
