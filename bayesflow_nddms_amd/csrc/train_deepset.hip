@@ -961,22 +961,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-// out[p] = sum over g of part[g][p], g in fixed order; entries p >= P_main were written by the first G_tail rows only
-__global__ void reduce_partials_kernel(const float *part, int G, int P, int P_main, int G_tail, float *out)
+// out[p] = sum over g of part[g][p], g in fixed order; entries p >= P_main were written by the first G_tail rows only.
+// A workgroup takes 64 columns; wave q sums the rows g = q (mod 4) of its columns (eight loads in flight per lane) -- the four sums
+// a_q the one-thread-per-column form kept in four accumulators -- and wave 0 adds them as that form did: (a0 + a1) + (a2 + a3), the
+// rows past the last whole group of four going to a0.  Same bits, four times the workgroups and a quarter of the dependent chain.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, int G, int P, int P_main, int G_tail, float *out)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    if (p >= P_main) G = G_tail;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        a0 += part[(long long)g * P + p];
-        a1 += part[(long long)(g + 1) * P + p];
-        a2 += part[(long long)(g + 2) * P + p];
-        a3 += part[(long long)(g + 3) * P + p];
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6, p = blockIdx.x * 64 + c, pc = min(p, P - 1);
+    if (pc >= P_main) G = G_tail;
+    const int G4 = G & ~3;
+    const float *src = part + pc;
+    float a = 0.0f;
+    int g = q;
+    for (; g + 28 < G4; g += 32) {                       // eight rows of this wave's residue class: the loads first, then the adds in order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(long long)(g + 4 * k) * P];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += v[k];
     }
-    for (; g < G; ++g) a0 += part[(long long)g * P + p];
-    out[p] = (a0 + a1) + (a2 + a3);
+    for (; g < G4; g += 4) a += src[(long long)g * P];
+    if (q == 0) for (g = G4; g < G; ++g) a += src[(long long)g * P];
+    red[q][c] = a;
+    __syncthreads();
+    if (q == 0 && p < P) out[p] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 }  // namespace nddm_deepset
@@ -1087,7 +1096,7 @@ int nddm_deepset_mlp2_bwd(const float *x, int d_in, int B, int N, int S, int row
 int nddm_deepset_reduce(const float *part, int G, int P, int P_main, int G_tail, float *out, void *stream)
 {
     if (G <= 0 || P <= 0 || P_main < 0 || P_main > P || G_tail < 0 || G_tail > G) return 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, G, P, P_main,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, G, P, P_main,
                        G_tail, out);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
