@@ -3,7 +3,9 @@
 amortizer -> trainer.train_experience_replay), with the simulator on the MI355X and a PyTorch-ROCm amortizer.
 
 Single GPU:   python examples/train_basic_ddm_dc.py --iterations 500
-              python examples/train_basic_ddm_dc.py --iterations 5000 --graph      (one hipGraph replay per iteration: ~4x faster)
+              python examples/train_basic_ddm_dc.py --iterations 5000 --graph      (one hipGraph replay per iteration: ~8x faster)
+              python examples/train_basic_ddm_dc.py --iterations 5000 --trainer-graph   (the same through the reference's call shape:
+                                                                                      amortizer.Trainer(..., graph=True).train_experience_replay(...))
 Multi GPU:    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_basic_ddm_dc.py --sharded
               (each rank simulates batch/G parameter sets; one RCCL all-gather reassembles the minibatch on every rank)
 """
@@ -28,6 +30,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--sharded", action="store_true")
     ap.add_argument("--graph", action="store_true", help="graph_trainer.GraphTrainer: the whole iteration as one hipGraph replay")
+    ap.add_argument("--trainer-graph", action="store_true", help="amortizer.Trainer(graph=True): the classic call shape, run as graph replays")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--max-steps", type=float, default=400.0)
     a = ap.parse_args()
@@ -69,7 +72,7 @@ def main():
         generative_model = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False,
                                                               dt=a.dt, max_steps=a.max_steps)
     amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
-    trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None)
+    trainer = Trainer(amortizer, generative_model, basic_ddm_dc.configurator, checkpoint_path=None, graph=a.trainer_graph and not a.sharded)
     t0 = time.time()
     res = trainer.train_experience_replay(epochs=1, iterations_per_epoch=a.iterations, batch_size=a.batch_size,
                                           save_checkpoint=False)
