@@ -153,6 +153,26 @@ __device__ __forceinline__ float mask_of(const Common &C, int n)
     return !C.mask ? 1.0f : (C.mask_is_count ? (n < *C.mask ? 1.0f : 0.0f) : C.mask[n]);
 }
 
+// mask_of(n) for a row that may lie beyond the set (-> 0): no branch around the load
+__device__ __forceinline__ float mask_or_zero(const Common &C, int n, int n_end)
+{
+    const float mk = !C.mask ? 1.0f : (C.mask_is_count ? (n < *C.mask ? 1.0f : 0.0f) : C.mask[min(n, n_end - 1)]);
+    return n < n_end ? mk : 0.0f;
+}
+
+// A tile of rows of a row-major [., 64] global array as a RAW BUFFER whose size is the tile's valid rows: a store (load) to a row beyond
+// them is dropped (returns 0) by the hardware's range check -- no `if (row < n_end)` around each of an epilogue's 16 stores, which
+// compiled to a branch, an exec save / restore and a 64-bit address computation per store (~1000 cycles of a 4500-cycle phase).
+struct RowTile {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ RowTile(const float *tile_base, int n_rows)
+        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile_base), 0, (n_rows > 0 ? n_rows : 0) * HS * 4, 0x00020000)) {}
+    __device__ __forceinline__ void put(int row, int col, float v) const
+    { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (row * HS + col) * 4, 0, 0); }
+    __device__ __forceinline__ float get(int row, int col) const
+    { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * HS + col) * 4, 0, 0)); }
+};
+
 // the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled
 __device__ __forceinline__ void context(const Common &C, int b, float *pooled, float *cs, int t)
 {
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
             __syncthreads();
         }
         STAMP(102);
+        const RowTile th1(O.h1 + (row0 + n0) * HS, n_end - n0), th2(O.h2 + (row0 + n0) * HS, n_end - n0);
         if (BIG) {                                   // layer 1
             const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
 #pragma unroll
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 const int r = 32 * rb + drow(v, kk);
                 const float val = fmaxf(acc[v] + bias1, 0.0f);
                 h1s[r][u] = val;
-                if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + u] = val;
+                th1.put(r, u, val);
             }
         } else {                                     // thread (unit t & 63, rows 16 (t >> 6) ...)
             const int uu = t & 63, rg = t >> 6;
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) a = fmaf(w[c], xsmall[r][c], a);
                 const float val = fmaxf(a, 0.0f);
                 h1s[r][uu] = val;
-                if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
+                th1.put(r, uu, val);
             }
         }
         if (n0 == n_begin) store64(w2s, r2, t);      // (its first reader is layer 2, behind the barrier)
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
                 const int r = 32 * rb + drow(v, kk);
                 const float val = fmaxf(acc[v] + bias2, 0.0f);
                 h2s[r][u] = val;
-                if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
+                th2.put(r, u, val);
             }
         }
         if (n0 == n_begin) store64(w3s, r3, t, C.d_out);
@@ -299,16 +320,20 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(Common C, FwdOut O)
         STAMP(104);
         {                                            // layer 3 (no activation), and the masked sums of its output
             const f32x16 acc = mma64<1, 1>(&h2s[32 * rb + m][32 * kk], &w3s[u][32 * kk], zero16());
+            // (branch-free: y as a raw buffer of the tile's valid rows -- of NO rows if y is not wanted -- whose range check drops the
+            //  stores of the other rows; a lane whose column is not written aims past the buffer; the pooled sum takes a zero mask)
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(O.y ? O.y + (row0 + n0) * O.ldy : O.h1, 0,
+                                                                                  O.y ? (n_end - n0) * O.ldy * 4 : 0, 0x00020000);
+            const bool colv = u < C.d_out, cole = O.extra && !colv && u < C.d_out + O.n_extra;
+            const int ue = min(max(u - C.d_out, 0), max(O.n_extra - 1, 0));
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int n = n0 + 32 * rb + drow(v, kk);
-                if (n < n_end && u < C.d_out) {
-                    const float val = acc[v] + bias3;
-                    if (O.y) O.y[(row0 + n) * O.ldy + u] = val;
-                    if (O.pool_part) pacc = fmaf(mask_of(C, n), val, pacc);
-                } else if (O.extra && n < n_end && u < C.d_out + O.n_extra) {
-                    O.y[(row0 + n) * O.ldy + u] = O.extra[(row0 + n) * O.extra_stride + (u - C.d_out)];
-                }
+                const int r = 32 * rb + drow(v, kk), n = n0 + r;
+                const float val = acc[v] + bias3;
+                if (O.pool_part) pacc = fmaf(colv ? mask_or_zero(C, n, n_end) : 0.0f, val, pacc);
+                float outv = val;
+                if (O.extra) { const float e = O.extra[(row0 + min(n, n_end - 1)) * O.extra_stride + ue]; outv = cole ? e : val; }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv), ry, (colv || cole) ? (r * O.ldy + u) * 4 : 0x7ffffff0, 0, 0);
             }
         }
         STAMP(105);
@@ -383,6 +408,9 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
     const int u = 32 * ub + m;                       // this lane's column of every result tile
     const float bias2 = C.P.b2[u], bias3 = C.P.b3[u], bias1 = cs[u];
     const float c1 = P2.b1[u], c2 = P2.b2[u], c3 = P2.b3[u];
+    const int nv = n_end - n0;                       // the tile's valid rows: stores beyond them are dropped by the buffers' range check
+    const RowTile th1(O.h1 + (row0 + n0) * HS, nv), th2(O.h2 + (row0 + n0) * HS, nv), ty(O.y + (row0 + n0) * HS, nv);
+    const RowTile tg1(O2.h1 + (row0 + n0) * HS, nv), tg2(O2.h2 + (row0 + n0) * HS, nv);
     // ---- MLP A
     if (BIG) {
         const f32x16 acc = mma64<1, 1>(&xs[32 * rb + m][32 * kk], &w1s[u][32 * kk], zero16());
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             const int r = 32 * rb + drow(v, kk);
             const float val = fmaxf(acc[v] + bias1, 0.0f);
             h1s[r][u] = val;
-            if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + u] = val;
+            th1.put(r, u, val);
         }
     } else {
         const int uu = t & 63, rg = t >> 6;
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             for (int c = 0; c < DS_MAX; ++c) if (c < C.d_in) a = fmaf(w[c], xsmall[r][c], a);
             const float val = fmaxf(a, 0.0f);
             h1s[r][uu] = val;
-            if (n0 + r < n_end) O.h1[(row0 + n0 + r) * HS + uu] = val;
+            th1.put(r, uu, val);
         }
     }
     store64(w2s, r2, t);
@@ -419,7 +447,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             const int r = 32 * rb + drow(v, kk);
             const float val = fmaxf(acc[v] + bias2, 0.0f);
             h2s[r][u] = val;
-            if (n0 + r < n_end) O.h2[(row0 + n0 + r) * HS + u] = val;
+            th2.put(r, u, val);
         }
     }
     store64(w3s, r3, t);
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             const int r = 32 * rb + drow(v, kk), n = n0 + r;
             const float val = n < n_end ? acc[v] + bias3 : 0.0f;          // (rows beyond the set: zero, as a loaded tile has them)
             xs[r][u] = val;                                               // (xs: A's layer 1 finished reading it two barriers ago)
-            if (n < n_end) O.y[(row0 + n) * HS + u] = val;
+            ty.put(r, u, val);
         }
     }
     __syncthreads();                                 // A's readers of w1s / w2s / w3s / h1s / h2s are done; xs is complete
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             const int r = 32 * rb + drow(v, kk);
             const float val = fmaxf(acc[v] + c1, 0.0f);
             h1s[r][u] = val;
-            if (n0 + r < n_end) O2.h1[(row0 + n0 + r) * HS + u] = val;
+            tg1.put(r, u, val);
         }
     }
     __syncthreads();
@@ -458,7 +486,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
             const int r = 32 * rb + drow(v, kk);
             const float val = fmaxf(acc[v] + c2, 0.0f);
             h2s[r][u] = val;
-            if (n0 + r < n_end) O2.h2[(row0 + n0 + r) * HS + u] = val;
+            tg2.put(r, u, val);
         }
     }
     __syncthreads();
@@ -468,7 +496,7 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int n = n0 + 32 * rb + drow(v, kk);
-            if (n < n_end) pacc = fmaf(mask_of(C, n), acc[v] + c3, pacc);
+            pacc = fmaf(mask_or_zero(C, n, n_end), acc[v] + c3, pacc);
         }
     }
     red[wave][lane] = pacc;                          // fixed-order sum of the four lanes that share a column (as mlp_fwd_kernel)
