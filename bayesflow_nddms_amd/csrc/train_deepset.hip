@@ -667,13 +667,11 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
             aW1 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &xs[32 * kk][u], aW1);
             if (Q.gx) {
                 const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+                const RowTile tgx(Q.gx + (row0 + n0) * HS, n_end - n0);      // (rows beyond the set: the range check drops them)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int n = n0 + 32 * rb + drow(v, kk);
-                    if (n < n_end) {
-                        float *o = Q.gx + (row0 + n) * HS + u;
-                        *o = Q.gx_acc ? *o + acc[v] : acc[v];
-                    }
+                    const int r = 32 * rb + drow(v, kk);
+                    tgx.put(r, u, Q.gx_acc ? tgx.get(r, u) + acc[v] : acc[v]);
                 }
             }
         } else {
@@ -872,12 +870,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         aW1 = mma64<LD, LD>(&gs[32 * kk][32 * rb + m], &xs[32 * kk][u], zero16());
         {   // X's input gradient (+ the other consumer's) = Y's output gradient: into d2s (its readers finished before the barrier above)
             const f32x16 acc = mma64<1, LD>(&gs[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+            const RowTile tprev(Q.gx_prev ? Q.gx_prev + (row0 + n0) * HS : Q.h1y, Q.gx_prev ? n_end - n0 : 0);   // (no such gradient: a buffer of no rows reads zeros)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int r = 32 * rb + drow(v, kk), n = n0 + r;
-                float g = 0.0f;
-                if (n < n_end) g = Q.gx_prev ? Q.gx_prev[(row0 + n) * HS + u] + acc[v] : acc[v];
-                d2s[r][u] = g;
+                const float g = tprev.get(r, u) + acc[v];
+                d2s[r][u] = n < n_end ? g : 0.0f;
             }
         }
         float *wp = Q.wpart_x + (long long)blockIdx.x * Q.ld_part;
@@ -940,10 +938,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             aW1 = mma64<LD, LD>(&d2s[32 * kk][32 * rb + m], &xs[32 * kk][u], zero16());
             if (Q.gx) {
                 const f32x16 acc = mma64<1, LD>(&d2s[32 * rb + m][32 * kk], &w1s[32 * kk][u], zero16());
+                const RowTile tgx(Q.gx + (row0 + n0) * HS, n_end - n0);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int n = n0 + 32 * rb + drow(v, kk);
-                    if (n < n_end) Q.gx[(row0 + n) * HS + u] = acc[v];
+                    tgx.put(32 * rb + drow(v, kk), u, acc[v]);
                 }
             }
         } else {
