@@ -131,14 +131,35 @@ __device__ __forceinline__ void store64(float (*dst)[LD], const f32x4 (&v)[HS * 
     }
 }
 
+// sum over s = 0 .. S - 1 of p[s * stride], added in that order -- with the loads of eight terms in flight at a time: as a plain loop
+// (the trip count is a kernel argument) every term waited for its own round trip to L2, 5 x ~0.6 us at the head of a kernel
+__device__ __forceinline__ float sum_in_order(const float *p, int S, long long stride)
+{
+    float a = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(long long)min(s0 + k, S - 1) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += s0 + k < S ? v[k] : 0.0f;
+    }
+    return a;
+}
+
 // four columns of row `row` of the input of a 64-wide MLP: loaded, or (x_part) the mean of the pooled partial sums
 __device__ __forceinline__ float4 x_row4(const Common &C, long long row, int c4, float inv_n)
 {
     if (!C.x_part) return *reinterpret_cast<const float4 *>(C.x + row * HS + 4 * c4);
     float4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < C.S_x; ++s) {
-        const float4 v = *reinterpret_cast<const float4 *>(C.x_part + (row * C.S_x + s) * HS + 4 * c4);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int s0 = 0; s0 < C.S_x; s0 += 8) {          // (eight partial rows in flight, added in order: see sum_in_order)
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(C.x_part + (row * C.S_x + min(s0 + k, C.S_x - 1)) * HS + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float f = s0 + k < C.S_x ? 1.0f : 0.0f;
+            a.x += f * v[k].x; a.y += f * v[k].y; a.z += f * v[k].z; a.w += f * v[k].w;
+        }
     }
     a.x *= inv_n; a.y *= inv_n; a.z *= inv_n; a.w *= inv_n;
     return a;
@@ -178,8 +199,7 @@ __device__ __forceinline__ void context(const Common &C, int b, float *pooled, f
 {
     if (C.ctx_part) {
         if (t < HS) {
-            float a = 0.0f;
-            for (int s = 0; s < C.S_ctx; ++s) a += C.ctx_part[((long long)b * C.S_ctx + s) * HS + t];
+            const float a = sum_in_order(C.ctx_part + (long long)b * C.S_ctx * HS + t, C.S_ctx, HS);
             pooled[t] = a * inv_count(C);
         }
         __syncthreads();
@@ -586,9 +606,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
         if (Q.gp_W) {
             if (t < HS) {
-                float a = 0.0f;
-                for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
-                dsum[t] = a;
+                dsum[t] = sum_in_order(Q.gpool + (long long)b * Q.gp_S * HS + t, Q.gp_S, HS);
             }
             __syncthreads();
             {   // four threads per unit, 16 independent loads each
@@ -808,9 +826,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     context(C, b, pooled, cs, t);                    // Y's pooled context (for the context columns' weight gradient)
     if (Q.gp_W) {                                    // the gradient of X's pooled output, per unit of this set
         if (t < HS) {
-            float a = 0.0f;
-            for (int s = 0; s < Q.gp_S; ++s) a += Q.gpool[((long long)b * Q.gp_S + s) * HS + t];
-            dsum[t] = a;
+            dsum[t] = sum_in_order(Q.gpool + (long long)b * Q.gp_S * HS + t, Q.gp_S, HS);
         }
         __syncthreads();
         const int k = t >> 2, q = t & 3;
