@@ -194,26 +194,50 @@ struct RowTile {
     { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * HS + col) * 4, 0, 0)); }
 };
 
-// the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled
-__device__ __forceinline__ void context(const Common &C, int b, float *pooled, float *cs, int t)
+// the set's pooled context: pooled[k] = inv_n * sum over the producer's workgroups; cs[u] = b1[u] + W1[u][d_in + .] . pooled.
+// In two halves: every load first -- the partial sums AND this thread's 16 context-column weights (thread (unit t / 4, quarter t % 4)),
+// which do not depend on the sums but stood behind the barrier that publishes them: one round trip to L2 instead of two -- then the
+// LDS hand-over and the product.
+struct CtxLoad { float sum, b1; float w[16]; };
+__device__ __forceinline__ void context_issue(const Common &C, int b, int t, CtxLoad &L)
 {
+    L.sum = 0.0f;
     if (C.ctx_part) {
-        if (t < HS) {
-            const float a = sum_in_order(C.ctx_part + (long long)b * C.S_ctx * HS + t, C.S_ctx, HS);
-            pooled[t] = a * inv_count(C);
-        }
-        __syncthreads();
         const int u = t >> 2, q = t & 3;
         const float *w = C.P.W1 + (long long)u * C.P.ldw1 + C.d_in + 16 * q;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) L.w[k] = w[k];
+        L.b1 = C.P.b1[u];
+        if (t < HS) L.sum = sum_in_order(C.ctx_part + (long long)b * C.S_ctx * HS + t, C.S_ctx, HS);
+    } else {
+        L.b1 = C.P.b1[t & (HS - 1)];
+    }
+}
+__device__ __forceinline__ void context_publish(const Common &C, float *pooled, int t, const CtxLoad &L)
+{
+    if (C.ctx_part && t < HS) pooled[t] = L.sum * inv_count(C);
+}
+__device__ __forceinline__ void context_product(const Common &C, const float *pooled, float *cs, int t, const CtxLoad &L)   // (behind a barrier)
+{
+    if (C.ctx_part) {
+        const int u = t >> 2, q = t & 3;
         float a = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a = fmaf(w[k], pooled[16 * q + k], a);
+        for (int k = 0; k < 16; ++k) a = fmaf(L.w[k], pooled[16 * q + k], a);
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
-        if (q == 0) cs[u] = a + C.P.b1[u];
+        if (q == 0) cs[u] = a + L.b1;
     } else if (t < HS) {
-        cs[t] = C.P.b1[t];
+        cs[t] = L.b1;
     }
+}
+__device__ __forceinline__ void context(const Common &C, int b, float *pooled, float *cs, int t)
+{
+    CtxLoad L;
+    context_issue(C, b, t, L);
+    context_publish(C, pooled, t, L);
+    if (C.ctx_part) __syncthreads();
+    context_product(C, pooled, cs, t, L);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -528,6 +552,27 @@ __global__ __launch_bounds__(NT) void mlp2_fwd_kernel(Common C, FwdOut O, Mlp P2
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// The gradient of a pooled output per unit of the set, gp[k] = inv_n * sum_i gp_W[i][k] * (sum over the consumer's workgroups of gpool[.][i]),
+// in the same two halves as the context: the partial sums and this thread's 16 weights (thread (unit t / 4, quarter t % 4)) in one round trip.
+struct GpLoad { float sum; float w[16]; };
+__device__ __forceinline__ void gp_issue(const float *gpool, int gp_S, const float *gp_W, int gp_ldw, int b, int t, GpLoad &L)
+{
+    const int k = t >> 2, q = t & 3;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L.w[i] = gp_W[(long long)(16 * q + i) * gp_ldw + k];
+    L.sum = t < HS ? sum_in_order(gpool + (long long)b * gp_S * HS + t, gp_S, HS) : 0.0f;
+}
+__device__ __forceinline__ void gp_product(const float *dsum, float *gp, float inv_n, int t, const GpLoad &L)      // (behind a barrier)
+{
+    const int k = t >> 2, q = t & 3;
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a = fmaf(L.w[i], dsum[16 * q + i], a);
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (q == 0) gp[k] = a * inv_n;
+}
+
 struct BwdIO {
     const float *h1, *h2;            // saved by the forward
     const float *gy; int ldgy;       // [B * N, ldgy] gradient of the output (columns [0, d_out)), or null
@@ -592,6 +637,13 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
                 xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
             }
     };
+    // the small loads that feed the context and the pooled gradient go FIRST (loads return in issue order): they are back while the
+    // tiles and the weights are still on their way
+    CtxLoad Lc;
+    GpLoad Lg;
+    const bool gpw = Q.gpool && Q.gp_W;
+    context_issue(C, b, t, Lc);
+    if (gpw) gp_issue(Q.gpool, Q.gp_S, Q.gp_W, Q.gp_ldw, b, t, Lg);
     {   // every weight load in flight before the first store (three stage64 calls in a row waited for three load latencies in turn)
         f32x4 r1[HS * HS / 4 / NT], r2[HS * HS / 4 / NT], r3[HS * HS / 4 / NT];
         fetch64(r3, C.P.W3, HS, t, C.d_out);
@@ -602,26 +654,12 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
         store64(w2s, r2, t);
         if (BIG && Q.gx) store64(w1s, r1, t);
     }
-    context(C, b, pooled, cs, t);                    // (pooled: for the context columns' weight gradient)
-    if (Q.gpool) {                                   // gradient of the pooled output, per unit of this set
-        if (Q.gp_W) {
-            if (t < HS) {
-                dsum[t] = sum_in_order(Q.gpool + (long long)b * Q.gp_S * HS + t, Q.gp_S, HS);
-            }
-            __syncthreads();
-            {   // four threads per unit, 16 independent loads each
-                const int k = t >> 2, q = t & 3;
-                float a = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a = fmaf(Q.gp_W[(long long)(16 * q + i) * Q.gp_ldw + k], dsum[16 * q + i], a);
-                a += __shfl_xor(a, 1);
-                a += __shfl_xor(a, 2);
-                if (q == 0) gp[k] = a * inv_n;
-            }
-        } else if (t < HS) {
-            gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
-        }
-    }
+    context_publish(C, pooled, t, Lc);               // (pooled: also for the context columns' weight gradient)
+    if (gpw && t < HS) dsum[t] = Lg.sum;
+    __syncthreads();
+    context_product(C, pooled, cs, t, Lc);
+    if (gpw) gp_product(dsum, gp, inv_n, t, Lg);     // gradient of the pooled output, per unit of this set
+    else if (Q.gpool && t < HS) gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
     __syncthreads();
     const int u = 32 * ub + m;
     f32x16 aW1 = zero16(), aW2 = zero16(), aW3 = zero16();
@@ -781,6 +819,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const long long row0 = (long long)b * C.N;
     const float inv_n = inv_count(C);
     const int u = 32 * ub + m, uu = t & 63, rg = t >> 6;
+    // ---- Y's pooled context and the gradient of X's pooled output, per unit of this set: their loads go out FIRST and are consumed
+    //      before the operand fetches below are issued (this kernel has no registers left to hold both) -- behind those fetches,
+    //      in issue order, they cost four round trips at the head of the kernel
+    {
+        CtxLoad Lc;
+        GpLoad Lg;
+        context_issue(C, b, t, Lc);
+        if (Q.gp_W) gp_issue(Q.gpool, Q.gp_S, Q.gp_W, Q.gp_ldw, b, t, Lg);
+        context_publish(C, pooled, t, Lc);
+        if (Q.gp_W && t < HS) dsum[t] = Lg.sum;
+        __syncthreads();
+        context_product(C, pooled, cs, t, Lc);
+        if (Q.gp_W) gp_product(dsum, gp, inv_n, t, Lg);
+        else if (t < HS) gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
+    }
     // ---- every global load up front, in the order of need.  X: h2 and W3 (layer 3 runs first), then h1 and W2, then the input tile
     //      and W1; they are stored to LDS just before the phase that reads them (behind the barriers that are there anyway), so
     //      one load latency is exposed instead of one per operand.  Y's operands follow and stay in registers until X is done.
@@ -823,22 +876,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int r = p / C.d_in, c = p - r * C.d_in, n = n0 + r;
             xsmall[r][c] = n < n_end ? C.x[(row0 + n) * C.d_in + c] : 0.0f;
         }
-    context(C, b, pooled, cs, t);                    // Y's pooled context (for the context columns' weight gradient)
-    if (Q.gp_W) {                                    // the gradient of X's pooled output, per unit of this set
-        if (t < HS) {
-            dsum[t] = sum_in_order(Q.gpool + (long long)b * Q.gp_S * HS + t, Q.gp_S, HS);
-        }
-        __syncthreads();
-        const int k = t >> 2, q = t & 3;
-        float a = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a = fmaf(Q.gp_W[(long long)(16 * q + i) * Q.gp_ldw + k], dsum[16 * q + i], a);
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        if (q == 0) gp[k] = a * inv_n;
-    } else if (t < HS) {
-        gp[t] = Q.gpool[(long long)b * HS + t] * inv_n;
-    }
+    // (Y's pooled context and the gradient of X's pooled output were computed at the head of the kernel: see there)
     store_tile(h2s, xh2);
     store64(w3s, xw3, t);
     __syncthreads();
