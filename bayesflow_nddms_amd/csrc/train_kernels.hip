@@ -60,6 +60,17 @@ constexpr int LDR = H + 4;      // row stride of the [row][unit] tiles and of W2
 // this kernel reads global memory that the kernel wrote.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The rows [r0, r0 + rows) of a row-major global array as a RAW BUFFER of just their size: a store to a row beyond them (the rows of
+// a tile past R) is dropped by the hardware's range check -- the `if (r0 + r < R)` around every one of a phase's stores compiled
+// to a branch, an exec save / restore and a 64-bit address each.
+struct RowBuf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ RowBuf(float *first_row, int rows, int ld)
+        : r(__builtin_amdgcn_make_buffer_rsrc(first_row, 0, (rows > 0 ? rows : 0) * ld * 4, 0x00020000)) {}
+    __device__ __forceinline__ void put(int off_floats, float v) const
+    { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off_floats * 4, 0, 0); }
+};
+
 constexpr int L_MAX = 8, D_MAX = 8;
 struct HalfP { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 struct LayerP { const float *scale, *bias; HalfP a, b; };
@@ -118,6 +129,8 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
         float *z_g = S.z_all + l * RD, *out_g = S.out_all + l * RD, *sl = S.s_all + l * RD + (second ? d2 : 0), *h = S.h_all + 4 * l * RH;
         float *h1_out = h + (second ? 2 : 0) * RH, *h2_out = h + (second ? 3 : 1) * RH;
         float (*xin)[D_MAX] = xs[l & 1], (*xout)[D_MAX] = xs[(l & 1) ^ 1];
+        const int nvr = Q.R - r0;                            // the tile's valid rows: stores beyond them are dropped by the buffers' range check
+        const RowBuf bh1(h1_out + (long long)r0 * H, nvr, H), bh2(h2_out + (long long)r0 * H, nvr, H), bz(z_g + (long long)r0 * D, nvr, D);
         // this half-layer's weights: out of the registers (fetched a half-layer ago) into LDS / this thread's W1 row
         lds_barrier();                                     // (the previous half-layer's readers of w2s, w3s, xs are done)
 #pragma unroll
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
                 const int r = t / D, c = t - r * D, p = P.perm[l][c];
                 const float v = fmaf(xin[r][p], expf(scv), biv);
                 zs[r][c] = v;
-                if (r0 + r < Q.R) z_g[(long long)(r0 + r) * D + c] = v;
+                bz.put(r * D + c, v);
             }
             if (t < TF) {
 #pragma unroll
@@ -188,11 +201,11 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
                     const int r = 4 * kk + q;
                     const float v0 = elu(acc0[q] + b10);
                     h1r[r][u0] = v0;
-                    if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + u0] = v0;
+                    bh1.put(r * H + u0, v0);
                     if constexpr (UW == 32) {
                         const float v1 = elu(acc1[q] + b11);
                         h1r[r][u1] = v1;
-                        if (r0 + r < Q.R) h1_out[(long long)(r0 + r) * H + u1] = v1;
+                        bh1.put(r * H + u1, v1);
                     }
                 }
             }
@@ -246,11 +259,11 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
                     const int r = 4 * kk + q;
                     const float v0 = elu(acc0[q] + b20);
                     h2r[r][u0] = v0;
-                    if (r0 + r < Q.R) h2_out[(long long)(r0 + r) * H + u0] = v0;
+                    bh2.put(r * H + u0, v0);
                     if constexpr (UW == 32) {
                         const float v1 = elu(acc1[q] + b21);
                         h2r[r][u1] = v1;
-                        if (r0 + r < Q.R) h2_out[(long long)(r0 + r) * H + u1] = v1;
+                        bh2.put(r * H + u1, v1);
                     }
                 }
             }
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
         const HalfD &X = T.half[hl];
         const bool second = hl & 1;
         const int DI = X.Dh + Q.C, M = 2 * X.Dt, Dt = X.Dt;
+        const RowBuf bda2(X.da2 + (long long)r0 * H, Q.R - r0, H), bda1(X.da1 + (long long)r0 * H, Q.R - r0, H);
         lds_barrier();                    // the previous half-layer's readers are done
         STAMP(10);
 #pragma unroll
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
                 const float v = acc[q] * elu_grad_from_out(h2r[r][i]);
                 da2r[r][i] = v;
-                if (r0 + r < Q.R) X.da2[(long long)(r0 + r) * H + i] = v;
+                bda2.put(r * H + i, v);
             }
         }
         lds_barrier();
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
                 const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
                 const float v = acc[q] * elu_grad_from_out(h1r[r][i]);
                 h2r[r][i] = v;
-                if (r0 + r < Q.R) X.da1[(long long)(r0 + r) * H + i] = v;
+                bda1.put(r * H + i, v);
             }
         }
         lds_barrier();
