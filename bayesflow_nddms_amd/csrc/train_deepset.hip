@@ -190,6 +190,7 @@ struct RowTile {
         : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile_base), 0, (n_rows > 0 ? n_rows : 0) * HS * 4, 0x00020000)) {}
     __device__ __forceinline__ void put(int row, int col, float v) const
     { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (row * HS + col) * 4, 0, 0); }
+    // (dword accesses only: this toolchain compiles __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load -- y, z, w read as zero)
     __device__ __forceinline__ float get(int row, int col) const
     { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * HS + col) * 4, 0, 0)); }
 };
@@ -743,11 +744,12 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     // ---- this workgroup's partial sums
     float *wp = Q.wpart + (long long)blockIdx.x * Q.ld_part;
     const int ld1 = C.P.ldw1, oW1 = 0, ob1 = HS * ld1, oW2 = ob1 + HS, ob2 = oW2 + HS * HS, oW3 = ob2 + HS, ob3 = oW3 + C.d_out * HS;
+    const RowTile tw3(wp + oW3, C.d_out);
 #pragma unroll
     for (int v = 0; v < 16; ++v) {                   // tile (rb, ub): row = unit out, column = unit in
         const int r = 32 * rb + drow(v, kk);
         wp[oW2 + r * HS + u] = aW2[v];
-        if (r < C.d_out) wp[oW3 + r * HS + u] = aW3[v];
+        tw3.put(r, u, aW3[v]);                       // (rows >= d_out: dropped)
         if (BIG) wp[oW1 + r * ld1 + u] = aW1[v];
     }
 #pragma unroll
