@@ -607,30 +607,40 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(Common C, BwdIO Q)
     const float inv_n = inv_count(C);
     STAMP(200);
     auto load_tile = [&](const int n0) {             // saved activations, input and output gradient (the pooled part: added below)
+        // every load unconditional, from a clamped row (rows beyond the set are zeroed at the store), and ALL of them issued before
+        // the first store: inside `if (n < n_end)` each of the four passes was a branch and a round trip to L2 of its own
+        // (f32x4, the compiler's own vector type: arrays of HIP's float4 struct are kept in memory)
+        f32x4 v1[TM * HS / 4 / NT], v2[TM * HS / 4 / NT], vg[TM * HS / 4 / NT], vx[TM * HS / 4 / NT];
+        const bool gy_dense = C.d_out == HS && Q.ldgy == HS;
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < TM * HS / 4 / NT; ++k) {
-            const int p = t + NT * k, r = p >> 4, c4 = p & 15, n = n0 + r;
-            float4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = v1, vg = v1, vx = v1;
-            if (n < n_end) {
-                const long long o = (row0 + n) * HS + 4 * c4;
-                v1 = *reinterpret_cast<const float4 *>(Q.h1 + o);
-                v2 = *reinterpret_cast<const float4 *>(Q.h2 + o);
-                if (Q.gy) {
-                    if (C.d_out == HS && Q.ldgy == HS) vg = *reinterpret_cast<const float4 *>(Q.gy + o);
-                    else {
-                        const float *gr = Q.gy + (row0 + n) * Q.ldgy;
-                        vg.x = 4 * c4 < C.d_out ? gr[4 * c4] : 0.0f;
-                        vg.y = 4 * c4 + 1 < C.d_out ? gr[4 * c4 + 1] : 0.0f;
-                        vg.z = 4 * c4 + 2 < C.d_out ? gr[4 * c4 + 2] : 0.0f;
-                        vg.w = 4 * c4 + 3 < C.d_out ? gr[4 * c4 + 3] : 0.0f;
-                    }
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            const long long row = row0 + min(n0 + r, n_end - 1), o = row * HS + 4 * c4;
+            v1[k] = *reinterpret_cast<const f32x4 *>(Q.h1 + o);
+            v2[k] = *reinterpret_cast<const f32x4 *>(Q.h2 + o);
+            vg[k] = z;
+            vx[k] = z;
+            if (Q.gy) {
+                if (gy_dense) vg[k] = *reinterpret_cast<const f32x4 *>(Q.gy + o);
+                else {                               // a narrow output (the summary): columns < d_out, rows ldgy floats apart
+                    const float *gr = Q.gy + row * Q.ldgy;
+                    const int cl = C.d_out - 1;
+                    const float a0 = gr[min(4 * c4, cl)], a1 = gr[min(4 * c4 + 1, cl)], a2 = gr[min(4 * c4 + 2, cl)], a3 = gr[min(4 * c4 + 3, cl)];
+                    vg[k] = f32x4{4 * c4 < C.d_out ? a0 : 0.0f, 4 * c4 + 1 < C.d_out ? a1 : 0.0f, 4 * c4 + 2 < C.d_out ? a2 : 0.0f,
+                                  4 * c4 + 3 < C.d_out ? a3 : 0.0f};
                 }
-                if (BIG) vx = x_row4(C, row0 + n, c4, inv_n);
             }
-            *reinterpret_cast<float4 *>(&h1s[r][4 * c4]) = v1;
-            *reinterpret_cast<float4 *>(&h2s[r][4 * c4]) = v2;
-            *reinterpret_cast<float4 *>(&gs[r][4 * c4]) = vg;
-            if (BIG) *reinterpret_cast<float4 *>(&xs[r][4 * c4]) = vx;
+            if (BIG) { const float4 xv = x_row4(C, row, c4, inv_n); vx[k] = f32x4{xv.x, xv.y, xv.z, xv.w}; }
+        }
+#pragma unroll
+        for (int k = 0; k < TM * HS / 4 / NT; ++k) {
+            const int p = t + NT * k, r = p >> 4, c4 = p & 15;
+            const bool ok = n0 + r < n_end;
+            *reinterpret_cast<f32x4 *>(&h1s[r][4 * c4]) = ok ? v1[k] : z;
+            *reinterpret_cast<f32x4 *>(&h2s[r][4 * c4]) = ok ? v2[k] : z;
+            *reinterpret_cast<f32x4 *>(&gs[r][4 * c4]) = ok ? vg[k] : z;
+            if (BIG) *reinterpret_cast<f32x4 *>(&xs[r][4 * c4]) = ok ? vx[k] : z;
         }
         if (!BIG)
             for (int p = t; p < TM * C.d_in; p += NT) {

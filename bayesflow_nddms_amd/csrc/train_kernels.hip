@@ -556,26 +556,33 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
     for (int q = 0; q < M_MAX / 8; ++q) dW3[q] = 0.0f;
     for (int r0 = 0; r0 < Q.R; r0 += TR) {
         if (r0) __syncthreads();          // the previous tile's readers are done
-        for (int p = t; p < TR * DI; p += NTB) {
-            const int r = p / DI, c = p - r * DI, row = r0 + r;
-            float v = 0.0f;
-            if (row < Q.R) v = c < X.Dh ? X.xh[(long long)row * D + c] : cond[(long long)row * Q.C + (c - X.Dh)];
-            in_s[r][c] = v;
+        // every load unconditional, from a clamped row, ALL of them issued before the first is used (a guarded load -- `ok ? p[o] : 0`
+        // -- is a branch and a wait of its own: the 18 loads of this prologue were ten round trips in a row, most of the kernel)
+        float v1[TR * H / NTB], v2[TR * H / NTB], v3[TR * H / NTB], v4[TR * H / NTB];
+#pragma unroll
+        for (int k = 0; k < TR * H / NTB; ++k) {
+            const long long o = (long long)min(r0 + g + 8 * k, Q.R - 1) * H + j;
+            v1[k] = X.h1[o]; v2[k] = X.h2[o]; v3[k] = X.da2[o]; v4[k] = X.da1[o];
         }
+        float vin = 0.0f, vdo = 0.0f;
+        {
+            const int r = t / DI, c = t - r * DI, row = min(r0 + min(r, TR - 1), Q.R - 1);     // (TR * DI <= NTB: one element per thread)
+            const float a = X.xh[(long long)row * D + min(c, X.Dh - 1)], b = cond[(long long)row * Q.C + min(max(c - X.Dh, 0), Q.C - 1)];
+            vin = c < X.Dh ? a : b;
+            const int r2 = t / M_MAX, m2 = t - r2 * M_MAX;
+            vdo = X.dos[(long long)min(r0 + min(r2, TR - 1), Q.R - 1) * M_MAX + m2];
+        }
+        if (t < TR * DI) { const int r = t / DI, c = t - r * DI; in_s[r][c] = r0 + r < Q.R ? vin : 0.0f; }
 #pragma unroll
         for (int k = 0; k < TR * H / NTB; ++k) {         // (rows beyond R: zero)
-            const int r = g + 8 * k, row = r0 + r;
-            const bool ok = row < Q.R;
-            const long long o = (long long)row * H + j;
-            h1r[r][j] = ok ? X.h1[o] : 0.0f;
-            h2r[r][j] = ok ? X.h2[o] : 0.0f;
-            da2r[r][j] = ok ? X.da2[o] : 0.0f;
-            da1r[r][j] = ok ? X.da1[o] : 0.0f;
+            const int r = g + 8 * k;
+            const bool ok = r0 + r < Q.R;
+            h1r[r][j] = ok ? v1[k] : 0.0f;
+            h2r[r][j] = ok ? v2[k] : 0.0f;
+            da2r[r][j] = ok ? v3[k] : 0.0f;
+            da1r[r][j] = ok ? v4[k] : 0.0f;
         }
-        for (int p = t; p < TR * M_MAX; p += NTB) {
-            const int r = p / M_MAX, m = p - r * M_MAX, row = r0 + r;
-            do_s[r][m] = (row < Q.R && m < M) ? X.dos[(long long)row * M_MAX + m] : 0.0f;
-        }
+        if (t < TR * M_MAX) { const int r = t / M_MAX, m = t - r * M_MAX; do_s[r][m] = (r0 + r < Q.R && m < M) ? vdo : 0.0f; }
         __syncthreads();
         // layer 3: thread (column j, rows m = g, g + 8)
 #pragma unroll
