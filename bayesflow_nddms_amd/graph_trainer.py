@@ -33,7 +33,7 @@ stays on the critical path, between its two graphs.  Replicas are made identical
 
 PyTorch is plumbing here (autograd nodes, the caching allocator, graphs): the simulator is the library's, and so -- where
 libnddm_train.so builds -- are the networks' forward / backward (amortizer.py) and the optimizer step on flat buffers
-(csrc/train_update.hip): 21 kernels and 0.33 ms per iteration of batch 32 on one MI355X.  Parity with BayesFlow's networks
+(csrc/train_update.hip): 21 kernels and 0.31 ms per iteration of batch 32 on one MI355X.  Parity with BayesFlow's networks
 is unpinned as for amortizer.py.
 """
 import math
