@@ -39,6 +39,15 @@ __device__ __forceinline__ float cosine_lr(const Hyper &H, float step_f)
     return 0.5f * H.lr0 * (1.0f + cosf(fminf(step_f, total) * (float)(M_PI / (double)total)));
 }
 
+// beta^n for an integer step count by repeated squaring (~2 log2 n double multiplications: the library's pow() is several hundred
+// instructions, twice, on one thread of every workgroup while the other 255 wait)
+__device__ __forceinline__ double ipow(double b, long long n)
+{
+    double r = 1.0;
+    for (; n > 0; n >>= 1) { if (n & 1) r *= b; b *= b; }
+    return r;
+}
+
 // (the counters of the step -- loss into the history, the rate that was used, step_i / step_f -- are advanced by the LAST workgroup
 // to finish: every workgroup has read them by then; `ticket` is a device word that is zero between launches)
 __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, float4 *m, float4 *v, long long n4, const float *partial,
@@ -56,8 +65,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(float4 *p, const float4 *g, fl
     if (threadIdx.x == 0) {
         const float gn = H.grad_scale * sqrtf(red[0]);                      // the norm of the (rank-averaged) gradient
         const float coef = fminf(H.clip / (gn + 1e-6f), 1.0f);              // torch.nn.utils.clip_grad_norm_
-        const double step = (double)(*step_i + 1);
-        const double bc1 = 1.0 - pow((double)H.beta1, step), bc2 = 1.0 - pow((double)H.beta2, step);
+        const double bc1 = 1.0 - ipow((double)H.beta1, *step_i + 1), bc2 = 1.0 - ipow((double)H.beta2, *step_i + 1);
         sh[0] = H.grad_scale * coef;
         sh[1] = (float)((double)cosine_lr(H, *step_f) / bc1);               // step size
         sh[2] = (float)sqrt(bc2);
