@@ -15,8 +15,9 @@ What makes the iteration capturable:
   * the random stream moves WITHOUT new kernel arguments: the simulator and the prior sampler add a 64-bit offset they
     read from device memory when they run (include/nddm.h: nddm_simulate_indirect / nddm_draw_prior_indirect), and the
     graph itself advances that word;
-  * N varies per batch (basic_ddm_dc.py:50-52, 131): it is BUCKETED -- 16 buckets over 60..300, one graph per bucket,
-    captured lazily -- the batch is simulated with the bucket's top number of trials and the summary network pools over
+  * N varies per batch (basic_ddm_dc.py:50-52, 131): it is BUCKETED -- 8 buckets over 60..300 (16 were 2.5 % slower: a graph that
+    has not been replayed for a while starts slower, and the padding costs the summary network's kernels nothing -- their time
+    is a workgroup's latency, not the number of workgroups), one graph per bucket, captured lazily -- the batch is simulated with the bucket's top number of trials and the summary network pools over
     the first N only (mask + 1/N from a device scalar), which equals pooling the unpadded batch: trial i of a set is the
     same function of (seed, set, i) whatever the launch's n_trials;
   * the loss is written to a device buffer indexed by the device-side step counter and read back when training ends (or on
@@ -62,7 +63,7 @@ class _Bucket:
 
 
 class GraphTrainer:
-    def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=16, dt=0.01,
+    def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=8, dt=0.01,
                  max_steps=400.0, seed=2023, learning_rate=5e-4, clip=5.0, device=None, use_graph=True,
                  world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic", overlap=True):
         """total_steps: length of the cosine schedule (past it the rate holds the schedule's final value) and size of the
