@@ -99,27 +99,37 @@ def train_source_hash():
     return h.hexdigest()
 
 
+def train_is_stale():
+    """True when libnddm_train.so is missing or was built from other source content than the one recorded beside it."""
+    stamp = TRAIN_SO_PATH + ".srchash"
+    try:
+        with open(stamp) as f:
+            return not os.path.exists(TRAIN_SO_PATH) or f.read().strip() != train_source_hash()
+    except OSError:
+        return True
+
+
 def build_train(force=False, verbose=False):
     """Compile the amortizer's kernels for gfx950; stale = other source content than the one recorded beside the library."""
-    stamp = TRAIN_SO_PATH + ".srchash"
-    fresh = os.path.exists(TRAIN_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == train_source_hash()
-    if fresh and not force:
+    if not force and not train_is_stale():
         return TRAIN_SO_PATH
     import fcntl
+    # several ranks may import a stale tree at once: one compiles, the others wait for the lock and then find the library fresh
     with open(TRAIN_SO_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        tmp = f"{TRAIN_SO_PATH}.{os.getpid()}.tmp"
-        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + TRAIN_SOURCES
-        if verbose:
-            print(" ".join(cmd))
-        try:
-            subprocess.check_call(cmd)
-            os.replace(tmp, TRAIN_SO_PATH)
-            with open(stamp, "w") as f:
-                f.write(train_source_hash())
-        finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
+        if force or train_is_stale():
+            tmp = f"{TRAIN_SO_PATH}.{os.getpid()}.tmp"
+            cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + TRAIN_SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, TRAIN_SO_PATH)
+                with open(TRAIN_SO_PATH + ".srchash", "w") as f:
+                    f.write(train_source_hash())
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return TRAIN_SO_PATH
 
 

@@ -246,8 +246,11 @@ static GraphArena *find_arena_locked(uint64_t id)
 static void free_list(GraphAlloc *list)
 {
     if (!list) return;
-    int cur = -1;
-    (void)hipGetDevice(&cur);
+    // blocks of another device are freed with that device current; the CALLER's current device is put back afterwards (a later
+    // nddm_* call or allocation on this thread must not land on the last block's GPU)
+    int entry = -1, cur = -1;
+    (void)hipGetDevice(&entry);
+    cur = entry;
     hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     while (list) {
@@ -258,6 +261,7 @@ static void free_list(GraphAlloc *list)
         list = n;
     }
     (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (entry >= 0 && cur != entry) (void)hipSetDevice(entry);
 }
 
 static char *graph_alloc(int dev, size_t bytes, hipError_t *err)

@@ -34,14 +34,22 @@ def all_gather_rows(local, n_sets, group=None):
     if pad:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
     local = local.contiguous()
-    full = local.new_empty((world * per,) + tuple(local.shape[1:]))
-    try:
-        dist.all_gather_into_tensor(full, local, group=group)
-    except (RuntimeError, NotImplementedError):      # backends without the flat form
+    # The collective's form is chosen by the BACKEND, never by catching an error: a failed RCCL collective (a shape mismatch between
+    # ranks, a broken communicator) must surface as its own message, not be followed by a second collective on the same communicator.
+    if flat_all_gather(dist.get_backend(group)):
+        full = local.new_empty((world * per,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(full, local, group=group)     # one RCCL all-gather into one tensor
+    else:
         parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local, group=group)
+        dist.all_gather(parts, local, group=group)                # gloo (the CPU rehearsal): the list form
         full = torch.cat(parts, dim=0)
     return full[:n_sets]
+
+
+def flat_all_gather(backend):
+    """True for the backends that implement all_gather_into_tensor (nccl = RCCL on ROCm); gloo -- the CPU rehearsal of the
+    multi-rank path -- has the list form only."""
+    return "nccl" in str(backend).lower()          # ("nccl", or a per-device map such as "cpu:gloo,cuda:nccl")
 
 
 class ShardedSimulator:

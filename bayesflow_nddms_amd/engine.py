@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory and streams); all arithmetic happens in 
 There is no CPU path: calls raise if no ROCm device / HIP library is available.
 """
 import math
+import os
 import threading
 
 import numpy as np
@@ -263,19 +264,41 @@ def draw_prior_device(model, batch_size, seed=0, set_offset=0, gamma=1.0, device
 
 
 PINNED_FROM_BYTES = 1 << 20
+# NDDM_PINNED_RESULTS=0 (or engine.PINNED_RESULTS = False): results come back in ordinary pageable memory (`.cpu()`), for callers
+# that KEEP many large results -- see to_host()
+PINNED_RESULTS = os.environ.get("NDDM_PINNED_RESULTS", "1") not in ("0", "false", "no")
 
 
-def to_host(t):
+def _pinned(pinned):
+    return PINNED_RESULTS if pinned is None else bool(pinned)
+
+
+def release_pinned_cache():
+    """Hand the pinned host blocks of results that were dropped back to the OS (PyTorch caches them for reuse otherwise)."""
+    torch = _torch()
+    fn = getattr(torch._C, "_host_emptyCache", None)
+    if fn is not None:
+        fn()
+        return True
+    return False
+
+
+def to_host(t, pinned=None):
     """Device tensor -> NumPy array (what the adapters' `as_numpy` forms return).  A result of a megabyte or more goes through
     PINNED host memory: the copy then runs at the link's rate (53 GB/s measured on the MI355X box against 6.4 GB/s into pageable
     memory -- 2.4 GB of trials in 45 ms instead of 380, `profiles/r4_pcie_rate.txt`).  The array owns its block (it returns to
-    PyTorch's pinned-memory cache when the array is dropped)."""
+    PyTorch's pinned-memory cache when the array is dropped).
+
+    What that costs: PyTorch's pinned allocator rounds a block up to a power of two (the 2.4 GB headline result pins 4 GB) and
+    keeps dropped blocks cached, so a caller that holds on to MANY large results (imputation loops, generate_data) can run out of
+    lockable memory where `.cpu()` would not.  `pinned=False` / NDDM_PINNED_RESULTS=0 selects the pageable path;
+    release_pinned_cache() returns the cached blocks of dropped results to the OS."""
     torch = _torch()
     if not isinstance(t, torch.Tensor):
         return np.asarray(t)
     if not t.is_cuda:
         return t.numpy()
-    if t.numel() * t.element_size() < PINNED_FROM_BYTES:
+    if t.numel() * t.element_size() < PINNED_FROM_BYTES or not _pinned(pinned):
         return t.cpu().numpy()
     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     h.copy_(t)
@@ -286,9 +309,10 @@ HOST_CHUNK_BYTES = 128 << 20
 
 
 def simulate_to_host(model, params, n_trials, seed=None, set_offset=None, stream_state=None, bounds=None, want_trials=True,
-                     want_summary=True, want_ext=False, device=None, chunk_bytes=None, **kw):
+                     want_summary=True, want_ext=False, device=None, chunk_bytes=None, pinned=None, **kw):
     """simulate() for a caller who wants NumPy arrays back (the adapters' `as_numpy` forms): {'trials', 'summary', 'ext'} as
-    float32 arrays in pinned host memory, plus 'seed' / 'set_offset'.
+    float32 arrays in pinned host memory (pinned=False / NDDM_PINNED_RESULTS=0: pageable memory, see to_host), plus 'seed' /
+    'set_offset'.
 
     A small batch is one launch and one copy.  A large one (more than `chunk_bytes` of trials, default 128 MB) is simulated in
     CHUNKS of parameter sets, and every chunk's results travel to the host on a second stream while the next chunk is simulated:
@@ -331,10 +355,10 @@ def simulate_to_host(model, params, n_trials, seed=None, set_offset=None, stream
         r = simulate(model, params, n_trials, set_offset=set_offset, bounds=bounds, **common)
         for k in ("trials", "summary", "ext"):
             if k in r:
-                res[k] = to_host(r[k])
+                res[k] = to_host(r[k], pinned)
         return res
     with torch.cuda.device(dev):
-        pin = lambda *shape: torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        pin = lambda *shape: torch.empty(shape, dtype=torch.float32, pin_memory=_pinned(pinned))
         host = {"trials": pin(B, n_trials, 2) if want_trials else None, "summary": pin(B, SUMMARY_K) if want_summary else None,
                 "ext": pin(B) if want_ext else None}
         cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)

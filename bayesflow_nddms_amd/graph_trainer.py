@@ -159,6 +159,7 @@ class GraphTrainer:
         # DESIGN §6, "Config 5, round 4").  So the side streams are CHOSEN by a probe: independent of the streams before them.
         # (A high-priority stream has a queue of its own by construction, but its mere existence slowed every kernel that ran
         # beside the simulator by 2-7 x on this chip: measured, not used.)
+        self.independent_queues = []       # one entry per probed side stream: did the probe find a queue of its own?
         self._sim_stream = self._independent_stream([self._stream]) if self.overlap else None
         self._comm = self._independent_stream([self._stream] + ([self._sim_stream] if self.overlap else [])) \
             if (self.overlap and self.world > 1) or self.split else torch.cuda.Stream(device=self.dev)
@@ -176,15 +177,19 @@ class GraphTrainer:
     def _independent_stream(self, others, candidates=12):
         """A stream whose hardware queue is none of `others`' queues, found by experiment: a ~2 ms spin kernel goes to each
         of `others`, a 4-byte fill and an event to the candidate; if the event completes while the spins still run, the
-        candidate's work does not queue behind theirs.  Falls back to the last candidate (correct, only slower)."""
+        candidate's work does not queue behind theirs.  If no candidate passes (host jitter, a card shared with other
+        processes), the last DISTINCT candidate serves -- correct, only slower (the producer then queues behind the training
+        graph: + ~45 us per iteration) -- and `independent_queues` says so (bench.py reports it, a RuntimeWarning is raised)."""
         import time
+        import warnings
         flag = torch.zeros(1, device=self.dev)
-        cand = None
+        fallback = None
         with torch.cuda.device(self.dev):
             for _ in range(candidates):
                 cand = torch.cuda.Stream(device=self.dev)
                 if any(cand.cuda_stream == o.cuda_stream for o in others):
                     continue
+                fallback = cand
                 torch.cuda.synchronize(self.dev)
                 for o in others:
                     with torch.cuda.stream(o):
@@ -199,8 +204,16 @@ class GraphTrainer:
                 ok = ev.query()
                 torch.cuda.synchronize(self.dev)
                 if ok:
+                    self.independent_queues.append(True)
                     return cand
-        return cand
+            self.independent_queues.append(False)
+            warnings.warn("GraphTrainer: no stream with a hardware queue of its own was found for the pipelined feed; the producer of "
+                          "batch i + 1 may queue behind the training graph of batch i (slower, same result)", RuntimeWarning, stacklevel=3)
+            while fallback is None:               # (every candidate so far was one of `others`: keep asking for a distinct one)
+                cand = torch.cuda.Stream(device=self.dev)
+                if not any(cand.cuda_stream == o.cuda_stream for o in others):
+                    fallback = cand
+        return fallback
 
     # ------------------------------------------------------------------------------------------------ the iteration
     def bucket_top(self, n):
@@ -432,7 +445,7 @@ class GraphTrainer:
         self._buckets[key] = bk
         return bk
 
-    def _run(self, bk, key, fn, stream=None):
+    def _run(self, bk, key, fn):
         """One graph-able stretch of the iteration on one bucket: captured at its first use -- after one eager pass at this
         shape (GEMM heuristics, workspaces, autograd buffers) whose every effect on the trainer's state is rolled back, so
         that capturing does not cost an iteration -- and replayed from then on."""
@@ -554,7 +567,7 @@ class GraphTrainer:
                         S.wait_event(bk.free_ev)        # the training graph that read this buffer set last (two uses ago) is done
                     if not gather:
                         self._set_n(bk, n)
-                self._run(bk, "sim", lambda: self._simulate(bk), stream=S)
+                self._run(bk, "sim", lambda: self._simulate(bk))
                 ev = torch.cuda.Event(enable_timing=_TIMED_EVENTS)
                 ev.record(S)
             if gather:

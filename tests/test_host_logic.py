@@ -350,3 +350,78 @@ def test_training_library_builds_and_exports_its_entry_points():
     L.nddm_deepset_supported.argtypes = [ctypes.c_int] * 2
     assert L.nddm_deepset_supported(64, 2) == 1 and L.nddm_deepset_supported(64, 64) == 1 and L.nddm_deepset_supported(64, 7) == 0
     assert build.train_source_hash() == open(build.TRAIN_SO_PATH + ".srchash").read().strip()
+
+
+_RACE_WORKER = r"""
+import os, stat, sys, time
+sys.path.insert(0, sys.argv[1])
+from bayesflow_nddms_amd import build
+tmp = sys.argv[2]
+build.TRAIN_SO_PATH = os.path.join(tmp, "libfake_train.so")
+build._hipcc = lambda: os.path.join(tmp, "fake_hipcc.sh")
+while not os.path.exists(os.path.join(tmp, "go")):      # both processes leave the gate together
+    time.sleep(0.005)
+build.build_train()
+assert not build.train_is_stale()
+"""
+
+
+def test_two_processes_racing_on_a_stale_training_library_compile_once(tmp_path):
+    """build_train() re-checks freshness AFTER taking the lock (as build_hip does): of two ranks that both found the library stale,
+    one compiles and the other finds it fresh when its turn comes.  (The compiler is a stand-in that logs each invocation and
+    takes half a second, writing to a scratch path: the tree's own library is not touched.)"""
+    import subprocess
+    import sys
+    import time
+    fake = tmp_path / "fake_hipcc.sh"
+    fake.write_text('#!/bin/bash\necho run >> "%s/calls.log"\nsleep 0.5\nwhile [ "$1" != "-o" ]; do shift; done\necho lib > "$2"\n' % tmp_path)
+    fake.chmod(0o755)
+    (tmp_path / "libfake_train.so.srchash").write_text("stale")
+    worker = tmp_path / "worker.py"
+    worker.write_text(_RACE_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(worker), ROOT, str(tmp_path)]) for _ in range(2)]
+    time.sleep(1.0)                                       # (imports done, both spinning at the gate)
+    (tmp_path / "go").write_text("")
+    assert [p.wait(timeout=60) for p in procs] == [0, 0]
+    assert (tmp_path / "calls.log").read_text().count("run") == 1
+
+
+def test_all_gather_form_follows_the_backend_and_errors_surface(monkeypatch):
+    """distributed.all_gather_rows picks the collective by dist.get_backend() -- RCCL: ONE all_gather_into_tensor, gloo: the list form
+    -- and never by catching an error: a failing RCCL collective raises its own message and no second collective follows on the
+    same communicator."""
+    import torch
+    from bayesflow_nddms_amd import distributed as D
+
+    class FakeDist:
+        def __init__(self, backend, fail=False):
+            self.backend, self.fail, self.calls = backend, fail, []
+
+        def get_world_size(self, group=None):
+            return 2
+
+        def get_backend(self, group=None):
+            return self.backend
+
+        def all_gather_into_tensor(self, full, local, group=None):
+            self.calls.append("flat")
+            if self.fail:
+                raise RuntimeError("NCCL error: unhandled system error")
+            full.copy_(torch.cat([local, local]))
+
+        def all_gather(self, parts, local, group=None):
+            self.calls.append("list")
+            for p in parts:
+                p.copy_(local)
+
+    x = torch.arange(6.0).view(3, 2)
+    for backend, form in (("nccl", "flat"), ("gloo", "list"), ("cpu:gloo,cuda:nccl", "flat")):
+        fd = FakeDist(backend)
+        monkeypatch.setattr(D, "_dist", lambda fd=fd: fd)
+        out = D.all_gather_rows(x, 5)
+        assert fd.calls == [form] and out.shape == (5, 2) and torch.equal(out[:3], x) and torch.equal(out[3:], x[:2])
+    fd = FakeDist("nccl", fail=True)
+    monkeypatch.setattr(D, "_dist", lambda: fd)
+    with pytest.raises(RuntimeError, match="unhandled system error"):
+        D.all_gather_rows(x, 5)
+    assert fd.calls == ["flat"]                            # nothing was attempted after the failure
