@@ -586,6 +586,7 @@ class Trainer:
         self.stream_state = stream_state
         self.loss_history = []
         self.replay = []
+        self._graph_pos = None             # graph=True: where the last train_* call left the random stream and the replay buffer
 
     def _simulate(self, batch_size):
         return self.configurator(self.generative_model(batch_size))
@@ -654,15 +655,23 @@ class Trainer:
     def _graph_loop(self, replay, epochs, iterations_per_epoch, batch_size, capacity_in_batches, validation_sims, save_checkpoint,
                     optimizer):
         """The call as graph replays: one GraphTrainer for THIS call (its cosine schedule spans epochs x iterations, a fresh Adam:
-        _setup_schedule's semantics), an epoch = one train_* call of it, validation loss and checkpoint between epochs."""
+        _setup_schedule's semantics), an epoch = one train_* call of it, validation loss and checkpoint between epochs.
+
+        The run's POSITION outlives the call (`self._graph_pos`, also in ckpt.pt): the next call -- and a run resumed through
+        load_pretrained_network -- continues the random stream (next parameter sets, next batch-shared N) and the experience-replay
+        buffer where this one stopped, as the eager loop does through `stream_state` and `self.replay`.  Training's parameter
+        sets start at graph_trainer.TRAIN_OFFSET_BASE of the seed's index space; the generative model's own draws (validation
+        sims, recovery data sets) count up from 0, so the two never meet."""
         spec = getattr(self.generative_model, "graph_spec", None)
         if spec is None or self.device.type != "cuda" or optimizer is not None:
             raise ValueError("Trainer(graph=True) needs a generative model made by a model module's make_generative_model "
                              "(it carries `graph_spec`), a ROCm device, and no caller-supplied optimizer")
-        from .graph_trainer import GraphTrainer
+        from .graph_trainer import TRAIN_OFFSET_BASE, GraphTrainer
         val = []
         with GraphTrainer(self.amortizer, batch_size=batch_size, total_steps=epochs * iterations_per_epoch, learning_rate=self.lr,
-                          device=self.device, **spec) as gt:
+                          device=self.device, offset_base=TRAIN_OFFSET_BASE, **spec) as gt:
+            if self._graph_pos is not None:
+                gt.set_position(self._graph_pos)
             for _ in range(epochs):
                 if replay:
                     gt.train_experience_replay(iterations_per_epoch, capacity_in_batches=capacity_in_batches)
@@ -671,9 +680,10 @@ class Trainer:
                 if validation_sims is not None:
                     val.append(gt.validation_loss(self.configurator(validation_sims)))
                 if save_checkpoint and self.checkpoint_path:
+                    self._graph_pos = gt.position()
                     self.loss_history_graph = gt.loss_history()
-                    gt.save_checkpoint(os.path.join(self.checkpoint_path, "graph_ckpt.pt"))
                     self.save_checkpoint(extra_losses=self.loss_history_graph)
+            self._graph_pos = gt.position()
             self.loss_history += gt.loss_history()
         self._optimizer_spent = True
         return val
@@ -733,6 +743,8 @@ class Trainer:
                  "loss_history": self.loss_history + list(extra_losses)}
         if self.stream_state is not None:
             state["stream_state"] = self.stream_state.get_state()
+        if self._graph_pos is not None:
+            state["graph_position"] = self._graph_pos
         torch.save(state, os.path.join(self.checkpoint_path, "ckpt.pt"))
         with open(os.path.join(self.checkpoint_path, "history.pkl"), "wb") as f:
             pickle.dump({"loss_history": state["loss_history"]}, f)
@@ -741,13 +753,14 @@ class Trainer:
         path = os.path.join(self.checkpoint_path or "", "ckpt.pt")
         if not os.path.exists(path):
             return False
-        state = torch.load(path, map_location=self.device)
+        state = torch.load(path, map_location=self.device, weights_only=False)       # (our own file: the replay generator's state is a dict)
         self.amortizer.load_state_dict(state["model"])
         self.optimizer.load_state_dict(state["optimizer"])
         self._optimizer_spent = False      # the loaded moments serve the next train_* call (which sets its own schedule)
         self.loss_history = list(state.get("loss_history", []))
         if self.stream_state is not None and "stream_state" in state:
             self.stream_state.set_state(state["stream_state"])
+        self._graph_pos = state.get("graph_position", self._graph_pos)      # graph=True: the next call continues the stream
         return True
 
 

@@ -49,6 +49,11 @@ from .distributed import shared_prior_N
 # basic_ddm_dc.py:62-80 draws 5 parameters; single_trial_alpha_not_scaled.py:78-102 draws 7, the kernel takes an eighth (gamma = 1)
 _PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5, 5), "single": (engine.SINGLE_TRIAL, 8, 7)}
 
+# Where TRAINING runs that share a seed with a generative model start in the 60-bit space of global set indices (csrc/nddm_sim.h:
+# low word + 28 high bits): the model modules' own DevicePrior counts up from 0 -- `generative_model(B)` for validation_sims and the
+# recovery loop's fresh data sets (basic_ddm_dc.py:186-188, 218-223) -- so evaluation never sees a parameter row training has seen.
+TRAIN_OFFSET_BASE = 1 << 59
+
 
 # Cross-stream dependencies of the pipelined loop: plain events.  (Timing events -- a barrier packet with a completion signal of its
 # own at the point of the record -- were tried when the simulate graph of batch i + 1 was seen starting 300-400 us into the training
@@ -65,13 +70,14 @@ class _Bucket:
 class GraphTrainer:
     def __init__(self, amortizer, batch_size=32, total_steps=1000, n_min=60, n_max=300, n_buckets=8, dt=0.01,
                  max_steps=400.0, seed=2023, learning_rate=5e-4, clip=5.0, device=None, use_graph=True,
-                 world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic", overlap=True):
+                 world=1, rank=0, parallel="gather", backend="nccl", split=None, model="basic", overlap=True, offset_base=0, n_base=0):
         """total_steps: length of the cosine schedule (past it the rate holds the schedule's final value) and size of the
         device-side loss ring (read out by the host before it wraps: the history is complete for any number of iterations).
         use_graph=False runs the SAME iteration eagerly (the comparator of the parity test).  split: force the two-graph
         form (the one used with a collective in the middle) at world 1.  overlap (graphs, any world size): batch i + 1 is
         simulated -- and all-gathered -- on streams of its own while batch i is trained on: same batches, same order, same
-        result as the sequential loop (overlap=False)."""
+        result as the sequential loop (overlap=False).  offset_base / n_base: where this run starts in the random stream -- the
+        global index of its first parameter set, and the key of its first batch-shared N (set_position() moves both later)."""
         if parallel not in ("gather", "ddp"):
             raise ValueError("parallel must be 'gather' or 'ddp'")
         torch_ = engine.require_device()
@@ -88,7 +94,9 @@ class GraphTrainer:
         self.world, self.rank, self.parallel, self.backend = int(world), int(rank), parallel, backend
         self.split = (self.world > 1) if split is None else bool(split)
         self.overlap = bool(overlap) and self.use_graph
-        self.iteration = 0
+        self.iteration = 0                 # iterations of THIS run: indexes the loss ring and the schedule
+        self.n_base = int(n_base)          # key of this run's first batch-shared N: batch k of the run draws N from (seed, n_base + k)
+        self._offset_base = int(offset_base)
         self._warned_past_end = False
         self._loss_host = []               # losses already read out of the device ring (_drain_losses)
         self._uses = {}                    # pipelined loop, direct form: how often each bucket was produced into (-> its buffer set)
@@ -139,7 +147,7 @@ class GraphTrainer:
                 self._flat_param.grad = self.flat[:n_el]
                 self.optimizer = torch.optim.Adam([self._flat_param], lr=self.lr_t, capturable=True, fused=True)
             # device-side counters and scalars
-            self.offset = torch.tensor([self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
+            self.offset = torch.tensor([self._offset_base + self.rank * self.B], dtype=torch.int64, device=self.dev)   # this rank's row 0 of the next batch
             self.step_i = torch.zeros(1, dtype=torch.int64, device=self.dev)
             self.step_f = torch.zeros(1, dtype=torch.float32, device=self.dev)
             self.loss_buf = torch.zeros(max(1, self.T), dtype=torch.float32, device=self.dev)
@@ -529,7 +537,7 @@ class GraphTrainer:
         T.wait_stream(cur)
         S.wait_stream(T)
         C.wait_stream(T)
-        ns = [shared_prior_N(self.seed, self.iteration + k, self.n_min, self.n_max) for k in range(int(iterations))]
+        ns = [shared_prior_N(self.seed, self.n_base + self.iteration + k, self.n_min, self.n_max) for k in range(int(iterations))]
         up = lambda: self._update(1.0 / self.world if (coll and ddp) else 1.0)
         stamps = self.stage_stamps = [] if _os.environ.get("NDDM_TRAIN_STAGE_STAMPS") else None     # developer aid (tools/train_stage_times.py)
         # Host order of an iteration.  The producer of batch i + 1 goes to its streams BEFORE the training graph of batch i goes
@@ -662,7 +670,7 @@ class GraphTrainer:
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
             for _ in range(int(iterations)):
-                self._iteration(shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max))   # batch-shared N (basic_ddm_dc.py:50-52, 131)
+                self._iteration(shared_prior_N(self.seed, self.n_base + self.iteration, self.n_min, self.n_max))   # batch-shared N (basic_ddm_dc.py:50-52, 131)
                 self.iteration += 1
         torch.cuda.current_stream(self.dev).wait_stream(self._stream)
 
@@ -673,15 +681,46 @@ class GraphTrainer:
         import numpy as np
         if self._replay is None:
             self._replay = ([], np.random.default_rng(replay_seed), int(capacity_in_batches))
+        elif self._replay[2] != int(capacity_in_batches):      # a continued buffer (set_position) under another capacity
+            ring, rng, _ = self._replay
+            del ring[int(capacity_in_batches):]
+            self._replay = (ring, rng, int(capacity_in_batches))
         self._note_schedule_end(iterations)
         if self.overlap:
             return self._train_overlapped(iterations, self._replay)
         self._stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.device(self.dev), torch.cuda.stream(self._stream):
             for _ in range(int(iterations)):
-                self._iteration(shared_prior_N(self.seed, self.iteration, self.n_min, self.n_max), self._replay)
+                self._iteration(shared_prior_N(self.seed, self.n_base + self.iteration, self.n_min, self.n_max), self._replay)
                 self.iteration += 1
         torch.cuda.current_stream(self.dev).wait_stream(self._stream)
+
+    # ---- the run's POSITION in the random stream, apart from its weights / optimizer / schedule: what a LATER run (the next
+    # train_* call of amortizer.Trainer(graph=True), or a resumed one) needs to continue with fresh data instead of replaying this one's
+    def position(self):
+        """{'offset': global index of the next batch's first parameter set (rank 0's row 0), 'n_key': key of the next batch-shared N,
+        'replay': the experience-replay buffer and its generator, or None} -- one synchronisation of the training stream."""
+        self._stream.synchronize()
+        pos = {"offset": int(self.offset.item()) - self.rank * self.B, "n_key": self.n_base + self.iteration, "replay": None}
+        if self._replay is not None:
+            ring, rng, cap = self._replay
+            pos["replay"] = {"ring": [(p.cpu(), t.cpu(), n) for p, t, n in ring], "rng": rng.bit_generator.state, "capacity": cap}
+        return pos
+
+    def set_position(self, pos):
+        """Continue the stream a previous run left at `pos` (position()): the next batch takes the next parameter sets and the next
+        N, experience replay goes on with the stored batches.  Weights, Adam's state and the schedule are not touched."""
+        import numpy as np
+        self._stream.synchronize()
+        with torch.no_grad():
+            self.offset.fill_(int(pos["offset"]) + self.rank * self.B)
+        self.n_base = int(pos["n_key"]) - self.iteration
+        self._replay = None
+        if pos.get("replay") is not None:
+            rng = np.random.default_rng(0)
+            rng.bit_generator.state = pos["replay"]["rng"]
+            self._replay = ([(p.to(self.dev), t.to(self.dev), n) for p, t, n in pos["replay"]["ring"]], rng, int(pos["replay"]["capacity"]))
+        torch.cuda.synchronize(self.dev)
 
     def _note_schedule_end(self, iterations):
         """A run that goes past `total_steps` trains on at the schedule's final rate (0 for the cosine): legal, and what
@@ -722,7 +761,7 @@ class GraphTrainer:
     # so that a resumed run continues the random stream and reproduces the uninterrupted one
     def state_dict(self):
         self._stream.synchronize()
-        st = {"model": self.amortizer.state_dict(), "optimizer": self._optimizer_state(), "iteration": self.iteration,
+        st = {"model": self.amortizer.state_dict(), "optimizer": self._optimizer_state(), "iteration": self.iteration, "n_base": self.n_base,
               "offset": self.offset.cpu(), "step_i": self.step_i.cpu(), "step_f": self.step_f.cpu(), "lr": self.lr_t.cpu(),
               "loss_buf": self.loss_buf.cpu(), "loss_host": self.loss_history(), "replay": None}
         if self._replay is not None:
@@ -756,6 +795,7 @@ class GraphTrainer:
             n = min(self.loss_buf.numel(), st["loss_buf"].numel())
             self.loss_buf[:n].copy_(st["loss_buf"][:n])
         self.iteration = int(st["iteration"])
+        self.n_base = int(st.get("n_base", 0))
         # (a checkpoint written before the ring existed holds the first min(iteration, capacity) losses in its buffer)
         self._loss_host = list(st["loss_host"]) if "loss_host" in st else st["loss_buf"][:min(self.iteration, n)].tolist()
         self._replay = None

@@ -182,3 +182,27 @@ def test_graph_route_of_the_classic_trainer_is_refused_without_a_device_or_a_rec
     with pytest.raises(ValueError, match="graph_spec"):
         tr.train_experience_replay(1, 2, 4)
 
+
+
+def test_the_graph_runs_position_travels_in_the_trainers_checkpoint(tmp_path):
+    """What Trainer(graph=True) keeps between train_* calls -- the next parameter set's global index, the key of the next
+    batch-shared N, the experience-replay buffer and its generator's state -- is written to ckpt.pt and comes back through
+    load_pretrained_network, so a resumed run continues the stream instead of replaying it.  (The position itself is produced on
+    the GPU: tests/test_gpu_training.py; here the round trip of the file.)"""
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    rng = np.random.default_rng(5)
+    rng.integers(10, size=7)
+    pos = {"offset": (1 << 59) + 12 * 32, "n_key": 12,
+           "replay": {"ring": [(torch.randn(32, 5), torch.randn(32, 90, 2), 77)], "rng": rng.bit_generator.state, "capacity": 100}}
+    ck = str(tmp_path / "ck")
+    a = Trainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), lambda b: None, checkpoint_path=ck, graph=True, device="cpu")
+    a._graph_pos = pos
+    a.save_checkpoint()
+    b = Trainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), lambda b: None, checkpoint_path=ck, graph=True, device="cpu")
+    assert b._graph_pos is None and b.load_pretrained_network()
+    got = b._graph_pos
+    assert got["offset"] == pos["offset"] and got["n_key"] == 12 and got["replay"]["capacity"] == 100
+    assert torch.equal(got["replay"]["ring"][0][1], pos["replay"]["ring"][0][1]) and got["replay"]["ring"][0][2] == 77
+    r2 = np.random.default_rng(0)
+    r2.bit_generator.state = got["replay"]["rng"]
+    assert r2.integers(1 << 30) == rng.integers(1 << 30)

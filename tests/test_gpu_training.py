@@ -306,7 +306,7 @@ def test_classic_trainer_call_shape_runs_as_graph_replays(tmp_path):
         tl, vl = np.array(out["train_losses"]), out["val_losses"]
         assert tl.shape == (240,) and len(vl) == 3 and np.all(np.isfinite(tl)) and np.all(np.isfinite(vl))
         assert tl[-40:].mean() < tl[:40].mean() - 0.5 and vl[-1] < vl[0]
-        assert os.path.exists(os.path.join(ck, "ckpt.pt")) and os.path.exists(os.path.join(ck, "graph_ckpt.pt"))
+        assert os.path.exists(os.path.join(ck, "ckpt.pt"))
         h = tr.train_online(epochs=1, iterations_per_epoch=20, batch_size=32)                   # a second call: a run of its own
         assert len(h) == 260 and len(tr.loss_history) == 260
         am2 = AmortizedPosterior(InvertibleNetwork(num_params=P), InvariantNetwork())
@@ -320,6 +320,52 @@ def test_classic_trainer_call_shape_runs_as_graph_replays(tmp_path):
     with pytest.raises(ValueError, match="graph_spec"):
         Trainer(AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()), plain, basic_ddm_dc.configurator,
                 graph=True).train_online(1, 2, 4)
+
+
+def test_trainer_graph_calls_continue_the_stream_and_a_resumed_run_does_too(tmp_path):
+    """Trainer(graph=True): every train_* call builds a GraphTrainer of its own (schedule, fresh Adam) but CONTINUES the run's random
+    stream -- parameter sets, batch-shared N, the experience-replay buffer and its generator -- and so does a run resumed with
+    load_pretrained_network (the position travels in ckpt.pt).  Learning rate 0, so a loss depends on its batch alone: a second call
+    that replayed the first call's batches would repeat its losses.  Training's parameter rows start at TRAIN_OFFSET_BASE of the
+    seed's index space; the generative model's own draws (validation sims, recovery data sets) count from 0 and never meet them."""
+    import torch
+    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+    from bayesflow_nddms_amd.graph_trainer import TRAIN_OFFSET_BASE
+    from bayesflow_nddms_amd.priors import DevicePrior
+
+    def fresh(ck):
+        torch.manual_seed(0)
+        gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+        return gm, Trainer(am, gm, basic_ddm_dc.configurator, checkpoint_path=ck, learning_rate=0.0, graph=True)
+
+    for replay in (False, True):
+        call = (lambda tr, n: tr.train_experience_replay(1, n, 32, capacity_in_batches=6)) if replay else (lambda tr, n: tr.train_online(1, n, 32))
+        _, a = fresh(str(tmp_path / f"a{replay}"))
+        call(a, 12); call(a, 12)
+        ha = np.array(a.loss_history)
+        assert ha.shape == (24,) and np.all(np.isfinite(ha))
+        assert np.abs(ha[12:] - ha[:12]).min() > 1e-6, "the second call replayed the first call's batches"
+        assert a._graph_pos["offset"] == TRAIN_OFFSET_BASE + 24 * 32 and a._graph_pos["n_key"] == 24
+        # one straight call of 24 iterations sees the same 24 batches (and the same replay draws) as the two calls of 12
+        _, s_ = fresh(None)
+        call(s_, 24)
+        assert np.allclose(np.array(s_.loss_history), ha, rtol=1e-5, atol=1e-5)
+        # resumed: 12 iterations, checkpoint; a NEW trainer loads it and goes on -> the straight run's second half
+        ck = str(tmp_path / f"b{replay}")
+        _, b = fresh(ck)
+        call(b, 12)
+        gm_c, c = fresh(ck)
+        assert c.load_pretrained_network() and c._graph_pos["offset"] == TRAIN_OFFSET_BASE + 12 * 32
+        call(c, 12)
+        hc = np.array(c.loss_history)
+        assert hc.shape == (24,) and np.allclose(hc, ha, rtol=1e-5, atol=1e-5), np.abs(hc - ha).max()
+    # evaluation draws: rows 0.. of the seed; training draws: rows TRAIN_OFFSET_BASE.. -- another part of the index space
+    ev = gm_c(64)["prior_draws"]
+    first_training_rows = DevicePrior("basic", seed=2023)(64, set_offset=TRAIN_OFFSET_BASE)
+    assert torch.equal(ev, DevicePrior("basic", seed=2023)(64, set_offset=gm_c.prior.prior.state.offset - 64))
+    assert not torch.isclose(ev[:, None, 0], first_training_rows[None, :, 0]).any()
 
 
 def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
