@@ -66,8 +66,9 @@ static int round_up_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // Every entry point that takes a stream validates the handle FIRST, with the one HIP call that checks instead of dereferencing:
 // hipStreamGetDevice answers hipErrorContextIsDestroyed for a destroyed stream, for a stream of another copy of the HIP runtime
 // in the process and for an integer that never was a stream, whereas hipStreamIsCapturing, hipStreamQuery, hipStreamSynchronize,
-// hipEventRecord (and the launch calls) dereference the handle -- a SIGSEGV in the caller's thread (probed call by call on ROCm
-// 7.0: tools/probe_stream_validation.py, profiles/r4_stream_validation.txt).  The stream must also belong to the current device:
+// hipEventRecord (and the launch calls) dereference the handle -- a SIGSEGV in the caller's thread (probed call by call on the HIP
+// runtime 7.0.51831 that PyTorch 2.10.0+rocm7.0 loads: tools/probe_stream_validation.py, profiles/r4_stream_validation.txt; bench.py
+// records the runtime in `toolchain`).  The stream must also belong to the current device:
 // the launch's memory is taken from that device's slots.
 static int check_stream(hipStream_t st)
 {
@@ -282,7 +283,8 @@ static char *graph_alloc(int dev, size_t bytes, hipError_t *err)
 }
 
 // zeroes the 64 counting-sort counters / the queue words of a captured launch (a kernel, not hipMemsetAsync: memset NODES
-// of a captured launch were observed not to take effect on graph replay with ROCm 7.2)
+// of a captured launch were observed not to take effect on graph replay -- HIP runtime 7.0.51831, the copy PyTorch 2.10.0+rocm7.0
+// loads; the library itself is built by hipcc 7.2.26015.  Probe: tools/probe_graph_memset_node.py, profiles/r5_probe_graph_memset_node.txt)
 __global__ void zero_words_kernel(unsigned int *ws) { ws[threadIdx.x] = 0u; }
 
 // resident waves of a kernel instantiation on the current device (persistent grid size)

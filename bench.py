@@ -22,6 +22,16 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   cpu_baseline  the CPU oracle (C restatement, same Philox stream) timed on this box's host cores on a bounded
                 sample of the same workload; plus the pure-Python/NumPy port the reference runs without numba
 
+  legs          (N = 1, default command) the OTHER BASELINE configs under the same command and clock, each outside the headline's timed
+                region: `single` = configs[3] (trials + fused summaries, and summaries alone), `alpha_ns_bridge` = configs[2], `train` =
+                configs[4] (GraphTrainer at one rank and in the RCCL all-gather form, both step sizes); each with rate, kernel time,
+                KS + bar, roofline_valu
+  dist          (any line with a process group) who ran it: backend, RCCL version, one entry per rank (device, PCI bus id, kernel ms,
+                elapsed, host prior seconds), imbalance = slowest / fastest
+  side_legs     (process group, default command) short timed passes the weak-scaling headline leaves out: the minibatch all-gather of
+                the summaries and of the 2-byte codes (north_star's collective), and the strong-scaling point (1M sets in total)
+  toolchain     HIP runtime actually loaded, hipcc, torch, RCCL, rocRAND
+
 `--train` measures BASELINE config 5 instead (online simulation feeding the PyTorch-ROCm amortizer): iterations/s,
 microseconds per simulate launch (eager and hipGraph), simulator share of a step, prefetch on/off.
 """
@@ -87,6 +97,11 @@ def parse():
     ap.add_argument("--cpu-full", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--no-ks", action="store_true")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the lockstep run that measures the VALU ceiling")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the side legs of the default line: at N = 1 the other BASELINE configs (single-trial + fused summaries, "
+                         "alpha_not_scaled with the bridge, the config-5 training loop), at N > 1 the all-gather and strong-scaling legs")
+    ap.add_argument("--leg-launches", type=int, default=4, help="timed launches per simulator side leg")
+    ap.add_argument("--leg-train-iters", type=int, default=150, help="timed iterations per training side leg")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --share-device rehearse the multi-process path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -306,7 +321,7 @@ def em_steps_of(summary, tau, dt, max_k, bridge):
     return float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
 
 
-def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry):
+def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry, model_name=None):
     """The step loop with every lane useful: the SAME kernel (variant and grid of the timed launch: `geometry` =
     engine.last_launch() after a timed step) on a workload whose trials all run to the step cap (no refill, no idle lanes,
     same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane efficiency it was measured at
@@ -314,7 +329,7 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed,
     max_k = engine.max_k_of(a.max_steps)
     N = a.trials
     B = int(max(2048, min(400_000, 4.8e10 / (N * max_k))))
-    p = torch.tensor([LOCKSTEP_ROW[a.model]] * B, dtype=torch.float32, device=dev)
+    p = torch.tensor([LOCKSTEP_ROW[model_name or a.model]] * B, dtype=torch.float32, device=dev)
     summ = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
     L = _lib.lib()
     # never leave the loop early (refill only when all lanes are done); the timed launch's kernel variant and grid
@@ -408,38 +423,31 @@ def barrier(a, ctx):
     ctx["torch"].cuda.synchronize()
 
 
-def simulate_bench(a, ctx):
-    world, rank, dev, torch, dist, engine, _lib, prior_util = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine",
-                                                                                   "_lib", "prior_util"))
-    B, N = a.sets, a.trials
+def simulate_pass(a, ctx, p_dev, B, gather, steps, warmup, first_step=0, summary_only=False):
+    """`warmup` untimed + `steps` timed passes of the hot path over batches of B parameter sets per rank (rows of p_dev), bracketed by
+    barrier + synchronize on both sides; with a process group and gather != 'none' the minibatch all-gather is inside the timed
+    region.  Returns {'elapsed': seconds, MAX over ranks; 'elapsed_local'; 'kernel_ms': mean simulate-kernel time on this rank (events
+    on the launch stream); 'trials' / 'summary': the buffers the last step wrote; 'geometry'; 'overlap'; 'step': the step function}."""
+    world, rank, dev, torch, dist, engine = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine"))
+    N = a.trials
     fast, packed = a.gauss != "exact", a.gauss == "packed"
-    if packed and MODELS[a.model][1]:
-        sys.exit("--gauss packed cannot be combined with the bridge correction")
-    model_attr, bridge, prior_fn, _, tau_i = MODELS[a.model]
+    model_attr, bridge, _, _, _ = MODELS[a.model]
     model_id = getattr(engine, model_attr)
-    # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
-    # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
-    t_prior = time.perf_counter()
-    p_host = getattr(prior_util, prior_fn)(B, 2023 + rank)
-    p_dev = torch.as_tensor(p_host).to(dev)
-    t_prior = time.perf_counter() - t_prior
-    # per-rank host work before the timed region: N ranks share the node's host cores (vectorised draws: ~0.2 s per 1M rows on one)
-    print(f"bench.py: rank {rank}/{world} on cuda:{torch.cuda.current_device()}: {B} parameter rows drawn on the host and copied in "
-          f"{t_prior:.2f} s", file=sys.stderr, flush=True)
     # Output buffers.  With a minibatch all-gather (north_star's reassembly step) the collective runs on a COMMUNICATION
     # stream and the outputs are double-buffered: step i+1's simulate is enqueued before step i's gather is waited on, so the
     # two overlap (DESIGN.md section 7: at weak scale the gather of the trials moves as many bytes over xGMI as the simulate
     # takes time for).  A buffer is handed to the simulator again only after the gather that reads it has completed.
     dist_on = ctx["dist_on"]
-    gather_on = dist_on and a.gather != "none"
-    if a.gather in ("trials", "codes") and a.summary_only:
+    gather_on = dist_on and gather != "none"
+    if gather in ("trials", "codes") and summary_only:
         sys.exit("--gather trials / codes needs the trials: drop --summary-only")
-    codes = a.gather == "codes"                       # the simulator writes 2-byte codes; floats appear after the gather, by decoding
+    codes = gather == "codes"                         # the simulator writes 2-byte codes; floats appear after the gather, by decoding
     if codes and (a.model not in ("basic", "alpha_ns") or a.max_steps >= 16384):
         sys.exit("--gather codes: basic / alpha_ns (no bridge) with max_steps < 2^14")
     overlap = gather_on and not a.no_overlap
     nbuf = 2 if overlap else 1
-    buf_trials = [None if (a.summary_only or codes) else torch.empty((B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    p_dev = p_dev[:B]
+    buf_trials = [None if (summary_only or codes) else torch.empty((B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     buf_codes = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(nbuf)] if codes else None
     buf_summary = [torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     gathered = g_codes = g_params = None
@@ -448,7 +456,7 @@ def simulate_bench(a, ctx):
         g_params = [torch.empty((world,) + tuple(p_dev.shape), dtype=torch.float32, device=dev) for _ in range(nbuf)]
         gathered = [torch.empty((world, B, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     elif gather_on:
-        shape = tuple((buf_summary if a.gather == "summary" else buf_trials)[0].shape)
+        shape = tuple((buf_summary if gather == "summary" else buf_trials)[0].shape)
         gathered = [torch.empty((world,) + shape, dtype=torch.float32, device=dev) for _ in range(nbuf)]
     # the communication stream has the higher priority: when a gather and the next simulate become runnable together the
     # collective's few workgroups are placed first, and the persistent simulator grid (which otherwise holds every wave slot
@@ -471,7 +479,7 @@ def simulate_bench(a, ctx):
             ev[0].record()                              # torch's current stream == the stream the kernel is launched on
         engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023,
                         set_offset=(i * world + rank) * B, fast=fast, out_trials=buf_trials[b], out_summary=buf_summary[b],
-                        want_trials=not (a.summary_only or codes), bridge=bridge, packed=packed,
+                        want_trials=not (summary_only or codes), bridge=bridge, packed=packed,
                         out_codes=buf_codes[b] if codes else None)
         if ev is not None:
             ev[1].record()
@@ -479,7 +487,7 @@ def simulate_bench(a, ctx):
         def exchange(blocking):
             """the collective(s) of this step on the current stream; returns the last one's handle (non-blocking form)"""
             if not codes:
-                return all_gather(gathered[b], buf_summary[b] if a.gather == "summary" else buf_trials[b], not blocking)
+                return all_gather(gathered[b], buf_summary[b] if gather == "summary" else buf_trials[b], not blocking)
             all_gather(g_params[b], p_dev, False)                # tau travels with the codes (20 B per set)
             all_gather(g_codes[b].view(torch.uint8), buf_codes[b].view(torch.uint8), False)     # (as bytes: RCCL has no 16-bit integer type;
                                                                                                   #  always the blocking form: the decode needs them)
@@ -512,25 +520,245 @@ def simulate_bench(a, ctx):
                 pending[b].wait()
                 pending[b] = None
 
-    for i in range(a.warmup):
-        step(i)
+    for i in range(warmup):
+        step(first_step + i)
     drain()
     barrier(a, ctx)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, ev[i])
+    for i in range(steps):
+        step(first_step + warmup + i, ev[i])
     drain()
     barrier(a, ctx)
-    elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed = time.perf_counter() - t0
     geometry = engine.last_launch()          # the timed launches' kernel variant, grid, ring, tiles (outside the timed region)
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    last = (a.warmup + a.steps - 1) % nbuf       # the buffers the last step wrote
-    out_trials, out_summary = buf_trials[last], buf_summary[last]
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    last = (first_step + warmup + steps - 1) % nbuf       # the buffers the last step wrote
+    return {"elapsed": elapsed, "elapsed_local": elapsed_local, "kernel_ms": float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])),
+            "trials": buf_trials[last], "summary": buf_summary[last], "geometry": geometry, "overlap": overlap, "codes": codes,
+            "step": step, "last_step": first_step + warmup + steps - 1}
+
+
+def rank_identity(a, ctx, t_prior, run):
+    """Who ran this line: one entry per rank -- the device it used (index, name, PCI bus id), its simulate-kernel time and its own
+    elapsed time of the timed region -- gathered with all_gather_object AFTER the timed region; plus the backend the process group
+    reports and the RCCL version.  `imbalance` = slowest / fastest rank.  (With --share-device every rank truthfully reports the same card.)"""
+    world, rank, dev, torch, dist = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist"))
+    props = torch.cuda.get_device_properties(dev)
+    bus = None
+    if all(hasattr(props, k) for k in ("pci_bus_id", "pci_device_id", "pci_domain_id")):
+        bus = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    me = {"rank": rank, "local_rank": ctx["local_rank"], "device": f"cuda:{torch.cuda.current_device()}", "device_name": props.name,
+          "pci_bus_id": bus, "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid(),
+          "kernel_ms": run["kernel_ms"], "elapsed_s": run["elapsed_local"], "host_prior_s": t_prior}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    ranks.sort(key=lambda r: r["rank"])
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                               # noqa: BLE001 -- a build without it
+        rccl = None
+    km, el = [r["kernel_ms"] for r in ranks], [r["elapsed_s"] for r in ranks]
+    return {"backend": str(dist.get_backend()), "world": dist.get_world_size(), "rccl_version": rccl,
+            "distinct_devices": len({(r["pci_bus_id"], r["device"]) for r in ranks}), "ranks": ranks,
+            "imbalance": {"kernel_ms_max_over_min": max(km) / min(km), "elapsed_max_over_min": max(el) / min(el)}}
+
+
+def toolchain(torch):
+    """What runs and what built this line: the HIP runtime the process actually LOADED (PyTorch's wheel brings its own copy, which is
+    the one the in-tree libraries then bind to), the compiler that built them, torch, RCCL, and the rocRAND release whose device API
+    the vendor yardstick (tools/ubench_rocrand.hip) was built against."""
+    import ctypes
+    import re
+    import shutil
+    import subprocess
+    out = {"torch": torch.__version__, "torch_hip": torch.version.hip, "hip_runtime": None, "hip_runtime_library": None, "hipcc": None,
+           "rccl": None, "rocrand": None}
+    try:
+        with open("/proc/self/maps") as f:
+            paths = sorted({l.split()[-1] for l in f if "libamdhip64" in l})
+        if paths:
+            v = ctypes.c_int(0)
+            ctypes.CDLL(paths[0]).hipRuntimeGetVersion(ctypes.byref(v))      # (already loaded: this returns the same handle)
+            out["hip_runtime"] = f"{v.value // 10000000}.{v.value // 100000 % 100}.{v.value % 100000}"
+            out["hip_runtime_library"] = paths[0]
+    except Exception:                                               # noqa: BLE001
+        pass
+    try:
+        exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        m = re.search(r"HIP version:\s*(\S+)", subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout)
+        out["hipcc"] = m.group(1) if m else None
+    except Exception:                                               # noqa: BLE001
+        pass
+    try:
+        out["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                               # noqa: BLE001
+        pass
+    try:
+        m = re.search(r"#define\s+ROCRAND_VERSION\s+(\d+)", open("/opt/rocm/include/rocrand/rocrand_version.h").read())
+        if m:
+            v = int(m.group(1))
+            out["rocrand"] = f"{v // 100000}.{v // 100 % 1000}.{v % 100}"
+    except Exception:                                               # noqa: BLE001
+        pass
+    return out
+
+
+def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False):
+    """One of the other BASELINE simulator configs as a SIDE LEG of the default line, outside the headline's timed region: the same
+    1M x 300 workload shape on model `name` (parameters from ITS reference prior, resident in HBM), `--leg-launches` launches timed
+    one by one with events on the launch stream; the same objects the model's own `--model` line carries -- rate, kernel time, HBM and
+    VALU rooflines (lockstep ceiling of THIS kernel variant, measured here), KS against the reference fixtures with its bar."""
+    dev, torch, engine, _lib, prior_util = (ctx[k] for k in ("dev", "torch", "engine", "_lib", "prior_util"))
+    B, N, L = a.sets, a.trials, max(1, a.leg_launches)
+    model_attr, bridge, prior_fn, _, tau_i = MODELS[name]
+    model_id = getattr(engine, model_attr)
+    p_host = getattr(prior_util, prior_fn)(B, 2023)
+    p_dev = torch.as_tensor(p_host).to(dev)
+    max_k = engine.max_k_of(a.max_steps)
+
+    def timed(want_trials):
+        run = lambda i: engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023, set_offset=i * B, fast=True,
+                                        out_trials=out_trials if want_trials else None, out_summary=out_summary,
+                                        want_trials=want_trials, bridge=bridge)
+        run(0)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
+        for i, (e0, e1) in enumerate(ev):
+            e0.record(); run(1 + i); e1.record()
+        torch.cuda.synchronize()
+        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    ms = timed(True)
+    geometry = engine.last_launch()
+    em_steps = em_steps_of(out_summary, p_dev[:, tau_i], a.dt, max_k, bridge)          # of the last launch
+    alg_bytes = B * N * 8 + B * (p_host.shape[1] * 4 + engine.SUMMARY_K * 4)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    nm = "single_trial_alpha_not_scaled" if name == "single" else name
+    leg = {"metric": f"simulated DDM trials/sec at n_trials={N} dt={a.dt:g} ({nm}, max_steps={a.max_steps:g})",
+           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": KERNEL_NAME[name] % "fast",
+           "workload": f"{nm} HIP simulator, {B} parameter sets x {N} trials per launch, dt={a.dt}, max_steps={a.max_steps:g}, params ~ its "
+                       f"reference prior (default_rng 2023); trials f32[B,N,2] + fused summaries f32[B,10]",
+           "em_steps_per_trial": em_steps / (B * N), "p_missing": float((out_summary[:, 2].sum() / (B * N)).item()), "launch": geometry,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "traffic": None}}
+    tr = pmc_traffic(name, B, N)
+    if tr:
+        leg["roofline"].update(traffic=tr["bytes"], traffic_source=tr["source"])
+    achieved_steps = em_steps / (ms * 1e-3)
+    rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s"}
+    if not a.no_ceiling:
+        c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, True, False, geometry, model_name=name)
+        rv.update({"peak": c["steps_per_s_all_lanes_useful"] / 1e9, "frac": achieved_steps / c["steps_per_s_all_lanes_useful"],
+                   "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
+                   "ceiling_lane_efficiency": c["lane_efficiency"], "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"]})
+    leg["roofline_valu"] = rv
+    if with_summary_only:                                # configs[3]'s second form: the fused reduction alone, no 8 B per trial
+        ms_s = timed(False)
+        leg["summary_only"] = {"value": B * N / (ms_s * 1e-3), "unit": "trials/s", "kernel_ms": ms_s,
+                               "outputs": "fused summaries f32[B,10] only", "launches": L}
+    if not a.no_ks:
+        leg["ks_vs_ref"] = ks_vs_golden(engine, name, a.dt, a.max_steps, True, False)
+    return leg
+
+
+def training_leg(a, ctx, gather_rccl):
+    """BASELINE configs[4] as a side leg: graph_trainer.GraphTrainer on the reference's loop shape (basic_ddm_dc.py:199-202: batch 32,
+    N ~ U{60..300} per batch), 10 + `--leg-train-iters` iterations with the graph captures, then `--leg-train-iters` timed, at the
+    reference's default step (dt=.01 / 400) and at the bench's (dt=.001 / 4000).  gather_rccl: the multi-rank form on this one GPU --
+    a process group over RCCL at world 1, simulate graph | all_gather_into_tensor on the communication stream | training graph,
+    pipelined -- i.e. every call the 8-GPU feed makes."""
+    dev, torch, dist = (ctx[k] for k in ("dev", "torch", "dist"))
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    from bayesflow_nddms_amd.graph_trainer import GraphTrainer
+    own_group = False
+    if gather_rccl and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        own_group = True
+    iters, warm, out = max(1, a.leg_train_iters), 10, {}
+    try:
+        for tag, dt, ms in (("dt.01_max400", 0.01, 400.0), ("dt.001_max4000", 0.001, 4000.0)):
+            torch.manual_seed(0)
+            amortizer = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+            with GraphTrainer(amortizer, batch_size=a.batch, total_steps=warm + 2 * iters, dt=dt, max_steps=ms, seed=2023, device=dev,
+                              world=1, rank=0, parallel="gather", backend="nccl", split=bool(gather_rccl)) as gt:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gt.train_online(warm + iters)                              # captures a graph whenever N falls into a new bucket
+                torch.cuda.synchronize()
+                t_first = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                gt.train_online(iters)
+                t_host = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                h = gt.loss_history()
+                out[tag] = {"iterations_per_s": iters / el, "ms_per_iteration": el / iters * 1e3, "iterations": iters,
+                            "host_enqueue_ms_per_iteration": t_host / iters * 1e3, "gpu_bound": bool(t_host < 0.9 * el),
+                            "first_pass_ms_per_iteration_with_captures": t_first / (warm + iters) * 1e3, "graphs_captured": gt.n_graphs,
+                            "loss_first10": float(np.mean(h[:10])), "loss_last10": float(np.mean(h[-10:])),
+                            "all_losses_finite": bool(np.all(np.isfinite(h))), "pipelined_feed": bool(gt.overlap),
+                            "pipelined_feed_independent_queues": list(gt.independent_queues),
+                            "collective": "all_gather_into_tensor (RCCL, world 1) between the simulate graph and the training graph"
+                                          if gather_rccl else None}
+    finally:
+        if own_group:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+    return out
+
+
+def simulate_bench(a, ctx):
+    world, rank, dev, torch, dist, engine, _lib, prior_util = (ctx[k] for k in ("world", "rank", "dev", "torch", "dist", "engine",
+                                                                                   "_lib", "prior_util"))
+    B, N = a.sets, a.trials
+    fast, packed = a.gauss != "exact", a.gauss == "packed"
+    if packed and MODELS[a.model][1]:
+        sys.exit("--gauss packed cannot be combined with the bridge correction")
+    model_attr, bridge, prior_fn, _, tau_i = MODELS[a.model]
+    model_id = getattr(engine, model_attr)
+    dist_on = ctx["dist_on"]
+    # synthetic inputs: the reference prior (basic_ddm_dc.py:62-80 / single_trial_alpha_not_scaled.py:78-102 /
+    # alpha_not_scaled.py:66-72), default_rng(2023 + rank), resident in HBM
+    t_prior = time.perf_counter()
+    p_host = getattr(prior_util, prior_fn)(B, 2023 + rank)
+    p_dev = torch.as_tensor(p_host).to(dev)
+    t_prior = time.perf_counter() - t_prior
+    # per-rank host work before the timed region: N ranks share the node's host cores (vectorised draws: ~0.2 s per 1M rows on one)
+    print(f"bench.py: rank {rank}/{world} on cuda:{torch.cuda.current_device()}: {B} parameter rows drawn on the host and copied in "
+          f"{t_prior:.2f} s", file=sys.stderr, flush=True)
+    run = simulate_pass(a, ctx, p_dev, B, a.gather, a.steps, a.warmup, summary_only=a.summary_only)
+    elapsed, kern_ms, geometry, overlap, codes, step = (run[k] for k in ("elapsed", "kernel_ms", "geometry", "overlap", "codes", "step"))
+    out_trials, out_summary = run["trials"], run["summary"]
+    # ---- everything below is OUTSIDE the headline's timed region
+    ident = rank_identity(a, ctx, t_prior, run) if dist_on else None            # (a collective: every rank takes part)
+    side = {}
+    if dist_on and not a.no_legs and a.model == "basic" and not a.summary_only and a.gather == "none":
+        # What the default multi-GPU command leaves out, as short timed passes of the same code (every rank takes part): north_star's
+        # minibatch all-gather in its two practical forms, and the strong-scaling point (a FIXED 1M-set batch split over the ranks)
+        del run
+        k_steps, k_warm, nxt = 4, 1, a.warmup + a.steps
+        for g in ("summary", "codes"):
+            r = simulate_pass(a, ctx, p_dev, B, g, k_steps, k_warm, first_step=nxt)
+            nxt += k_steps + k_warm
+            side["gather_" + g] = {"value": world * B * N * k_steps / r["elapsed"], "unit": "trials/s", "ms_per_step": r["elapsed"] / k_steps * 1e3,
+                                   "kernel_ms": r["kernel_ms"], "steps": k_steps, "warmup": k_warm, "scaling": "weak",
+                                   "bytes_gathered_per_rank_per_step": world * B * (engine.SUMMARY_K * 4 if g == "summary" else (N * 2 + p_host.shape[1] * 4)),
+                                   "what": ("all-gather of the fused summaries f32[B,10]" if g == "summary" else
+                                            "all-gather of the trials as 2-byte codes + the parameter rows, decoded to f32[world*B,N,2] on every rank")
+                                           + (" on a communication stream, double-buffered (inside the timed region)" if r["overlap"] else " (serialised)")}
+            del r
+        Bs = -(-B // world)                                  # the headline's per-GPU batch (1M sets by default) as the FIXED total
+        r = simulate_pass(a, ctx, p_dev, Bs, "none", k_steps, k_warm, first_step=nxt)
+        side["strong"] = {"sets_total": Bs * world, "sets_per_gpu": Bs, "value": world * Bs * N * k_steps / r["elapsed"], "unit": "trials/s",
+                          "ms_per_step": r["elapsed"] / k_steps * 1e3, "kernel_ms": r["kernel_ms"], "steps": k_steps, "warmup": k_warm,
+                          "scaling": "strong", "what": f"a fixed batch of {Bs * world} parameter sets x {N} trials split over the ranks, no gather"}
+        del r
     if rank != 0:
         return
 
@@ -572,10 +800,15 @@ def simulate_bench(a, ctx):
         res["roofline"]["traffic"] = tr["bytes"]
         res["roofline"]["traffic_source"] = tr["source"]
     res["host_prior_seconds_rank0"] = t_prior
+    res["toolchain"] = toolchain(torch)
+    if ident is not None:
+        res["dist"] = ident
+    if side:
+        res["side_legs"] = side
     if world > 1:
         # the per-kernel analysis belongs to the one-GPU line: these objects are measured at N = 1 only (their absence here is
         # by design, not a failure); `roofline` (the contract's object) and `launch` are on every line
-        res["n1_only"] = ["roofline_valu", "occupancy", "ks_vs_ref", "packed_gauss", "cpu_baseline", "gpu_over_cpu_1core"]
+        res["n1_only"] = ["roofline_valu", "occupancy", "ks_vs_ref", "packed_gauss", "cpu_baseline", "gpu_over_cpu_1core", "legs"]
     if world == 1:
         achieved_steps = em_steps / (kern_ms * 1e-3)
         rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
@@ -659,6 +892,24 @@ def simulate_bench(a, ctx):
                                    "ks_vs_ref": ks_vs_golden(engine, a.model, a.dt, a.max_steps, True, True),
                                    "what": "same workload with flags |= NDDM_GAUSS_PACKED (opt-in: 8 normals per Philox block from "
                                            "16 + 16 bit Box-Muller pairs; include/nddm.h), 3 launches outside the timed region"}
+        if not a.no_legs and a.model == "basic" and a.gauss == "fast" and not a.summary_only:
+            # the OTHER BASELINE configs under this same command (and the driver's clock), each outside the headline's timed
+            # region: configs[3] single-trial + fused summaries (and summaries alone), configs[2] alpha_not_scaled with the bridge,
+            # configs[4] the training loop at one rank and in its RCCL all-gather form
+            t_legs = time.perf_counter()
+            legs = {"single": simulator_leg(a, ctx, "single", out_trials, out_summary, with_summary_only=True),
+                    "alpha_ns_bridge": simulator_leg(a, ctx, "alpha_ns_bridge", out_trials, out_summary)}
+            from bayesflow_nddms_amd import _train_lib
+            one, gat = training_leg(a, ctx, False), training_leg(a, ctx, True)
+            legs["train"] = {"metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE configs[4])",
+                             "value": one["dt.01_max400"]["iterations_per_s"], "unit": "iterations/s",
+                             "workload": f"basic_ddm_dc online training feed: {a.batch} sets per step, N ~ U{{60..300}} per batch, device prior -> "
+                                         "simulate -> DeepSet + 6-layer coupling flow -> Adam, one hipGraph replay per iteration "
+                                         "(graph_trainer.GraphTrainer); value = one rank at the reference's default dt=.01 / 400",
+                             "training_kernels": "libnddm_train.so" if _train_lib.lib() is not None else "PyTorch (library not built)",
+                             "one_rank": one, "gather_rccl_world1": gat}
+            legs["wall_seconds"] = time.perf_counter() - t_legs
+            res["legs"] = legs
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, p_host, a.model, N, a.dt, a.max_steps, a.cpu_seconds)
             res["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
@@ -863,7 +1114,7 @@ def train_bench(a, ctx):
                        "train_mode": a.train_mode,
                        # libnddm_train.so (flow, summary network, optimizer step as HIP kernels) or the PyTorch composition
                        "training_kernels": "libnddm_train.so" if _train_lib.lib() is not None else "PyTorch (library not built)"},
-            "loss_first10": ref["loss_first10"], "loss_last10": ref["loss_last10"],
+            "loss_first10": ref["loss_first10"], "loss_last10": ref["loss_last10"], "toolchain": toolchain(torch),
             "train": results})
 
 

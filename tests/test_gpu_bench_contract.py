@@ -12,11 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--sets", "30000", "--cpu-seconds", "0.5", "--cpu-sample"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--sets", "30000", "--cpu-seconds", "0.5", "--cpu-sample", "--leg-launches", "2", "--leg-train-iters", "40"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # exactly ONE JSON line
     d = json.loads(lines[0])
+    _check_legs(d)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -33,6 +35,36 @@ def test_bench_json_contract():
     assert 0 < rv["frac"] < 1.05 and rv["ceiling_measured_steps_per_s"] > 0           # ceiling measured in the same run
     assert "arithmetic" in d["config"] and d["cpu_baseline"]["numpy_port"]["reference_default"]["dt"] == 0.01
     assert d["config"]["gauss"] == "fast" and d["packed_gauss"]["ks_vs_ref"]["max"] < 0.01     # opt-in mode: beside, not as, the headline
+
+
+def _check_legs(d):
+    """The default N = 1 line carries EVERY BASELINE config, not only configs[1]: `legs.single` (configs[3]: trials + fused summaries,
+    and summaries alone), `legs.alpha_ns_bridge` (configs[2]) and `legs.train` (configs[4]: the graph trainer at one rank and in its
+    RCCL all-gather form, at both step sizes) -- each with its rate, kernel time, KS distance against the reference fixtures WITH its
+    bar, and the VALU roofline against the lockstep ceiling of its own kernel variant, all measured in this run."""
+    legs = d["legs"]
+    for name, kernel in (("single", "sim_kernel<1 (single_trial)"), ("alpha_ns_bridge", "bridge>")):
+        leg = legs[name]
+        assert leg["unit"] == "trials/s" and leg["value"] > 1e8 and leg["kernel_ms"] > 0 and kernel in leg["kernel"], (name, leg["value"])
+        assert abs(leg["value"] - 30000 * 300 / (leg["kernel_ms"] * 1e-3)) / leg["value"] < 1e-6
+        ks = leg["ks_vs_ref"]
+        assert ks["bar"] == 0.01 and ks["max"] < ks["bar"] and ks["meets_bar"] is True, (name, ks["max"])
+        assert 0 < leg["roofline_valu"]["frac"] < 1.05 and leg["roofline_valu"]["ceiling_lane_efficiency"] > 0.9
+        assert leg["roofline"]["bound"] == "hbm" and 0 < leg["roofline"]["frac"] < 1 and leg["em_steps_per_trial"] > 50
+    so = legs["single"]["summary_only"]
+    assert so["value"] >= 0.95 * legs["single"]["value"] and so["kernel_ms"] > 0          # no 8 B per trial: never slower
+    tr = legs["train"]
+    assert tr["unit"] == "iterations/s" and tr["training_kernels"] == "libnddm_train.so"
+    assert tr["value"] == tr["one_rank"]["dt.01_max400"]["iterations_per_s"]
+    for form in ("one_rank", "gather_rccl_world1"):
+        for tag in ("dt.01_max400", "dt.001_max4000"):
+            t = tr[form][tag]
+            assert t["iterations_per_s"] > 500 and t["all_losses_finite"] and t["loss_last10"] < t["loss_first10"], (form, tag, t)
+            assert t["pipelined_feed"] is True and t["graphs_captured"] >= 2
+            assert (t["collective"] is not None) == (form == "gather_rccl_world1")
+    assert legs["wall_seconds"] < 60
+    tc = d["toolchain"]
+    assert tc["hip_runtime"] and tc["hipcc"] and tc["torch"] and tc["rccl"] and "libamdhip64" in tc["hip_runtime_library"]
 
 
 @pytest.mark.parametrize("model", ["single", "alpha_ns_bridge"])
@@ -76,12 +108,24 @@ def test_bench_many_ranks_rehearsal_names_what_an_n_gpu_line_omits():
     r = _bench("--gpus", "5", "--share-device", "--backend", "gloo", "--sets", "20000", "--steps", "3", "--warmup", "1", env=env)
     d = _one_line(r)
     assert d["n_gpus"] == 5 and d["scaling"] == "weak" and "roofline" in d and "launch" in d
+    # the line says WHO ran it: the backend the process group reports, one entry per rank with its device and its own times
+    ds = d["dist"]
+    assert ds["backend"] == "gloo" and ds["world"] == 5 and [r_["rank"] for r_ in ds["ranks"]] == [0, 1, 2, 3, 4]
+    assert len({r_["pid"] for r_ in ds["ranks"]}) == 5 and all(r_["device"] == "cuda:0" and r_["kernel_ms"] > 0 and r_["elapsed_s"] > 0
+                                                                and r_["host_prior_s"] >= 0 for r_ in ds["ranks"])
+    assert ds["distinct_devices"] == 1 and ds["imbalance"]["kernel_ms_max_over_min"] >= 1.0       # (the rehearsal: five ranks, ONE card)
+    # ... and carries what the collective-free weak-scaling headline leaves out: north_star's all-gather (two forms) and the strong point
+    sl = d["side_legs"]
+    for k in ("gather_summary", "gather_codes"):
+        assert sl[k]["scaling"] == "weak" and sl[k]["value"] > 0 and sl[k]["bytes_gathered_per_rank_per_step"] > 0
+        assert abs(sl[k]["value"] - 5 * 20000 * 300 / (sl[k]["ms_per_step"] * 1e-3)) / sl[k]["value"] < 1e-6
+    assert sl["strong"]["scaling"] == "strong" and sl["strong"]["sets_total"] == 20_000 and sl["strong"]["sets_per_gpu"] == 4_000
     assert abs(d["value"] - 5 * 20000 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert set(d["n1_only"]) >= {"roofline_valu", "ks_vs_ref", "cpu_baseline"} and not (set(d["n1_only"]) & set(d))
-    seen = [l for l in r.stderr.splitlines() if l.startswith("bench.py: rank ")]
-    assert sorted(int(l.split()[2].split("/")[0]) for l in seen) == [0, 1, 2, 3, 4] and all("/5 on cuda:0" in l for l in seen)
+    import re                          # (five processes share one stderr pipe: a line may start in the middle of another's)
+    assert sorted(int(m) for m in re.findall(r"bench\.py: rank (\d+)/5 on cuda:0", r.stderr)) == [0, 1, 2, 3, 4]
     one = _one_line(_bench("--sets", "20000", "--steps", "2", "--warmup", "1", "--no-ceiling", "--no-ks", "--no-cpu-baseline", env=env))
-    assert "n1_only" not in one and one["host_prior_seconds_rank0"] < 5.0
+    assert "n1_only" not in one and one["host_prior_seconds_rank0"] < 5.0 and "dist" not in one and "side_legs" not in one
 
 
 def _one_line(r):
@@ -104,6 +148,7 @@ def test_bench_rccl_branch_runs_at_world_1(gather):
     plain = _one_line(_bench(*common, env=env))
     d = _one_line(_bench("--dist", "--backend", "nccl", "--gather", gather, *common, env=env))
     assert d["n_gpus"] == 1 and "distributed code path forced at world 1 (nccl)" in d["config"]["parallelism"]
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["rccl_version"] and d["dist"]["world"] == 1 and d["dist"]["ranks"][0]["pci_bus_id"]
     assert f"gather={gather}" in d["config"]["parallelism"] and "communication stream" in d["config"]["parallelism"]
     assert abs(d["value"] / plain["value"] - 1.0) < (0.02 if gather == "summary" else 0.05), (d["value"], plain["value"])
     # and serialised on the simulate stream (the round-2 form) it still runs

@@ -72,3 +72,30 @@ def test_issue_model_reads_the_shipped_library():
         assert sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
     t = im.tally(im.step_loop(im.kernel_insts(txt, im.KERNELS["basic_packed"])), cost, sgpr_cost)
     assert 95 <= t["valu"] <= 105 and sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc missing")
+def test_toolchain_probes_compile(tmp_path):
+    """The workarounds that blame the toolchain name a TRACKED probe each (tools/probe_buffer_load_b128.hip, tools/probe_graph_memset_node.py,
+    tools/probe_stream_validation.py; their MI355X outputs are under profiles/).  The b128 claim is checkable without a GPU: this
+    hipcc compiles __builtin_amdgcn_raw_buffer_load_b128 to buffer_load_dword -- one dword, not four.  If a toolchain update makes
+    this test fail, the builtin has been fixed and RowTile (csrc/train_deepset.hip) may take 16-byte loads again."""
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "tools", "probe_buffer_load_b128.hip")
+    asm = tmp_path / "probe.s"
+    r = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = asm.read_text()
+    b128 = text[text.index("copy_b128"):text.index("copy_b32")] if text.index("copy_b128") < text.index("copy_b32") else text[text.index("copy_b128"):]
+    assert "buffer_load_dwordx4" not in b128 and "buffer_load_dword " in b128, "the b128 builtin now loads 16 bytes: drop the workaround"
+    exe = tmp_path / "probe"
+    r = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-o", str(exe), src], capture_output=True, text=True)
+    assert r.returncode == 0 and exe.exists(), r.stderr[-2000:]
+    for py in ("probe_graph_memset_node.py", "probe_stream_validation.py"):
+        compile(open(os.path.join(ROOT, "tools", py)).read(), py, "exec")
+    # every workaround comment names its probe
+    for rel, needle in (("bayesflow_nddms_amd/csrc/train_deepset.hip", "tools/probe_buffer_load_b128.hip"),
+                        ("bayesflow_nddms_amd/csrc/nddm_kernels.hip", "tools/probe_graph_memset_node.py"),
+                        ("bayesflow_nddms_amd/csrc/nddm_kernels.hip", "tools/probe_stream_validation.py")):
+        assert needle in open(os.path.join(ROOT, rel)).read(), (rel, needle)
