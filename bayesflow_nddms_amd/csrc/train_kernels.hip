@@ -548,12 +548,17 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
     f32x16 dW2;
 #pragma unroll
     for (int q = 0; q < 16; ++q) dW2[q] = 0.0f;
-    float dW1[DI_MAX / 8], dW3[M_MAX / 8];
-    float db2 = 0.0f, db1 = 0.0f, db3 = 0.0f;
+    // The sums one thread carries through ALL rows in sequence -- the three bias gradients, dW1, dW3 (and the ActNorm's below) -- are
+    // accumulated in float64: a sequential float32 sum of R same-signed terms loses ~R/2 ulps where PyTorch's tree reduction loses
+    // log2 R, measured as 3 .. 12 x PyTorch's error against a float64 evaluation on the bias gradients (tools/fused_accuracy.py,
+    // profiles/r5_fused_accuracy.txt).  A handful of f64 adds per row tile in a kernel whose time is load latency; the products stay f32
+    // (exact in f64).  dW2 is the MFMA chain -- the same K-long f32 accumulation a GEMM makes: at PyTorch's error already.
+    double dW1[DI_MAX / 8], dW3[M_MAX / 8];
+    double db2 = 0.0, db1 = 0.0, db3 = 0.0;
 #pragma unroll
-    for (int q = 0; q < DI_MAX / 8; ++q) dW1[q] = 0.0f;
+    for (int q = 0; q < DI_MAX / 8; ++q) dW1[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < M_MAX / 8; ++q) dW3[q] = 0.0f;
+    for (int q = 0; q < M_MAX / 8; ++q) dW3[q] = 0.0;
     for (int r0 = 0; r0 < Q.R; r0 += TR) {
         if (r0) __syncthreads();          // the previous tile's readers are done
         // every load unconditional, from a clamped row, ALL of them issued before the first is used (a guarded load -- `ok ? p[o] : 0`
@@ -589,15 +594,15 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
         for (int q = 0; q < M_MAX / 8; ++q) {
             const int m = 8 * q + g;
             if (m < M) {
-                float acc = dW3[q];
+                double acc = dW3[q];
 #pragma unroll 8
-                for (int r = 0; r < TR; ++r) acc = fmaf(do_s[r][m], h2r[r][j], acc);
+                for (int r = 0; r < TR; ++r) acc = fma((double)do_s[r][m], (double)h2r[r][j], acc);
                 dW3[q] = acc;
             }
         }
         if (t < M) {
 #pragma unroll 4
-            for (int r = 0; r < TR; ++r) db3 += do_s[r][t];
+            for (int r = 0; r < TR; ++r) db3 += (double)do_s[r][t];
         }
         {   // layer 2, dW2[jo][i] += sum_r da2[r][jo] h1[r][i].  Lane l: A[jo = l & 31][k = l >> 5], B[k][i = l & 31];
             // the sum's order is free, so step s takes rows r = 16 k + s (A and B alike)
@@ -608,22 +613,22 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
         }
         if (t < H) {
 #pragma unroll 8
-            for (int r = 0; r < TR; ++r) db2 += da2r[r][t];
+            for (int r = 0; r < TR; ++r) db2 += (double)da2r[r][t];
         }
         // layer 1: thread (row j, columns c = g, g + 8, ...)
 #pragma unroll
         for (int q = 0; q < DI_MAX / 8; ++q) {
             const int c = 8 * q + g;
             if (c < DI) {
-                float acc = dW1[q];
+                double acc = dW1[q];
 #pragma unroll 8
-                for (int r = 0; r < TR; ++r) acc = fmaf(da1r[r][j], in_s[r][c], acc);
+                for (int r = 0; r < TR; ++r) acc = fma((double)da1r[r][j], (double)in_s[r][c], acc);
                 dW1[q] = acc;
             }
         }
         if (g == 0) {
 #pragma unroll 8
-            for (int r = 0; r < TR; ++r) db1 += da1r[r][j];
+            for (int r = 0; r < TR; ++r) db1 += (double)da1r[r][j];
         }
     }
     {   // dW2's tile: register v of lane l is row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31
@@ -633,24 +638,24 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
         for (int v = 0; v < 16; ++v) o[((v & 3) + 8 * (v >> 2)) * H] = dW2[v];
     }
 #pragma unroll
-    for (int q = 0; q < DI_MAX / 8; ++q) { const int c = 8 * q + g; if (c < DI) X.gW1[j * DI + c] = dW1[q]; }
+    for (int q = 0; q < DI_MAX / 8; ++q) { const int c = 8 * q + g; if (c < DI) X.gW1[j * DI + c] = (float)dW1[q]; }
 #pragma unroll
-    for (int q = 0; q < M_MAX / 8; ++q) { const int m = 8 * q + g; if (m < M) X.gW3[(long long)m * H + j] = dW3[q]; }
-    if (t < H) X.gb2[t] = db2;
-    if (g == 0) X.gb1[j] = db1;
-    if (t < M) X.gb3[t] = db3;
+    for (int q = 0; q < M_MAX / 8; ++q) { const int m = 8 * q + g; if (m < M) X.gW3[(long long)m * H + j] = (float)dW3[q]; }
+    if (t < H) X.gb2[t] = (float)db2;
+    if (g == 0) X.gb1[j] = (float)db1;
+    if (t < M) X.gb3[t] = (float)db3;
     if (X.norm < 0) return;
     // the ActNorm's parameters: 32 threads per column, fixed order
     const NormW &N = T.norm[X.norm];
     if (t < 32 * D) {
         const int c = t >> 5, i = t & 31, p = N.perm[c];
         const float ex = expf(N.scale[p]);
-        float sb = 0.0f, ss = 0.0f, sd = 0.0f;
+        double sb = 0.0, ss = 0.0, sd = 0.0;                 // (f64 sums: as above)
         for (int row = i; row < Q.R; row += 32) {
             const float gv = N.gz[(long long)row * D + c];
-            sb += gv;
-            ss = fmaf(gv * ex, N.x[(long long)row * D + p], ss);
-            sd += g_ld[row];
+            sb += (double)gv;
+            ss = fma((double)(gv * ex), (double)N.x[(long long)row * D + p], ss);
+            sd += (double)g_ld[row];
         }
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) {
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
             ss += __shfl_xor(ss, m, 32);
             sd += __shfl_xor(sd, m, 32);
         }
-        if (i == 0) { N.gbias[p] = sb; N.gscale[p] = ss + sd; }
+        if (i == 0) { N.gbias[p] = (float)sb; N.gscale[p] = (float)(ss + sd); }
     }
 }
 

@@ -10,7 +10,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bayesflow_nddms_amd.amortizer import InvertibleNetwork            # noqa: E402
+from bayesflow_nddms_amd.amortizer import InvariantNetwork, InvertibleNetwork            # noqa: E402
 
 
 def err(a, e):
@@ -21,7 +21,7 @@ def err(a, e):
 def main():
     torch.manual_seed(3)
     print(f"{'layers':>6} {'rows':>5} {'D':>2} {'scale':>5} | {'tensor':10} | {'max fused':>10} {'max torch':>10} {'ratio':>6} | {'rms fused':>10} {'rms torch':>10} {'ratio':>6} | max |f64|")
-    worst_max, worst_rms = {}, {}
+    worst_max, worst_rms, by_kind = {}, {}, {}
     for scale in (1.0, 1.5, 3.0):
         for layers, R, D in ((1, 32, 5), (2, 77, 5), (6, 256, 5), (6, 32, 8), (6, 32, 7), (6, 32, 5), (2, 4001, 5), (6, 512, 7)):
             for rep in range(3):
@@ -47,6 +47,16 @@ def main():
                     net.fused = fused
                     out[fused] = run(net, theta, cond)
                 ex = run(net64, th64, c64)
+                # which KIND of parameter carries the weight-gradient error (RMS ratio fused / pytorch, worst layer of each kind)
+                kinds = {}
+                for (name, _), a, b, e in zip(net.named_parameters(), out[True]["d weights"], out[False]["d weights"], ex["d weights"]):
+                    parts = name.split(".")                    # layers.<i>.net1.<k>.weight -> net1.<k>.weight; an_scale.<i> -> an_scale
+                    kind = ".".join(parts[2:]) if parts[0] == "layers" else parts[0]
+                    kinds[kind] = max(kinds.get(kind, 0.0), err(a, e)[1] / max(err(b, e)[1], 1e-300))
+                for k_, v_ in kinds.items():
+                    by_kind[k_] = max(by_kind.get(k_, 0.0), v_)
+                if rep == 0:
+                    print("        d weights by kind (RMS ratio):", {k_: round(v_, 2) for k_, v_ in kinds.items()})
                 for key in ex:
                     rows = [(err(a, e), err(b, e), float(e.abs().max())) for a, b, e in zip(out[True][key], out[False][key], ex[key])]
                     # the tensor of the group where the fused kernel is worst relative to PyTorch (RMS)
@@ -59,6 +69,52 @@ def main():
     print("largest ratio fused / pytorch-f32 of the error against f64 over all cases (3 networks per shape):")
     print("  max-norm:", {k: round(v, 2) for k, v in worst_max.items()})
     print("  RMS     :", {k: round(v, 2) for k, v in worst_rms.items()})
+    print("  d weights by kind of parameter, RMS:", {k: round(v, 2) for k, v in by_kind.items()})
+    deepset()
+
+
+def deepset():
+    """The summary network's kernels (csrc/train_deepset.hip) the same way: summary and every parameter gradient, by parameter."""
+    torch.manual_seed(5)
+    print("\nsummary network (DeepSet): error against f64, fused / pytorch-f32 (RMS ratio), per parameter; [blocks, sets, trials, real trials]")
+    worst = {}
+    for blocks, B, N, n_real in ((2, 32, 300, 237), (2, 32, 300, None), (2, 32, 60, None), (1, 5, 131, 131), (2, 4, 129, 64), (0, 7, 200, 77), (2, 256, 300, 180)):
+        for rep in range(3):
+            net = InvariantNetwork(num_equiv=blocks).cuda()
+            with torch.no_grad():
+                for p in net.parameters():
+                    if p.dim() == 1:
+                        p.copy_(0.1 * torch.randn_like(p))
+            net64 = copy.deepcopy(net).double()
+            x = torch.stack([0.3 + torch.rand(B, N, device="cuda") * 2.0, (torch.rand(B, N, device="cuda") < 0.7).float()], dim=-1)
+            mask = inv_n = mask64 = inv64 = None
+            if n_real is not None:
+                mask = (torch.arange(N, device="cuda") < n_real).float().view(1, N, 1)
+                inv_n = torch.tensor(1.0 / n_real, device="cuda")
+                mask64, inv64 = mask.double(), inv_n.double()
+            w = torch.randn(B, net.summary_dim, device="cuda")
+
+            def run(n, xx, m, iv):
+                out = n(xx, m, iv)
+                return [out.detach()] + [t.detach() for t in torch.autograd.grad((out * w.to(out.dtype)).sum(), list(n.parameters()))]
+
+            res = {}
+            for fused in (True, False):
+                net.fused = fused
+                res[fused] = run(net, x, mask, inv_n)
+            ex = run(net64, x.double(), mask64, inv64)
+            names = ["summary"] + [n_ for n_, _ in net.named_parameters()]
+            ratios = {}
+            for name, a, b, e in zip(names, res[True], res[False], ex):
+                parts = name.split(".")
+                kind = name if name == "summary" else ".".join(p_ for p_ in parts if not (p_.isdigit() and parts.index(p_) == 1))
+                r_ = err(a, e)[1] / max(err(b, e)[1], 1e-300)
+                ratios[kind] = max(ratios.get(kind, 0.0), r_)
+                worst[kind] = max(worst.get(kind, 0.0), r_)
+            if rep == 0:
+                top = sorted(ratios.items(), key=lambda kv: -kv[1])[:6]
+                print(f"  [{blocks}, {B}, {N}, {n_real}] summary {ratios['summary']:.2f}; largest: " + ", ".join(f"{k} {v:.2f}" for k, v in top))
+    print("  largest RMS ratio per parameter over all cases:", {k: round(v, 2) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])})
 
 
 if __name__ == "__main__":
