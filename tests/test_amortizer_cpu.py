@@ -206,3 +206,36 @@ def test_the_graph_runs_position_travels_in_the_trainers_checkpoint(tmp_path):
     r2 = np.random.default_rng(0)
     r2.bit_generator.state = got["replay"]["rng"]
     assert r2.integers(1 << 30) == rng.integers(1 << 30)
+
+
+def test_the_flows_inverse_is_exact_in_the_tails_of_z():
+    """The wild posterior draws of a sharply trained flow (tools/locate_tail_draws.py) are points the learned
+    density really covers, not an arithmetic fault of sample(): the inverse -- soft clamp, ActNorm and permutations included -- undoes
+    the forward for base draws far in the tails too.  On a network made ill-conditioned on purpose (weights x 1.5, ActNorms away from
+    the identity, log-scales at the clamp's bound) and z out to 8 standard deviations: forward(inverse(z)) == z to 1e-9 in float64,
+    the float32 inverse agrees with the float64 one to float32 round-off RELATIVE to the size of what it returns (values up to 1e4 and
+    beyond), and log q(theta) of such a draw is the finite number the change-of-variables formula gives."""
+    import copy
+    torch.manual_seed(11)
+    net = InvertibleNetwork(num_params=7, num_coupling_layers=6, seed=3)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.5)
+        for p in list(net.an_scale) + list(net.an_bias):
+            p.copy_(0.3 * torch.randn_like(p))
+    net64 = copy.deepcopy(net).double()
+    cond = torch.randn(1, 11).expand(4000, 11).contiguous()
+    z = 2.0 * torch.randn(4000, 7)                                      # tails out to ~8 sigma of the base density
+    assert float(z.abs().max()) > 6.0
+    with torch.no_grad():
+        x32 = net.inverse(z, cond)
+        x64 = net64.inverse(z.double(), cond.double())
+        back, log_det = net64(x64, cond.double())
+    assert torch.isfinite(x64).all() and torch.isfinite(log_det).all()
+    assert float((back - z.double()).abs().max()) < 1e-9 * (1.0 + float(x64.abs().max()))
+    scale = x64.abs().amax(dim=1, keepdim=True) + 1.0
+    assert float(((x32.double() - x64).abs() / scale).max()) < 5e-4          # f32 round-off amplified by an ill-conditioned inverse
+    far = x64.abs().amax(dim=1) > 50.0 * float(x64.abs().amax(dim=1).median())
+    assert int(far.sum()) >= 1                                          # the runaway region exists in an UNtrained net too
+    # each clamped log-scale is bounded by 1.9: |log det| <= layers * D * 1.9 + the ActNorms'
+    assert float(log_det.abs().max()) <= 6 * 7 * 1.9 + float(sum(p.detach().abs().sum() for p in net.an_scale)) + 1e-6

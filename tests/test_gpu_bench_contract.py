@@ -144,7 +144,8 @@ def test_bench_rccl_branch_runs_at_world_1(gather):
     the device-side all_reduce(MAX) of the elapsed time -- every distributed call `bench.py --gpus 8` makes.  The line says
     n_gpus 1 and its value is the plain run's (the collective of one rank is a copy, overlapped with the next simulate)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    common = ["--sets", "300000", "--steps", "6", "--warmup", "2", "--no-ceiling", "--no-ks", "--no-cpu-baseline"]
+    # (20 timed steps of ~10 ms: with 6 -- 60 ms of timed region -- one hiccup of the box read as a 27 % gap once in round 5)
+    common = ["--sets", "300000", "--steps", "20", "--warmup", "3", "--no-ceiling", "--no-ks", "--no-cpu-baseline", "--no-legs"]
     plain = _one_line(_bench(*common, env=env))
     d = _one_line(_bench("--dist", "--backend", "nccl", "--gather", gather, *common, env=env))
     assert d["n_gpus"] == 1 and "distributed code path forced at world 1 (nccl)" in d["config"]["parallelism"]
@@ -154,6 +155,14 @@ def test_bench_rccl_branch_runs_at_world_1(gather):
     # and serialised on the simulate stream (the round-2 form) it still runs
     e = _one_line(_bench("--dist", "--backend", "nccl", "--gather", gather, "--no-overlap", *common, env=env))
     assert e["n_gpus"] == 1 and "communication stream" not in e["config"]["parallelism"]
+    if gather == "summary":
+        # the driver's PLAIN command over RCCL (gather none): the line carries the all-gather and strong-scaling side legs, and -- at
+        # world 1 -- the N = 1 legs too, whose RCCL training form joins the process group that is already up
+        f = _one_line(_bench("--dist", "--backend", "nccl", "--sets", "30000", "--steps", "2", "--warmup", "1", "--no-ceiling", "--no-ks",
+                             "--no-cpu-baseline", "--leg-launches", "1", "--leg-train-iters", "30", env=env))
+        assert f["dist"]["backend"] == "nccl" and set(f["side_legs"]) == {"gather_summary", "gather_codes", "strong"}
+        assert all(v["value"] > 0 and v["kernel_ms"] > 0 for v in f["side_legs"].values()) and f["side_legs"]["strong"]["sets_total"] == 30000
+        assert f["legs"]["train"]["gather_rccl_world1"]["dt.01_max400"]["iterations_per_s"] > 300
 
 
 def test_bench_gather_summary_overlapped_costs_nothing_on_two_ranks():

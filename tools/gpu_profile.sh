@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-ks $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-ks --no-legs $*"       # (the headline kernel alone; the legs have a trace pass of their own below)
 echo "python3 bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
 i=0
@@ -23,4 +23,10 @@ for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR S
   rocprofv3 --kernel-trace --pmc $PMC -d "$OUT/pmc$i" -o bench --output-format csv -- python3 bench.py $ARGS --no-ceiling > "$OUT/bench_pmc$i.json" 2> "$OUT/pmc$i.err" || { echo "pmc pass $i failed"; tail -3 "$OUT/pmc$i.err"; }
   echo "pmc pass $i done"
 done
+# the default command WITH its side legs (every BASELINE config in one trace): tools/legs_trace_summary.py
+if [ -z "$*" ]; then
+  LEGS="--steps 5 --warmup 1 --no-cpu-baseline --no-ks --no-ceiling"
+  echo "python3 bench.py $LEGS" > "$OUT/command_legs.txt"
+  rocprofv3 --kernel-trace --stats -d "$OUT/trace_legs" -o bench --output-format csv -- python3 bench.py $LEGS > "$OUT/bench_trace_legs.json" 2> "$OUT/trace_legs.err" || { tail -5 "$OUT/trace_legs.err"; }
+fi
 find "$OUT" -name "*.csv" | head -50
