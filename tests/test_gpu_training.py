@@ -29,6 +29,46 @@ def test_online_training_on_device_simulator():
     assert post.shape == (1000, 5) and np.all(np.isfinite(post))
 
 
+def test_posterior_mean_recovery_floor_on_the_references_statistic():
+    """The recovery loop of basic_ddm_dc.py:211-241 on the reference's own statistic -- posterior MEANS, Pearson rho and r2_score per
+    parameter, the "converged" count -- after 20 000 graph-replayed iterations of the reference's training call (6 s; the reference runs
+    500 000): a floor on the means (profiles/r4_recovery.txt reads .94 .77 .90 .95 .68 at this length), the means and the medians
+    agreeing wherever no draw lies far outside the prior's range, and training / evaluation parameter rows disjoint by construction."""
+    import torch
+    from scipy import stats
+    from sklearn.metrics import r2_score
+    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    from bayesflow_nddms_amd.graph_trainer import TRAIN_OFFSET_BASE, GraphTrainer
+    torch.manual_seed(0)
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+    with GraphTrainer(am, batch_size=32, total_steps=20000, seed=2023, offset_base=TRAIN_OFFSET_BASE) as gt:
+        gt.train_experience_replay(20000)
+        h = np.array(gt.loss_history())
+    assert np.all(np.isfinite(h)) and h[-200:].mean() < -8.0, h[-200:].mean()
+    np.random.seed(2023)
+    gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+    am.eval()
+    true, means, meds, far = [], [], [], []
+    lo, hi = torch.tensor([-10.0, 0.0, 0.0, 0.0, 0.0], device="cuda"), torch.tensor([10.0, 10.0, 1.0, 1.5, 10.0], device="cuda")
+    for _ in range(300):
+        conf = basic_ddm_dc.configurator(gm(1))
+        post = am.sample(conf, 2000, to_numpy=False)
+        true.append(conf["parameters"][0].cpu().numpy()); means.append(post.mean(0).cpu().numpy()); meds.append(post.median(0).values.cpu().numpy())
+        far.append(bool(((post < lo - (hi - lo)) | (post > hi + (hi - lo))).any()))       # a draw more than a prior width outside the prior's range
+    true, means, meds, far = np.array(true, np.float64), np.array(means, np.float64), np.array(meds, np.float64), np.array(far)
+    clean = ~far
+    assert clean.sum() >= 290, f"{int(far.sum())} of 300 data sets hold a wild draw: far above the ~1e-6 per draw of DESIGN.md section 8"
+    rho = np.array([stats.pearsonr(true[clean, j], means[clean, j])[0] for j in range(5)])
+    r2 = np.array([r2_score(true[clean, j], means[clean, j]) for j in range(5)])
+    rho_med = np.array([stats.pearsonr(true[clean, j], meds[clean, j])[0] for j in range(5)])
+    assert np.all(rho > np.array([0.88, 0.62, 0.80, 0.90, 0.55])), rho           # drift, boundary, beta, tau, dc
+    assert r2[0] > 0.75 and r2[3] > 0.8, r2
+    assert np.abs(rho - rho_med).max() < 0.02, (rho, rho_med)                  # means == medians where no tail draw interferes
+    converged = (means[:, 3] > 0) & (means[:, 3] < 1)                          # basic_ddm_dc.py:239-241
+    assert converged.sum() >= 0.93 * len(means), converged.sum()              # (P(tau > 1) = 2.3 % under the prior)
+
+
 def test_prefetched_online_training_sees_the_same_batches():
     """train_online(prefetch=True) simulates batch i+1 on a side stream while batch i is trained on.  Same seeds =>
     the same batches in the same order => the same loss curve as without prefetching, the same simulator stream state
