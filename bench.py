@@ -562,8 +562,11 @@ def rank_identity(a, ctx, t_prior, run):
     except Exception:                                               # noqa: BLE001 -- a build without it
         rccl = None
     km, el = [r["kernel_ms"] for r in ranks], [r["elapsed_s"] for r in ranks]
+    distinct = len({(r["pci_bus_id"], r["device"]) for r in ranks})
+    if distinct < world and not a.share_device:
+        print(f"bench.py: WARNING: {world} ranks ran on {distinct} distinct device(s)", file=sys.stderr, flush=True)
     return {"backend": str(dist.get_backend()), "world": dist.get_world_size(), "rccl_version": rccl,
-            "distinct_devices": len({(r["pci_bus_id"], r["device"]) for r in ranks}), "ranks": ranks,
+            "distinct_devices": distinct, "every_rank_on_a_device_of_its_own": bool(distinct == world), "ranks": ranks,
             "imbalance": {"kernel_ms_max_over_min": max(km) / min(km), "elapsed_max_over_min": max(el) / min(el)}}
 
 
