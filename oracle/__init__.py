@@ -19,22 +19,40 @@ SUMMARY_K = 10
 _lib = None
 
 
+def _src_hash():
+    import hashlib
+    with open(_SRC, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def build(force=False):
-    """gcc the oracle into oracle/liboracle.so (contraction off: every fma is spelled out)."""
-    if (not force and os.path.exists(_SO)
-            and (not os.path.exists(_SRC) or os.path.getmtime(_SO) >= os.path.getmtime(_SRC))):
-        return _SO
+    """gcc the oracle into oracle/liboracle.so (contraction off: every fma is spelled out).  Stale = built from other source CONTENT
+    than the tree's (the hash is kept beside the library: a snapshot copied to the GPU box has arbitrary file times)."""
+    stamp = _SO + ".srchash"
+    if not force and os.path.exists(_SO) and os.path.exists(_SRC):
+        try:
+            if open(stamp).read().strip() == _src_hash():
+                return _SO
+        except OSError:
+            pass
+    elif not force and os.path.exists(_SO):
+        return _SO                                           # (a prebuilt library without its source beside it)
+    tmp = f"{_SO}.{os.getpid()}.tmp"
     cmd = ["gcc", "-O2", "-ffp-contract=off", "-mfma", "-fno-math-errno", "-fopenmp", "-fPIC", "-shared",
-           "-o", _SO, _SRC, "-lm"]
+           "-o", tmp, _SRC, "-lm"]
     subprocess.check_call(cmd)
+    os.replace(tmp, _SO)
+    with open(stamp, "w") as f:
+        f.write(_src_hash())
     return _SO
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        # NDDM_ORACLE_LIB: another build of the same source (tests/test_oracle_golden.py runs the oracle's battery under
+        # AddressSanitizer + UndefinedBehaviorSanitizer in a child process)
+        L = ctypes.CDLL(os.environ.get("NDDM_ORACLE_LIB") or build())
         L.oracle_mt_seed.argtypes = [ctypes.c_uint32]
         L.oracle_mt_double.restype = ctypes.c_double
         L.oracle_mt_gauss.restype = ctypes.c_double
