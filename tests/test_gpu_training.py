@@ -58,7 +58,7 @@ def test_posterior_mean_recovery_floor_on_the_references_statistic():
         far.append(bool(((post < lo - (hi - lo)) | (post > hi + (hi - lo))).any()))       # a draw more than a prior width outside the prior's range
     true, means, meds, far = np.array(true, np.float64), np.array(means, np.float64), np.array(meds, np.float64), np.array(far)
     clean = ~far
-    assert clean.sum() >= 290, f"{int(far.sum())} of 300 data sets hold a wild draw: far above the ~1e-6 per draw of DESIGN.md section 8"
+    assert clean.sum() >= 290, f"{int(far.sum())} of 300 data sets hold a wild draw: far above the 4e-7 .. 8e-7 per draw of DESIGN.md section 8"
     rho = np.array([stats.pearsonr(true[clean, j], means[clean, j])[0] for j in range(5)])
     r2 = np.array([r2_score(true[clean, j], means[clean, j]) for j in range(5)])
     rho_med = np.array([stats.pearsonr(true[clean, j], meds[clean, j])[0] for j in range(5)])
