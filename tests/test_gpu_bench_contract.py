@@ -151,7 +151,9 @@ def test_bench_rccl_branch_runs_at_world_1(gather):
     assert d["n_gpus"] == 1 and "distributed code path forced at world 1 (nccl)" in d["config"]["parallelism"]
     assert d["dist"]["backend"] == "nccl" and d["dist"]["rccl_version"] and d["dist"]["world"] == 1 and d["dist"]["ranks"][0]["pci_bus_id"]
     assert f"gather={gather}" in d["config"]["parallelism"] and "communication stream" in d["config"]["parallelism"]
-    assert abs(d["value"] / plain["value"] - 1.0) < (0.02 if gather == "summary" else 0.05), (d["value"], plain["value"])
+    # (measured over rounds 3-5: summary within 0.2-1 %, trials / codes within 1-3 % of the plain run; two separate processes on a box
+    #  whose run-to-run jitter is ~1 %: the bars are 4 % / 6 %)
+    assert abs(d["value"] / plain["value"] - 1.0) < (0.04 if gather == "summary" else 0.06), (d["value"], plain["value"])
     # and serialised on the simulate stream (the round-2 form) it still runs
     e = _one_line(_bench("--dist", "--backend", "nccl", "--gather", gather, "--no-overlap", *common, env=env))
     assert e["n_gpus"] == 1 and "communication stream" not in e["config"]["parallelism"]
