@@ -167,6 +167,13 @@ CHUNK = 10_000
 # KAT tier
 # ---------------------------------------------------------------------------
 def make_kat():
+    out = compute_kat()
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
+    print("kat.npz:", {k: np.shape(v) for k, v in out.items()})
+
+
+def compute_kat():
+    """The known answers as a dict, nothing written (tests/test_oracle_golden.py re-derives them whenever the reference is mounted)."""
     out = {}
     b = load_slice("basic_sim")
     # (1) the reference's own call shape: simulate_trials(params, 300), default dt=.01/400
@@ -245,8 +252,7 @@ def make_kat():
 
     out["basic_sets"] = BASIC_SETS
     out["single_sets"] = SINGLE_SETS
-    np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
-    print("kat.npz:", {k: np.shape(v) for k, v in out.items()})
+    return out
 
 
 def _basic_trial(ns, p, dt, ms):
