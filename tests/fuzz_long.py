@@ -1,6 +1,6 @@
 """A long run of the randomised bit-parity check (tests/test_gpu_fuzz.py draws 90 cases; this draws cases for a given number of
 minutes from seeds the suite does not use): GPU exact mode vs the CPU oracle, every bit of trials, summaries and external datum.
-usage: python tools/fuzz_long.py [minutes=8] [first_seed=5000]     (prints progress; exit code 1 at the first mismatch)"""
+usage: python tests/fuzz_long.py [minutes=8] [first_seed=5000]     (prints progress; exit code 1 at the first mismatch)"""
 import os
 import sys
 import time

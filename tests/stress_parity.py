@@ -1,5 +1,5 @@
 """Larger-scale bit parity of the GPU exact mode against the oracle than the small unit cases (ordering pre-pass
-active, many queue chunks, ring wrap-around, split sets), every model, both bit layouts, default tuning.  `python tools/stress_parity.py`
+active, many queue chunks, ring wrap-around, split sets), every model, both bit layouts, default tuning.  `python tests/stress_parity.py`
 runs all sizes (~80M trials, ~20 s on one MI355X + 16 host threads); tests/test_gpu_fuzz.py runs a subset."""
 import os
 import sys

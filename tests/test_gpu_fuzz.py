@@ -61,10 +61,10 @@ def test_fuzz_bit_parity(chunk):
 
 
 def test_stress_parity_subset():
-    """tools/stress_parity.py at two sizes per model: the ordering pre-pass (B >= 2048), a multi-chunk queue and a set
+    """tests/stress_parity.py at two sizes per model: the ordering pre-pass (B >= 2048), a multi-chunk queue and a set
     split into tiles (N = 700), against the oracle, every bit."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import stress_parity
     assert stress_parity.run(sizes=((6000, 300), (2500, 700)), verbose=False, threads=8) == []

@@ -114,6 +114,18 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src and "ddm_oracle" not in src, f
+    # ... nor may tools/ or examples/ (checker programs that need the oracle -- the long fuzz run, the stress parity run -- live under
+    # tests/); bench.py uses it in cpu_baseline() only and __graft_entry__ in smoke() / build() only
+    for sub in ("tools", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".c", ".h", ".hip")):
+                    src = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M) and "liboracle" not in src, os.path.join(sub, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"^\s*(import|from)\s+oracle\b", bench, flags=re.M)]
+    lo, hi = bench.index("def cpu_baseline("), bench.index("def ks_vs_golden(")
+    assert uses and all(lo < u < hi for u in uses), "bench.py may touch the oracle inside cpu_baseline() only"
 
 
 def test_validation_and_stream_state():
