@@ -781,9 +781,11 @@ def posterior_estimates(amortizer, generative_model, configurator, n_datasets=10
 def posterior_recovery(amortizer, generative_model, configurator, n_datasets=100, n_samples=1000, statistic="mean"):
     """The recovery loop of basic_ddm_dc.py:218-223 in miniature: posterior means vs true parameters -> per-parameter
     Pearson correlation (the reference plots R^2 / rho, pyhddmjagsutils.py:609-623).  statistic="median": the posterior median
-    instead -- the inverse of a sharply trained flow can carry a tail draw of z far outside the prior's range, and ONE such draw
-    among a data set's thousand moves its mean (and one such data set among hundreds the correlation) while the posterior's
-    bulk sits on the truth."""
+    instead.  A sharply trained flow carries ~5e-7 of its mass at |theta| up to 1e6 (regions maximum-likelihood training never
+    visits: once the inverse's intermediate vector leaves the trained range, the conditioners' log-scales flip sign and every
+    remaining half-layer multiplies by e^1.9; the inverse is exact there -- DESIGN.md section 8, tools/locate_tail_draws.py), and ONE
+    such draw among a data set's ten thousand moves its mean (and one such data set among hundreds the correlation) while the
+    posterior's bulk sits on the truth.  The mean is the reference's statistic and the default here."""
     if statistic not in ("mean", "median"):
         raise ValueError("statistic must be 'mean' or 'median'")
     true, means, meds = posterior_estimates(amortizer, generative_model, configurator, n_datasets, n_samples)
