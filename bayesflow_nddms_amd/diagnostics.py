@@ -71,3 +71,29 @@ def ks_quantile_table(sample, q_table):
     f_emp_hi = np.arange(1, n + 1) / n
     f_emp_lo = np.arange(0, n) / n
     return float(max(np.max(np.abs(f_emp_hi - f_ref)), np.max(np.abs(f_emp_lo - f_ref))))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The numbers the reference's recovery plots print (the consumer of amortizer.sample on the other side of the path)
+def recovery_statistics(theta_true, theta_est):
+    """Per parameter, what `recovery_scatter` writes into its panels (pyhddmjagsutils.py:609-623): R^2 = sklearn's r2_score(true,
+    estimate) -- 1 - SS_res / SS_tot about the mean of the TRUE values, negative when the estimates are worse than that mean -- and
+    Pearson's rho.  theta_true, theta_est: [n_datasets, P] (the reference passes posterior MEANS: basic_ddm_dc.py:236-250).
+    -> {'r2': [P], 'rho': [P]}."""
+    t, e = np.asarray(theta_true, dtype=np.float64), np.asarray(theta_est, dtype=np.float64)
+    if t.shape != e.shape or t.ndim != 2:
+        raise ValueError(f"theta_true and theta_est must both be [n_datasets, P]; got {t.shape} and {e.shape}")
+    ss_res = ((t - e) ** 2).sum(axis=0)
+    ss_tot = ((t - t.mean(axis=0)) ** 2).sum(axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r2 = np.where(ss_tot > 0, 1.0 - ss_res / ss_tot, np.where(ss_res == 0, 1.0, 0.0))      # (r2_score's convention for a constant target)
+        tc, ec = t - t.mean(axis=0), e - e.mean(axis=0)
+        rho = (tc * ec).sum(axis=0) / np.sqrt((tc ** 2).sum(axis=0) * (ec ** 2).sum(axis=0))
+    return {"r2": r2, "rho": rho}
+
+
+def converged_fits(param_means, index=3, low=0.0, high=1.0):
+    """The reference's "clearly good" filter (basic_ddm_dc.py:239-241, single_trial_alpha_not_scaled.py:326-328): model fits whose
+    posterior MEAN of the non-decision time (parameter 3 in both models) lies inside (0, 1) -> boolean [n_datasets]."""
+    m = np.asarray(param_means, dtype=np.float64)
+    return (m[:, index] > low) & (m[:, index] < high)

@@ -35,9 +35,7 @@ def test_posterior_mean_recovery_floor_on_the_references_statistic():
     500 000): a floor on the means (profiles/r4_recovery.txt reads .94 .77 .90 .95 .68 at this length), the means and the medians
     agreeing wherever no draw lies far outside the prior's range, and training / evaluation parameter rows disjoint by construction."""
     import torch
-    from scipy import stats
-    from sklearn.metrics import r2_score
-    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd import basic_ddm_dc, diagnostics as dg
     from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
     from bayesflow_nddms_amd.graph_trainer import TRAIN_OFFSET_BASE, GraphTrainer
     torch.manual_seed(0)
@@ -59,13 +57,12 @@ def test_posterior_mean_recovery_floor_on_the_references_statistic():
     true, means, meds, far = np.array(true, np.float64), np.array(means, np.float64), np.array(meds, np.float64), np.array(far)
     clean = ~far
     assert clean.sum() >= 290, f"{int(far.sum())} of 300 data sets hold a wild draw: far above the 4e-7 .. 8e-7 per draw of DESIGN.md section 8"
-    rho = np.array([stats.pearsonr(true[clean, j], means[clean, j])[0] for j in range(5)])
-    r2 = np.array([r2_score(true[clean, j], means[clean, j]) for j in range(5)])
-    rho_med = np.array([stats.pearsonr(true[clean, j], meds[clean, j])[0] for j in range(5)])
+    st = dg.recovery_statistics(true[clean], means[clean])               # (the reference's r2_score / pearsonr: pyhddmjagsutils.py:609-623)
+    rho, r2, rho_med = st["rho"], st["r2"], dg.recovery_statistics(true[clean], meds[clean])["rho"]
     assert np.all(rho > np.array([0.88, 0.62, 0.80, 0.90, 0.55])), rho           # drift, boundary, beta, tau, dc
     assert r2[0] > 0.75 and r2[3] > 0.8, r2
     assert np.abs(rho - rho_med).max() < 0.02, (rho, rho_med)                  # means == medians where no tail draw interferes
-    converged = (means[:, 3] > 0) & (means[:, 3] < 1)                          # basic_ddm_dc.py:239-241
+    converged = dg.converged_fits(means)                                       # basic_ddm_dc.py:239-241
     assert converged.sum() >= 0.93 * len(means), converged.sum()              # (P(tau > 1) = 2.3 % under the prior)
 
 

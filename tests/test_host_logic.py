@@ -437,3 +437,24 @@ def test_all_gather_form_follows_the_backend_and_errors_surface(monkeypatch):
     with pytest.raises(RuntimeError, match="unhandled system error"):
         D.all_gather_rows(x, 5)
     assert fd.calls == ["flat"]                            # nothing was attempted after the failure
+
+
+def test_recovery_statistics_are_the_reference_plots_numbers():
+    """diagnostics.recovery_statistics == what pyhddmjagsutils.recovery_scatter prints (sklearn r2_score and scipy pearsonr per
+    parameter, :609-623), including R^2 far below zero when one estimate is carried off; converged_fits == basic_ddm_dc.py:239-241."""
+    from scipy import stats
+    from sklearn.metrics import r2_score
+    from bayesflow_nddms_amd import diagnostics as dg
+    rng = np.random.default_rng(3)
+    true = rng.normal(size=(200, 5)) * np.array([2.0, 0.5, 0.2, 0.25, 0.5]) + np.array([0.0, 1.0, 0.5, 0.5, 1.0])
+    est = true + 0.3 * rng.normal(size=true.shape) * np.array([2.0, 0.5, 0.2, 0.25, 0.5])
+    est[17, 1] = -1.4e6                                                 # one posterior mean carried off by a tail draw
+    got = dg.recovery_statistics(true, est)
+    for j in range(5):
+        assert abs(got["r2"][j] - r2_score(true[:, j], est[:, j])) <= 1e-9 * max(1.0, abs(got["r2"][j]))
+        assert abs(got["rho"][j] - stats.pearsonr(true[:, j], est[:, j])[0]) < 1e-12
+    assert got["r2"][1] < -1e6 and got["r2"][0] > 0.8
+    conv = dg.converged_fits(est)
+    assert conv.dtype == bool and conv.sum() == ((est[:, 3] > 0) & (est[:, 3] < 1)).sum()
+    with pytest.raises(ValueError):
+        dg.recovery_statistics(true, est[:, :4])

@@ -22,8 +22,7 @@ from bayesflow_nddms_amd.graph_trainer import TRAIN_OFFSET_BASE, GraphTrainer   
 
 def recovery(am, mod, names, n_datasets=500, n_draws=10000):
     """basic_ddm_dc.py:211-241.  Returns (true [n, P], posterior means, posterior medians, number of trials per data set)."""
-    from sklearn.metrics import r2_score
-    from scipy import stats
+    from bayesflow_nddms_amd import diagnostics as dg
     np.random.seed(2023)                                    # (:217; the batch-shared N comes from NumPy's global generator)
     gm = mod.make_generative_model(batched=True, device_prior=True, as_numpy=False)
     torch.manual_seed(1234)                                 # the base draws z (tools/locate_tail_draws.py re-creates them from this seed)
@@ -37,10 +36,9 @@ def recovery(am, mod, names, n_datasets=500, n_draws=10000):
         meds.append(post.median(0).values.cpu().numpy())
         n_trials.append(conf["summary_conditions"].shape[1])
     true, means, meds = np.array(true, dtype=np.float64), np.array(means, dtype=np.float64), np.array(meds, dtype=np.float64)
-    P = true.shape[1]
-    r2 = lambda est: np.round([r2_score(true[:, j], est[:, j]) for j in range(P)], 3)
-    rho = lambda est: np.round([stats.pearsonr(true[:, j], est[:, j])[0] for j in range(P)], 3)
-    converged = (means[:, 3] > 0) & (means[:, 3] < 1)       # :239-241 (index 3 = the non-decision time in both models)
+    r2 = lambda est: np.round(dg.recovery_statistics(true, est)["r2"], 3)          # (== sklearn r2_score / scipy pearsonr per parameter:
+    rho = lambda est: np.round(dg.recovery_statistics(true, est)["rho"], 3)        #  tests/test_host_logic.py)
+    converged = dg.converged_fits(means)                    # :239-241 (index 3 = the non-decision time in both models)
     carried = (np.abs(means - meds) > 5.0 * (np.abs(meds) + 1.0)).any(axis=1)
     print(f"recovery: {n_datasets} fresh data sets x {n_draws} posterior draws ({time.time() - t1:.1f} s); mean number of simulated trials "
           f"{np.mean(n_trials):.0f} +/- {np.std(n_trials):.2f}; parameters: {names}\n"
