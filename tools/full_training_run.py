@@ -6,7 +6,8 @@ the reference's size and on the reference's statistic: 500 fresh data sets, 10 0
 parameters -> r2_score and Pearson rho per parameter (recovery_scatter, pyhddmjagsutils.py:609-623) and the "converged" count (posterior
 mean of the non-decision time inside (0, 1), :239-241).  Medians are printed beside the means, never instead of them.
 Prints the time and loss per 50 epochs.  `single`: the same for single_trial_alpha_not_scaled.py:284-287 (7 parameters, data (choicert, z1)).
-usage: python tools/full_training_run.py [epochs=500] [basic|single] [file to save the trained amortizer's state_dict to]"""
+usage: python tools/full_training_run.py [epochs=500] [basic|single] [file to save the trained amortizer's state_dict to | -] [run=0]
+(run r > 0: another initialisation, torch.manual_seed(r), and another training stream, seed 2023 + r; the recovery data sets stay the same)"""
 import os
 import sys
 import time
@@ -55,13 +56,14 @@ def recovery(am, mod, names, n_datasets=500, n_draws=10000):
 def main():
     epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     model = sys.argv[2] if len(sys.argv) > 2 else "basic"
+    run = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     per_epoch, chunk = 1000, 50
-    torch.manual_seed(0)
+    torch.manual_seed(run)
     am = AmortizedPosterior(InvertibleNetwork(num_params=5 if model == "basic" else 7), InvariantNetwork())
     t0 = time.time()
     # (training's parameter sets start at TRAIN_OFFSET_BASE of the seed's index space: the recovery loop's generative model draws
     #  its rows from 0 up and never meets them)
-    with GraphTrainer(am, model=model, batch_size=32, total_steps=epochs * per_epoch, seed=2023, offset_base=TRAIN_OFFSET_BASE) as gt:
+    with GraphTrainer(am, model=model, batch_size=32, total_steps=epochs * per_epoch, seed=2023 + run, offset_base=TRAIN_OFFSET_BASE) as gt:
         for e0 in range(0, epochs, chunk):
             n = min(chunk, epochs - e0) * per_epoch
             gt.train_experience_replay(n)
@@ -73,7 +75,7 @@ def main():
     total = time.time() - t0
     print(f"{len(h)} iterations ({len(h) * 32:.3g} data sets) in {total:.1f} s = {len(h) / total:.0f} it/s; nan {int(np.isnan(h).sum())}; "
           f"loss first 1000 {h[:1000].mean():.3f}, last 1000 {h[-1000:].mean():.3f}", flush=True)
-    if len(sys.argv) > 3:
+    if len(sys.argv) > 3 and sys.argv[3] != "-":
         torch.save(am.state_dict(), sys.argv[3])
     if model == "basic":
         mod, names = basic_ddm_dc, "drift, boundary, beta, tau, dc"
