@@ -387,6 +387,24 @@ def test_numpy_results_go_through_pinned_memory_and_equal_the_device_tensors():
     assert col.shape == (2000, 300) and np.array_equal(col, keep[..., 0])
     assert np.array_equal(engine.to_host(dev["sim_data"][:3]), keep[:3])                        # (small: the plain route)
     assert engine.to_host(torch.arange(4)).tolist() == [0, 1, 2, 3] and engine.to_host([1, 2]).tolist() == [1, 2]
+    # the opt-out for callers that KEEP many large results (pinned blocks are rounded up to powers of two and cached): pageable memory,
+    # same bits -- per call, or for the process (engine.PINNED_RESULTS / NDDM_PINNED_RESULTS=0); and the cache can be handed back
+    stats = lambda: torch._C._cuda_hostMemoryStats() if hasattr(torch._C, "_cuda_hostMemoryStats") else None
+    before = stats()
+    pageable = engine.to_host(dev["sim_data"], pinned=False)
+    assert np.array_equal(pageable, keep)
+    if before is not None and "allocated_bytes.current" in before:
+        assert stats()["allocated_bytes.current"] == before["allocated_bytes.current"]          # nothing new was pinned for it
+    chunked = engine.simulate_to_host(engine.BASIC_DDM_DC, p, 300, seed=9, set_offset=0, chunk_bytes=1 << 20, pinned=False)
+    assert np.array_equal(chunked["trials"], keep)
+    try:
+        engine.PINNED_RESULTS = False
+        assert np.array_equal(basic_ddm_dc.batch_simulate_trials(p, 300, seed=9, set_offset=0)["sim_data"], keep)
+    finally:
+        engine.PINNED_RESULTS = True
+    del host, other, col
+    gc.collect()
+    assert engine.release_pinned_cache() is True
 
 
 def test_chunked_results_to_the_host_equal_one_launch():
