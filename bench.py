@@ -900,12 +900,23 @@ def simulate_bench(a, ctx):
             # region: configs[3] single-trial + fused summaries (and summaries alone), configs[2] alpha_not_scaled with the bridge,
             # configs[4] the training loop at one rank and in its RCCL all-gather form
             t_legs = time.perf_counter()
-            legs = {"single": simulator_leg(a, ctx, "single", out_trials, out_summary, with_summary_only=True),
-                    "alpha_ns_bridge": simulator_leg(a, ctx, "alpha_ns_bridge", out_trials, out_summary)}
+
+            def guarded(fn, *args, **kw):
+                """A side leg that raises must not cost the line its headline: the leg then reads {"error": ...} (and the traceback
+                goes to standard error); tests/test_gpu_bench_contract.py asserts that no leg does."""
+                try:
+                    return fn(*args, **kw)
+                except Exception as e:                                      # noqa: BLE001
+                    import traceback
+                    traceback.print_exc(file=sys.stderr)
+                    return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+            legs = {"single": guarded(simulator_leg, a, ctx, "single", out_trials, out_summary, with_summary_only=True),
+                    "alpha_ns_bridge": guarded(simulator_leg, a, ctx, "alpha_ns_bridge", out_trials, out_summary)}
             from bayesflow_nddms_amd import _train_lib
-            one, gat = training_leg(a, ctx, False), training_leg(a, ctx, True)
+            one, gat = guarded(training_leg, a, ctx, False), guarded(training_leg, a, ctx, True)
             legs["train"] = {"metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE configs[4])",
-                             "value": one["dt.01_max400"]["iterations_per_s"], "unit": "iterations/s",
+                             "value": one.get("dt.01_max400", {}).get("iterations_per_s"), "unit": "iterations/s",
                              "workload": f"basic_ddm_dc online training feed: {a.batch} sets per step, N ~ U{{60..300}} per batch, device prior -> "
                                          "simulate -> DeepSet + 6-layer coupling flow -> Adam, one hipGraph replay per iteration "
                                          "(graph_trainer.GraphTrainer); value = one rank at the reference's default dt=.01 / 400",

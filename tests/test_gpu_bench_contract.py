@@ -43,6 +43,8 @@ def _check_legs(d):
     RCCL all-gather form, at both step sizes) -- each with its rate, kernel time, KS distance against the reference fixtures WITH its
     bar, and the VALU roofline against the lockstep ceiling of its own kernel variant, all measured in this run."""
     legs = d["legs"]
+    assert not any("error" in (legs[k] if isinstance(legs[k], dict) else {}) for k in legs) and "error" not in legs["train"]["one_rank"] \
+        and "error" not in legs["train"]["gather_rccl_world1"], legs
     for name, kernel in (("single", "sim_kernel<1 (single_trial)"), ("alpha_ns_bridge", "bridge>")):
         leg = legs[name]
         assert leg["unit"] == "trials/s" and leg["value"] > 1e8 and leg["kernel_ms"] > 0 and kernel in leg["kernel"], (name, leg["value"])
