@@ -746,7 +746,20 @@ def simulate_bench(a, ctx):
         # minibatch all-gather in its two practical forms, and the strong-scaling point (a FIXED 1M-set batch split over the ranks)
         del run
         k_steps, k_warm, nxt = 4, 1, a.warmup + a.steps
+
+        def every_rank_has(nbytes):
+            """A side leg runs only if EVERY rank has the device memory for it (decided collectively: a leg that one rank skipped
+            and another entered would wait in its collective forever)."""
+            free = torch.cuda.mem_get_info(dev)[0]
+            ok = torch.tensor([1 if free > nbytes * 1.25 + (1 << 30) else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return bool(ok.item())
+
         for g in ("summary", "codes"):
+            need = 2 * (B * N * (8 if g == "summary" else 2) + world * B * (engine.SUMMARY_K * 4 if g == "summary" else N * 10))
+            if not every_rank_has(need):
+                side["gather_" + g] = {"skipped": f"needs {need / 1e9:.1f} GB of device memory on every rank"}
+                continue
             r = simulate_pass(a, ctx, p_dev, B, g, k_steps, k_warm, first_step=nxt)
             nxt += k_steps + k_warm
             side["gather_" + g] = {"value": world * B * N * k_steps / r["elapsed"], "unit": "trials/s", "ms_per_step": r["elapsed"] / k_steps * 1e3,
