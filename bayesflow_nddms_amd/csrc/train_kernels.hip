@@ -414,8 +414,11 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
             const int r = t / Dt, d = t - r * Dt, row = r0 + r;
             // second: the gradient of out[:, :d1]; first: of out[:, d1:] plus what came through net 2's conditioning input
             const float gg = second ? gout_s[r][d] : gout_s[r][d1 + d] + gy2_s[r][d];
-            const float es = expf(ns), u = ns / Q.clamp;
-            const float d_os = row < Q.R ? fmaf(gg * nx, es, ngl) * (1.0f - u * u) : 0.0f, d_t = row < Q.R ? gg : 0.0f;
+            // d s / d o = 1 - tanh^2 = (clamp - s)(clamp + s) / clamp^2: the DIFFERENCE clamp - s is exact where it matters (a log-scale
+            // near the clamp's bound: Sterbenz), whereas 1 - (s / clamp)^2 rounds the quotient and its square first -- three times
+            // PyTorch's error on saturated units (it keeps tanh's own output), and a sharply trained flow sits at the bound
+            const float es = expf(ns), dclamp = (Q.clamp - ns) * (Q.clamp + ns) / (Q.clamp * Q.clamp);
+            const float d_os = row < Q.R ? fmaf(gg * nx, es, ngl) * dclamp : 0.0f, d_t = row < Q.R ? gg : 0.0f;
             gz_s[r][second ? d : d1 + d] = gg * es;      // d z of the transformed half (the other half: the input gradient below)
             do_s[r][d] = d_os;
             do_s[r][Dt + d] = d_t;
