@@ -37,7 +37,11 @@ __device__ int g_nstamps;
 #endif
 
 __device__ __forceinline__ float elu(float v) { return v > 0.0f ? v : expm1f(v); }
-__device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }   // alpha = 1
+// ELU' from the saved PRE-activation: exp(a) itself.  (Until round 5 the forward saved the OUTPUT h and the backward took h + 1: an
+// absolute 2^-24 on a factor that can be far below 1 -- PyTorch keeps the input -- which left the activation-gradient chain at ~2 x
+// PyTorch's error against float64, tools/fused_accuracy.py.  The saved tensors h_all now hold a = W in + b; the weight-gradient kernel
+// re-derives h = elu(a) when it stages its tiles.)
+__device__ __forceinline__ float elu_grad_from_pre(float a) { return a > 0.0f ? 1.0f : expf(a); }   // alpha = 1
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid = ceil(R / 16) workgroups of 512 threads over tiles of 16 rows (two workgroups at batch 32: every product then fills the
@@ -199,13 +203,13 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 4 * kk + q;
-                    const float v0 = elu(acc0[q] + b10);
+                    const float a0 = acc0[q] + b10, v0 = elu(a0);
                     h1r[r][u0] = v0;
-                    bh1.put(r * H + u0, v0);
+                    bh1.put(r * H + u0, a0);
                     if constexpr (UW == 32) {
-                        const float v1 = elu(acc1[q] + b11);
+                        const float a1 = acc1[q] + b11, v1 = elu(a1);
                         h1r[r][u1] = v1;
-                        bh1.put(r * H + u1, v1);
+                        bh1.put(r * H + u1, a1);
                     }
                 }
             }
@@ -257,13 +261,13 @@ __global__ __launch_bounds__(NT) void flow_fwd_kernel(FlowDims Q, FlowP P, const
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 4 * kk + q;
-                    const float v0 = elu(acc0[q] + b20);
+                    const float a0 = acc0[q] + b20, v0 = elu(a0);
                     h2r[r][u0] = v0;
-                    bh2.put(r * H + u0, v0);
+                    bh2.put(r * H + u0, a0);
                     if constexpr (UW == 32) {
-                        const float v1 = elu(acc1[q] + b21);
+                        const float a1 = acc1[q] + b21, v1 = elu(a1);
                         h2r[r][u1] = v1;
-                        bh2.put(r * H + u1, v1);
+                        bh2.put(r * H + u1, a1);
                     }
                 }
             }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                    // D: unit 16 ib + (l & 15), row 16 rb + 4 (l >> 4) + register
                 const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
-                const float v = acc[q] * elu_grad_from_out(h2r[r][i]);
+                const float v = acc[q] * elu_grad_from_pre(h2r[r][i]);
                 da2r[r][i] = v;
                 bda2.put(r * H + i, v);
             }
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(NTD) void flow_dgrad_kernel(FlowDims Q, FlowD T, Fl
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 16 * rb + 4 * kk + q, i = 16 * ib + n;
-                const float v = acc[q] * elu_grad_from_out(h1r[r][i]);
+                const float v = acc[q] * elu_grad_from_pre(h1r[r][i]);
                 h2r[r][i] = v;
                 bda1.put(r * H + i, v);
             }
@@ -585,8 +589,8 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
         for (int k = 0; k < TR * H / NTB; ++k) {         // (rows beyond R: zero)
             const int r = g + 8 * k;
             const bool ok = r0 + r < Q.R;
-            h1r[r][j] = ok ? v1[k] : 0.0f;
-            h2r[r][j] = ok ? v2[k] : 0.0f;
+            h1r[r][j] = ok ? elu(v1[k]) : 0.0f;          // (the saved tensors hold the pre-activations)
+            h2r[r][j] = ok ? elu(v2[k]) : 0.0f;
             da2r[r][j] = ok ? v3[k] : 0.0f;
             da1r[r][j] = ok ? v4[k] : 0.0f;
         }
@@ -670,15 +674,15 @@ __global__ __launch_bounds__(NTB) void flow_wgrad_kernel(FlowDims Q, FlowW T, co
     }
 }
 
-// mean over the rows of |z|^2 / 2 - log|det| (fixed summation order)
+// mean over the rows of |z|^2 / 2 - log|det| (fixed summation order; the running sums in float64: one workgroup, latency-bound)
 __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *ld, int R, int D, float *out)
 {
-    __shared__ float red[256];
-    float a = 0.0f;
+    __shared__ double red[256];
+    double a = 0.0;
     for (int r = threadIdx.x; r < R; r += 256) {
-        float q = 0.0f;
-        for (int c = 0; c < D; ++c) q = fmaf(z[(long long)r * D + c], z[(long long)r * D + c], q);
-        a += 0.5f * q - ld[r];
+        double q = 0.0;
+        for (int c = 0; c < D; ++c) { const double v = (double)z[(long long)r * D + c]; q = fma(v, v, q); }
+        a += 0.5 * q - (double)ld[r];
     }
     red[threadIdx.x] = a;
     __syncthreads();
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256) void nll_kernel(const float *z, const float *l
         if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0] / (float)R;
+    if (threadIdx.x == 0) *out = (float)(red[0] / (double)R);
 }
 
 }  // namespace nddm_train
@@ -714,7 +718,7 @@ static void fill(FlowP &P, int L, int D, const void *const *params, const int *p
     }
 }
 
-/* -> z = out_all[L - 1] and ld [R] (log|det|, ActNorm terms included); z_all / out_all / s_all [L, R, D] and h_all [L, 4, R, H]
+/* -> z = out_all[L - 1] and ld [R] (log|det|, ActNorm terms included); z_all / out_all / s_all [L, R, D] and h_all [L, 4, R, H] (the PRE-activations of the coupling nets' two hidden layers)
  * are what the backward needs.  nll (may be NULL): the maximum-likelihood loss, mean over the rows of |z|^2 / 2 - log|det|. */
 int nddm_train_flow_fwd(int L, int R, int D, int d1, int C, float clamp, const void *const *params, const int *perm,
                         const float *theta, const float *cond, float *z_all, float *out_all, float *s_all, float *h_all, float *ld,

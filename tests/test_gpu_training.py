@@ -502,12 +502,12 @@ def test_fused_flow_equals_the_pytorch_path():
     pooled relative rms error <= 2 x PyTorch's + 32 ulp, no single case off by more than 8 x), for one and six layers and row counts
     that are not a multiple of the kernels' 8- and 32-row tiles and span several of them, on flows made ill-conditioned on purpose;
     and the fused forward's z goes back through the FLOAT64 inverse (the round trip).  Shapes the kernels do not cover fall back.
-    Measured on the MI355X (round 5, after the weight-gradient kernel's running sums went to f64 and the clamp's derivative to its
-    exact-difference form), pooled rms error fused / pytorch: flow form z 1.10, log|det| 0.88, d theta 1.70, d cond 1.10, d weights
-    1.28, d biases 1.44, d ActNorm 1.73; loss form 1.56 / 1.90 / 1.49 / 1.90 / 2.15 / 2.05 (loss, d theta, d cond, d weights, d biases,
-    d ActNorm: the last two pass on the 32-ulp term); round trip 1.41.  What is left is the backward chain re-deriving ELU' from the
-    saved OUTPUT (h + 1 where PyTorch keeps the input: an absolute 2^-24 on a factor that can be far below 1).  (Before: bias
-    gradients 3 .. 12 x PyTorch's error -- a sequential f32 sum over the rows against a tree.)"""
+    Measured on the MI355X, pooled rms error fused / pytorch (round 5, after three accuracy fixes the yardstick found: the
+    weight-gradient kernel's running sums in f64 -- bias gradients were 3 .. 12 x PyTorch's error, a sequential f32 sum over the rows
+    against a tree --, the clamp's derivative as an exact difference, and ELU' from the saved PRE-activation instead of output + 1):
+    flow form z 1.10, log|det| 0.88, d theta 1.45, d cond 0.99, d weights 1.11, d biases 1.22, d ActNorm 1.42; loss form 1.51 / 1.80 /
+    1.40 / 1.79 / 2.01 / 1.93 (loss, d theta, d cond, d weights, d biases, d ActNorm -- its gradient seeds are the forward's own z,
+    which weights the ill-conditioned rows); round trip 1.41."""
     import copy
     import torch
     from bayesflow_nddms_amd import _train_lib
