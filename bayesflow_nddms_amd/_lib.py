@@ -6,8 +6,8 @@ import os
 from .build import SO_PATH
 
 NDDM_OK, NDDM_ERR_NULL, NDDM_ERR_SHAPE, NDDM_ERR_PARAM, NDDM_ERR_HIP, NDDM_ERR_NO_DEVICE = range(6)
-GAUSS_EXACT, GAUSS_FAST, BRIDGE, GAUSS_PACKED = 0, 1, 2, 4
-ABI_VERSION = 3
+GAUSS_EXACT, GAUSS_FAST, BRIDGE, GAUSS_PACKED, STATE_F64 = 0, 1, 2, 4, 8
+ABI_VERSION = 4
 
 _lib = None
 
@@ -46,9 +46,10 @@ def _declare(L):
     L.nddm_graph_arena_info.argtypes = [c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(c.c_int32)]
     L.nddm_graph_arena_release.argtypes = [c.c_uint64]
     L.nddm_source_hash.restype = c.c_char_p
+    L.nddm_build_info.restype = c.c_char_p
     L.nddm_debug_normals.argtypes = [fp, c.c_int64, c.c_uint32, c.c_uint32, c.c_uint32, fp, vp]
     for name in EXPORTS:
-        if name not in ("nddm_last_error", "nddm_source_hash"):
+        if name not in ("nddm_last_error", "nddm_source_hash", "nddm_build_info"):
             getattr(L, name).restype = c.c_int
 
 
@@ -60,7 +61,7 @@ EXPORTS = [
     "nddm_simulate", "nddm_draw_prior", "nddm_debug_normals", "nddm_set_tuning", "nddm_set_debug_trace", "nddm_set_ordering",
     "nddm_release_graph_memory", "nddm_debug_set_slot_limit", "nddm_debug_last_launch",
     "nddm_simulate_indirect", "nddm_draw_prior_indirect", "nddm_source_hash", "nddm_simulate_codes", "nddm_decode_codes",
-    "nddm_graph_arena_create", "nddm_graph_arena_bind", "nddm_graph_arena_info", "nddm_graph_arena_release",
+    "nddm_graph_arena_create", "nddm_graph_arena_bind", "nddm_graph_arena_info", "nddm_graph_arena_release", "nddm_build_info",
 ]
 
 

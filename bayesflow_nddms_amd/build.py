@@ -61,6 +61,16 @@ def is_stale():
     return embedded_hash() != source_hash()
 
 
+def hipcc_version():
+    """HIP version of the compiler (`hipcc --version`), recorded in the library at build time (nddm_build_info) so that nothing has
+    to start the compiler at run time to report it."""
+    try:
+        m = re.search(r"HIP version:\s*(\S+)", subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout)
+        return m.group(1) if m else "unknown"
+    except Exception:                                                   # noqa: BLE001
+        return "unknown"
+
+
 def build_hip(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libnddm_hip.so; returns the path."""
     if not force and not is_stale():
@@ -71,7 +81,7 @@ def build_hip(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or is_stale():
             tmp = f"{SO_PATH}.{os.getpid()}.tmp"
-            cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DNDDM_SOURCE_HASH="{source_hash()}"', "-o", tmp] + SOURCES
+            cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DNDDM_SOURCE_HASH="{source_hash()}"', f'-DNDDM_HIPCC_VERSION="{hipcc_version()}"', "-o", tmp] + SOURCES
             if verbose:
                 print(" ".join(cmd))
             try:

@@ -318,7 +318,7 @@ static int resident_waves(K kernel, size_t lds_bytes, int cus)
 }
 
 // one (MODEL, BRIDGE, SMALL, PACKED, VKEYS) variant: pick the Gaussian transform and the step-cap form, size the grid
-template <int MODEL, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false>
+template <int MODEL, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false, bool F64 = false>
 static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_bytes, int n_chunks, int cus, int grid_override,
                            bool grid_forced, hipStream_t st)
 {
@@ -331,10 +331,10 @@ static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_by
         g_last.grid_waves = waves; g_last.vkeys = VKEYS ? 1 : 0;                               \
         hipLaunchKernelGGL(KERNEL, dim3(waves), block, lds_bytes, st, A);                      \
     } while (0)
-    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
-    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
-    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
-    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, SMALL, PACKED, VKEYS, CODES>));
+    if (fast && cap4)       NDDM_LAUNCH((sim_kernel<MODEL, true, true, BRIDGE, SMALL, PACKED, VKEYS, CODES, F64>));
+    else if (fast)          NDDM_LAUNCH((sim_kernel<MODEL, true, false, BRIDGE, SMALL, PACKED, VKEYS, CODES, F64>));
+    else if (cap4)          NDDM_LAUNCH((sim_kernel<MODEL, false, true, BRIDGE, SMALL, PACKED, VKEYS, CODES, F64>));
+    else                    NDDM_LAUNCH((sim_kernel<MODEL, false, false, BRIDGE, SMALL, PACKED, VKEYS, CODES, F64>));
 #undef NDDM_LAUNCH
 }
 
@@ -342,7 +342,7 @@ static void launch_variant(const SimArgs &A, bool fast, bool cap4, size_t lds_by
 // Philox round keys in VGPRs (nddm_sim.h) is 13-29 % faster there and 1.6 % slower on a full grid; it exists for the models
 // whose kernels have the registers to spare
 template <int MODEL, bool BRIDGE>
-static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, size_t lds_bytes, int n_chunks, int cus,
+static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, bool f64, size_t lds_bytes, int n_chunks, int cus,
                         int grid_override, bool grid_forced, hipStream_t st)
 {
     const bool cap4 = (A.max_k % ((packed || BRIDGE) ? 8 : 4)) == 0;     // the step cap falls on a block boundary (bridge, packed: 8 steps per pass)
@@ -350,7 +350,14 @@ static int launch_model(const SimArgs &A, bool fast, bool packed, bool vkeys, si
     constexpr bool HAS_VKEYS = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED || MODEL == NDDM_EXPLICIT_BOUNDARY);
 #define NDDM_ARGS A, fast, cap4, lds_bytes, n_chunks, cus, grid_override, grid_forced, st
     constexpr bool HAS_CODES = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_ALPHA_NOT_SCALED);
-    if (A.out_codes) {          // the wire-format variant (the host has checked: small, not packed, not the bridge); round keys from LDS
+    constexpr bool HAS_F64 = !BRIDGE && (MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_SINGLE_TRIAL);
+    if (f64) {                  // NDDM_STATE_F64 (the host has checked: basic / single, no bridge, not packed, no codes); round keys from LDS
+        if constexpr (HAS_F64) {
+            if (small) launch_variant<MODEL, false, true, false, false, false, true>(NDDM_ARGS);
+            else launch_variant<MODEL, false, false, false, false, false, true>(NDDM_ARGS);
+        }
+    }
+    else if (A.out_codes) {     // the wire-format variant (the host has checked: small, not packed, not the bridge); round keys from LDS
         if constexpr (HAS_CODES) launch_variant<MODEL, false, true, false, false, true>(NDDM_ARGS);
     }
     else if constexpr (BRIDGE) launch_variant<MODEL, true, false, false, false>(NDDM_ARGS);
@@ -391,9 +398,13 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     if (set_offset >= (1ull << 60) || set_offset + (uint64_t)B > (1ull << 60))
         return fail(NDDM_ERR_SHAPE, "set_offset + B must be <= 2^60 (the random stream is keyed by 60 bits of the set index)%s");
     if (!(dt > 0.0f) || !isfinite(dt)) return fail(NDDM_ERR_PARAM, "dt must be finite and > 0%s");
-    if (flags > 7u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
+    if (flags > 15u) return fail(NDDM_ERR_PARAM, "unknown flags%s");
     const bool bridge = (flags & NDDM_BRIDGE) != 0;
     const bool packed = (flags & NDDM_GAUSS_PACKED) != 0;
+    const bool f64 = (flags & NDDM_STATE_F64) != 0;
+    if (f64 && ((model != NDDM_BASIC_DDM_DC && model != NDDM_SINGLE_TRIAL) || bridge || packed || out_codes))
+        return fail(NDDM_ERR_PARAM, "NDDM_STATE_F64 exists for NDDM_BASIC_DDM_DC and NDDM_SINGLE_TRIAL, without NDDM_BRIDGE, NDDM_GAUSS_PACKED "
+                                    "or the 2-byte wire format%s");
     if (packed && (bridge || max_steps >= 16384))
         return fail(NDDM_ERR_PARAM, "NDDM_GAUSS_PACKED needs max_steps < 2^14 and cannot be combined with NDDM_BRIDGE%s");
     if (bridge && model != NDDM_ALPHA_NOT_SCALED)
@@ -441,6 +452,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
     A.dbg = dbg; A.dbg_waves = dbg_waves; A.dbg_chunks = dbg_chunks;
+    A.dt64 = (double)dt; A.sqrt_dt64 = sqrt((double)dt);      // (sqrt of a double: correctly rounded, as np.sqrt(dt) is)
 
     // tiling: a set whose trials do not fit the LDS ring comfortably is split into equal tiles ("virtual sets");
     // the random stream is keyed by the trial's index within the SET, so results do not depend on the tiling
@@ -622,6 +634,7 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         const int threads = 256;
         long long blocks = (B + threads - 1) / threads;
         hipError_t e = hipSuccess;
+        const int rec_mode = (fast ? 1 : 0) | (f64 ? 2 : 0);
         if (want_order) {
             int *order_ws = reinterpret_cast<int *>(scratch);
             uint32_t *recs = reinterpret_cast<uint32_t *>(order_ws + 64);
@@ -629,13 +642,13 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
             hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned int *>(order_ws));
             hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, params, P, (int)B, dt,
                                (int)max_steps, order_ws);
-            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P,
+            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, rec_mode, params, P,
                                (int)B, dt, A.sqrt_dt, (int)max_steps, (unsigned long long)set_offset,
                                reinterpret_cast<const unsigned long long *>(set_offset_dev), order_ws, recs);
             A.recs = recs;
         } else {
             uint32_t *recs = reinterpret_cast<uint32_t *>(scratch);
-            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, fast ? 1 : 0, params, P, (int)B, dt,
+            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, model, rec_mode, params, P, (int)B, dt,
                                A.sqrt_dt, (unsigned long long)set_offset, reinterpret_cast<const unsigned long long *>(set_offset_dev), recs);
             A.recs = recs;
         }
@@ -653,14 +666,14 @@ static int simulate(int model, const float *params, const float *bounds, int64_t
         g_last.ring = ring; g_last.tile_trials = tile_n; g_last.tiles_per_set = tiles; g_last.sets_per_chunk = spc;
         g_last.refill_thresh = A.refill_thresh; g_last.lds_bytes = (int)lds;
         switch (model) {
-        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
-        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
-        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_BASIC_DDM_DC: rc = launch_model<NDDM_BASIC_DDM_DC, false>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL: rc = launch_model<NDDM_SINGLE_TRIAL, false>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        case NDDM_SINGLE_TRIAL_ALT: rc = launch_model<NDDM_SINGLE_TRIAL_ALT, false>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         case NDDM_ALPHA_NOT_SCALED:
-            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st)
-                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st);
+            rc = bridge ? launch_model<NDDM_ALPHA_NOT_SCALED, true>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st)
+                        : launch_model<NDDM_ALPHA_NOT_SCALED, false>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st);
             break;
-        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, vkeys, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
+        default: rc = launch_model<NDDM_EXPLICIT_BOUNDARY, false>(A, fast, packed, vkeys, f64, lds, (int)n_chunks, di.cus, gw, tun.grid_waves > 0, st); break;
         }
     }
     if (rc == NDDM_OK && A.partials) {
@@ -974,6 +987,13 @@ const char *nddm_source_hash(void)
     static const char tag[] = "NDDM_SRC_HASH=" NDDM_SOURCE_HASH;      // the tag makes the hash findable in the file without loading it
     return tag + 14;
 }
+
+/* what built this library, as build.py recorded it ("hipcc=<HIP version of the compiler>"; "hipcc=unknown" for a hand-made build):
+ * lets a caller report its toolchain without starting the compiler at run time */
+#ifndef NDDM_HIPCC_VERSION
+#define NDDM_HIPCC_VERSION "unknown"
+#endif
+const char *nddm_build_info(void) { return "hipcc=" NDDM_HIPCC_VERSION; }
 
 int nddm_debug_normals(const uint32_t *counters, int64_t n, uint32_t k0, uint32_t k1, uint32_t flags, float *out,
                        void *stream)

@@ -56,7 +56,8 @@ __device__ __forceinline__ unsigned long long global_offset(unsigned long long s
     return set_offset + (off_dev ? *off_dev : 0ull);
 }
 
-__global__ void order_scatter_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
+// mode: bit 0 = fast Gaussian transform, bit 1 = NDDM_STATE_F64 (make_record)
+__global__ void order_scatter_kernel(int model, int mode, const float *params, int P, int B, float dt, float sqrt_dt, int max_k,
                                      unsigned long long set_offset, const unsigned long long *off_dev, int *ws, uint32_t *recs)
 {
     const unsigned long long g0 = global_offset(set_offset, off_dev);
@@ -77,19 +78,19 @@ __global__ void order_scatter_kernel(int model, int fast, const float *params, i
         __syncthreads();
         if (i < B) {
             const int q = start[b] + lbase[b] + r;      // position of set i in the processing order
-            make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i, g0 + (unsigned long long)i, recs + (long long)q * REC);
+            make_record(model, (mode & 1) != 0, (mode & 2) != 0, params + (long long)i * P, dt, sqrt_dt, i, g0 + (unsigned long long)i, recs + (long long)q * REC);
         }
         __syncthreads();
     }
 }
 
 // launches too small to be worth sorting: records in the given order
-__global__ void prep_kernel(int model, int fast, const float *params, int P, int B, float dt, float sqrt_dt,
+__global__ void prep_kernel(int model, int mode, const float *params, int P, int B, float dt, float sqrt_dt,
                             unsigned long long set_offset, const unsigned long long *off_dev, uint32_t *recs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B)
-        make_record(model, fast != 0, params + (long long)i * P, dt, sqrt_dt, i,
+        make_record(model, (mode & 1) != 0, (mode & 2) != 0, params + (long long)i * P, dt, sqrt_dt, i,
                     global_offset(set_offset, off_dev) + (unsigned long long)i, recs + (long long)i * REC);
 }
 

@@ -66,6 +66,7 @@ struct SimArgs {
                               // 2 = ... and the tile has <= 512 trials (the flush's 32-bit / DPP reduction path)
     int refill_thresh;        // leave the step loop once this many lanes hold a finished trial
     uint32_t ring_magic;      // floor(2^32 / ring): t mod ring by a multiply (ring_slot())
+    double dt64, sqrt_dt64;   // NDDM_STATE_F64: (double)dt and its correctly rounded double square root (the reference's np.sqrt(dt))
 };
 
 // The launch arguments as they sit in the kernarg segment (constant address space: scalar loads).  The rarely executed
@@ -183,7 +184,9 @@ __device__ __forceinline__ void finalize_summary(float *o, int n_up, int n_lo, i
 // S = noise_unit(sqrt(dt) * dc): the state is carried in noise units (nddm_rng.h).
 enum { REC = 12, R_A = 0, R_B = 4, R_SET = 8, R_TAU = 9, R_GLO = 10, R_GHI = 11 };
 
-__device__ __forceinline__ void make_record(int model, bool fast, const float *row, float dt, float sqrt_dt, int set,
+// f64 (NDDM_STATE_F64, basic and single): A holds the RAW parameters -- drift, dc, boundary | std_alpha, beta | mu_alpha -- and the
+// hand-out forms the reference's float64 quantities from them (boundary * beta, drift * dt, sqrt(dt) * dc) in double.
+__device__ __forceinline__ void make_record(int model, bool fast, bool f64, const float *row, float dt, float sqrt_dt, int set,
                                             unsigned long long gset, uint32_t *r)
 {
     float drift = 0.0f, a = 0.0f, beta = 0.0f, sig_c = 1.0f, tau;
@@ -203,6 +206,10 @@ __device__ __forceinline__ void make_record(int model, bool fast, const float *r
     else if (model == NDDM_SINGLE_TRIAL_ALT) { a0 = row[0]; a1 = row[1]; a2 = row[2]; a3 = row[4]; }
     else if (model == NDDM_ALPHA_NOT_SCALED) { a0 = row[0]; }
     else if (model == NDDM_EXPLICIT_BOUNDARY) { a2 = beta; a3 = 0.0f; }
+    if (f64) {
+        a0 = drift; a1 = sig_c;
+        if (model == NDDM_BASIC_DDM_DC) { a2 = a; a3 = beta; }      // (single keeps std_alpha, mu_alpha in A.z, A.w and beta in B.z)
+    }
     r[0] = __float_as_uint(a0); r[1] = __float_as_uint(a1); r[2] = __float_as_uint(a2); r[3] = __float_as_uint(a3);
     r[4] = __float_as_uint(b0); r[5] = __float_as_uint(b1); r[6] = __float_as_uint(b2); r[7] = 0u;
     r[8] = (uint32_t)set; r[9] = __float_as_uint(tau);
@@ -266,6 +273,22 @@ __device__ __forceinline__ void trial_latent(const u32v4 dA, const u32v4 dB, uin
     if (!(v > 0.0f)) v = fabsf(v);
     latent = v;
     z = __builtin_fmaf(sigma1, z0, gamma * v);
+}
+
+// NDDM_STATE_F64, single-trial model: the per-trial boundary in the reference's arithmetic,
+//     bound_trial = mu_alpha + std_alpha * normal   (single_trial_alpha_not_scaled.py:113-116; float64)
+// on the SAME auxiliary normals (1, 2, ...: rejection draws) as trial_latent.  Returns the ACCEPTED normal (a float: what the
+// latent FIFO holds); the hand-out rebuilds the double from it with the same two operations.
+template <bool FAST>
+__device__ __forceinline__ float latent_normal_f64(const u32v4 dA, uint32_t set_lo, uint32_t c3, uint32_t trial, uint32_t kbase)
+{
+    const double sd = (double)__uint_as_float(dA.z), mean = (double)__uint_as_float(dA.w);
+    AuxStream<FAST> aux(kbase, set_lo, c3, trial);
+    float z0, z;
+    aux.first_pair(z0, z);
+    double v = mean + sd * (double)z;
+    for (uint32_t ai = 2; !(v > 0.0) && ai <= MAX_REJECT; ++ai) { z = aux.normal(ai); v = mean + sd * (double)z; }
+    return z;
 }
 
 // Fixed-point terms of the external datum's sums: trunc(z * 2^32) and trunc(z^2 * 2^24) with z clamped to +-2^18, as the
@@ -467,9 +490,16 @@ __device__ __forceinline__ bool in_range(float w, float h)
 // block (nddm_rng.h): no LDS instruction and no wait in the loop.  Same VALU work; measured 1.6 % slower on a full grid
 // and 13-29 % faster when a wave has a SIMD (nearly) to itself, so the host picks it for small launches.
 // CODES: the variant that also stores the trials as 2-byte codes (flush_set); instantiated for basic / alpha_not_scaled, SMALL only.
-template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false>
+// F64: NDDM_STATE_F64 -- the evidence is carried as the REFERENCE carries it (basic_ddm_dc.py:91-103): a float64 in its natural
+// units, evidence += drift*dt + sqrt(dt)*dc*normal with every operation a separate IEEE double operation in the reference's
+// order, the range test (evidence > 0) && (evidence < boundary) on doubles; the normal is the exact double product of the
+// float32 Box-Muller radius and cosine / sine.  Philox, the transform, the hand-out and the flush are the float32 kernel's.
+// basic and single only; bit-equal in (step, choice) to oracle_philox_simulate_f64 in exact mode.
+template <int MODEL, bool FAST, bool CAP4, bool BRIDGE, bool SMALL, bool PACKED, bool VKEYS, bool CODES = false, bool F64 = false>
 __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
 {
+    static_assert(!F64 || ((MODEL == NDDM_BASIC_DDM_DC || MODEL == NDDM_SINGLE_TRIAL) && !BRIDGE && !PACKED && !VKEYS && !CODES),
+                  "NDDM_STATE_F64 kernels");
     using T = ModelTraits<MODEL>;
     constexpr int P = T::P;
     extern __shared__ uint32_t lds_raw[];
@@ -513,6 +543,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
     // per-lane trial state
     // w: centred evidence, h: boundary / 2, mu_dt: drift per step -- all in NOISE UNITS (divided by noise_unit(sigma))
     float w = 0.0f, h = 0.0f, mu_dt = 0.0f;
+    // F64: xe = evidence, ab = boundary, cdt = drift * dt, sdc = sqrt(dt) * dc (fast transform: * sqrt(2 ln 2), its radius unit)
+    [[maybe_unused]] double xe = 0.0, ab = 0.0, cdt = 0.0, sdc = 0.0;
     int k = 0;
     // BRIDGE only: ta / tb = h - |w|, the distance to the nearer boundary carried from step to step; jraw = the crossing-uniform
     // word of the trial's current step pair (its jitter bits are taken when the trial retires).  With the bridge, k counts the
@@ -621,6 +653,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
         const unsigned long long fin_mask0 = has_m & ~act_m;
         if (__builtin_amdgcn_inverse_ballot_w64(fin_mask0)) {
             uint32_t code = invalid ? 3u : (w >= h ? 1u : (w <= -h ? 2u : 0u));
+            if constexpr (F64) code = xe >= ab ? 1u : (xe <= 0.0 ? 2u : 0u);        // basic_ddm_dc.py:106-111
             uint32_t tfix = (uint32_t)k;
             if constexpr (BRIDGE) {
                 // started: the trial began inside (0, a); stepped: ... and ended by crossing a boundary (at a grid point or, by
@@ -709,6 +742,8 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                             // A = Nu, 1/S, a/(2S), w0;  B = Eta: the trial's drift N(Nu, Eta) per step, in noise units
                             AuxStream<FAST> aux(kbase, sw.y, sw.x, btrial);
                             v = (__builtin_fmaf(__uint_as_float(dB.x), aux.normal(0), __uint_as_float(dA.x)) * fresh_args(Ak)->dt) * __uint_as_float(dA.y);
+                        } else if constexpr (F64) {
+                            v = latent_normal_f64<FAST>(dA, sw.y, sw.x, btrial, kbase);     // the accepted normal
                         } else {
                             float z_unused;
                             trial_latent<MODEL, FAST>(dA, dB, sw.y, sw.x, btrial, kbase, v, z_unused);
@@ -759,7 +794,20 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                     latent = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
                         kbase + FIFO_OFF + (((uint32_t)fifo_pos + lane_rank(want_mask)) & (LATENT_FIFO - 1)) * 4u);
                 invalid = false;
-                if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
+                if constexpr (F64) {
+                    // A = drift, dc, boundary | std_alpha, beta | mu_alpha (raw); single: B.z = beta, latent = the accepted normal
+                    double beta64;
+                    if constexpr (MODEL == NDDM_BASIC_DDM_DC) { ab = (double)a2; beta64 = (double)a3; }
+                    else {
+                        ab = (double)a3 + (double)a2 * (double)latent;
+                        if (!(ab > 0.0)) ab = __builtin_fabs(ab);
+                        beta64 = (double)__uint_as_float(rw[D_B + 2]);
+                    }
+                    xe = ab * beta64;                                               // basic_ddm_dc.py:91
+                    cdt = (double)a0 * H->dt64;
+                    sdc = H->sqrt_dt64 * (double)a1;
+                    if constexpr (FAST) sdc *= 1.1774100225154747;                  // the fast radius is sqrt(-log2 u)
+                } else if constexpr (MODEL == NDDM_BASIC_DDM_DC) {
                     mu_dt = a0; h = a2; w = a3;
                 } else if constexpr (MODEL == NDDM_SINGLE_TRIAL) {
                     // A = drift*dt/S, 1/S, std_alpha, mu_alpha;  B = sigma1, gamma, beta
@@ -798,6 +846,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
             // fresh compares over all lanes (an invalid trial has h == 0 and is never in range; lanes without a trial
             // are masked by has_m)
             if constexpr (BRIDGE) act_m = __builtin_amdgcn_ballot_w64(ta > 0.0f) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+            else if constexpr (F64) act_m = __builtin_amdgcn_ballot_w64(xe > 0.0) & __builtin_amdgcn_ballot_w64(xe < ab) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
             else act_m = __builtin_amdgcn_ballot_w64(in_range(w, h)) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
         }
         // ------------------------------------------------------------ step phase
@@ -904,7 +953,7 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 if (it >= it_limit) break;
                 continue;
             }
-            [[maybe_unused]] bool active = (CAP4 && !PACKED) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
+            [[maybe_unused]] bool active = (CAP4 && !PACKED && !F64) ? false : __builtin_amdgcn_inverse_ballot_w64(act_m);
             // counter word 0 of the path stream = index of the block's first step (a multiple of NS: a lane only starts
             // a block after taking all NS steps of the previous one), so no shift is needed
             constexpr int NS = PACKED ? 8 : 4;
@@ -925,6 +974,28 @@ __global__ __launch_bounds__(WAVE) void sim_kernel(const SimArgs A)
                 polar_pair<FAST, true>(rb.x, rb.y, rr[0], tt[0], tt[1]);
                 polar_pair<FAST, true>(rb.z, rb.w, rr[2], tt[2], tt[3]);
                 rr[1] = rr[0]; rr[3] = rr[2];
+            }
+            if constexpr (F64) {
+                // the reference's recurrence, one IEEE double operation per Python operation (this translation unit is compiled
+                // with -ffp-contract=off): t1 = drift*dt, t2 = sqrt(dt)*dc (both per trial), t3 = t2 * normal, t4 = t1 + t3,
+                // evidence = evidence + t4; then the loop condition of basic_ddm_dc.py:95
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    if (active) {
+                        asm volatile("" ::: "memory");
+                        const double zn = (double)rr[j] * (double)tt[j];        // exact: 24 x 24 bits
+                        xe = xe + (cdt + sdc * zn);
+                        k++;
+                        if (j < NS - 1) {
+                            if constexpr (CAP4) active = (xe > 0.0) && (xe < ab);
+                            else active = (xe > 0.0) && (xe < ab) && (k < A.max_k);
+                        }
+                    }
+                }
+                act_m = __builtin_amdgcn_ballot_w64(xe > 0.0) & __builtin_amdgcn_ballot_w64(xe < ab) & __builtin_amdgcn_ballot_w64(k < A.max_k) & has_m;
+                if ((int)__popcll(has_m & ~act_m) >= leave_at) break;
+                if (it >= it_limit) break;
+                continue;
             }
             if constexpr (CAP4 && !PACKED) {
                 // The four steps with the execution mask narrowed by the range compare itself (v_cmpx writes EXEC): fmac, add,

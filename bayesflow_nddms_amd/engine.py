@@ -94,8 +94,12 @@ def validate_params_host(model, params):
 def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_offset=None, fast=None,
              bounds=None, ext_sigma=0.0, ext_mode=0, bridge=False, packed=False, want_trials=True, want_summary=True, want_ext=False,
              out_trials=None, out_summary=None, stream_state=None, device=None, set_offset_dev=None, want_codes=False,
-             out_codes=None):
+             out_codes=None, state_f64=False):
     """Run one batched simulation on the current ROCm device.
+
+    state_f64=True selects NDDM_STATE_F64 (include/nddm.h): the evidence is carried in float64 exactly as the reference's recurrence
+    does (basic_ddm_dc.py:91-103) on the same normals -- basic_ddm_dc and single_trial only; with fast=False every trial's (step,
+    choice) equals the float64 oracle's bit for bit.
 
     params: array-like or torch tensor [B, P] (or [P]) in the reference's parameter order.
     packed=True selects NDDM_GAUSS_PACKED (include/nddm.h): 8 normals per Philox block from 16 + 16 bit pairs, ~25 % faster,
@@ -162,7 +166,8 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     set_offset = int(set_offset) & 0xFFFFFFFFFFFFFFFF
     fast = DEFAULT_FAST if fast is None else bool(fast)
-    flags = (_lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT) | (_lib.BRIDGE if bridge else 0) | (_lib.GAUSS_PACKED if packed else 0)
+    flags = (_lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT) | (_lib.BRIDGE if bridge else 0) | (_lib.GAUSS_PACKED if packed else 0) \
+        | (_lib.STATE_F64 if state_f64 else 0)
     if bridge and model != ALPHA_NOT_SCALED:
         raise ValueError("the Brownian-bridge correction is only available for the alpha_not_scaled model")
 

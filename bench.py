@@ -40,6 +40,7 @@ import glob
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -231,7 +232,7 @@ def cpu_baseline(a, params, model_name, n_trials, dt, max_steps, target_s):
     return out
 
 
-def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
+def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False, state_f64=False):
     """KS distance vs the golden fixtures made from the reference (tests/golden/): the signed step index against
     ks_hist.npz (basic, single; >= 4e5 trials per side per parameter set), the signed RT against the exact sampler's
     quantile tables ratcliff.npz (alpha_not_scaled; 2e5 reference draws per set)."""
@@ -250,7 +251,8 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
         for si, p in enumerate(gold[f"{model_name}_sets"]):
             row = p if model_name == "basic" else np.append(p, 1.0)
             r = engine.simulate(getattr(engine, MODELS[model_name][0]), np.tile(row, (2048, 1)), 200, dt=dt,
-                                max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, packed=packed, want_summary=False)
+                                max_steps=max_steps, seed=777, set_offset=si * 4096, fast=fast, packed=packed, want_summary=False,
+                                state_f64=state_f64)
             h = dg.step_hist_from_trials(r["trials"].cpu().numpy(), float(np.float32(p[3])), dt, K, signed=model_name == "single")
             per.append(round(dg.ks_signed(h, gold[f"{model_name}_hist_s{si}_c{ci}"]), 5))
         return {"max": max(per), "per_set": per, "n_trials_per_side": 409600, "bar": 0.01, "meets_bar": bool(max(per) < 0.01),
@@ -271,23 +273,36 @@ def ks_vs_golden(engine, model_name, dt, max_steps, fast, packed=False):
                                                         "the BASELINE configs[2] measurement")}
 
 
-def pmc_traffic(model_name, B, N):
+def _round_key(path):
+    m = re.match(r"r(\d+)_", os.path.basename(path))
+    return (int(m.group(1)) if m else -1, os.path.basename(path))
+
+
+def pmc_traffic(model_name, B, N, dt=0.001, gauss="fast"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/*_pmc.json, made by tools/gpu_profile.sh + tools/summarize_profile.py): WRITE_SIZE is exact for streaming
-    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if no matching profile."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  A file counts only if it was collected from THIS
+    library: it records the nddm_source_hash() of the library it profiled, and a file with another hash (or none: rounds 1-5) is
+    refused -- the line then says `traffic: null` and why (`traffic_refused`) instead of quoting counters of other code."""
+    from bayesflow_nddms_amd.build import source_hash
+    want, stale = source_hash(), []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=_round_key, reverse=True):
         try:
             d = json.load(open(path))
             if (d.get("model", "basic") == model_name and d["sets_per_gpu"] == B and d["n_trials"] == N
-                    and "WRITE_SIZE" in d["pmc_per_launch"]):
+                    and abs(d.get("dt", 0.001) - dt) < 1e-12 and d.get("gauss", "fast") == gauss and "WRITE_SIZE" in d["pmc_per_launch"]):
+                if d.get("source_hash") != want:
+                    stale.append(os.path.basename(path))
+                    continue
                 c = d["pmc_per_launch"]
-                return {"bytes": (2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, "source": os.path.basename(path)}
+                return {"bytes": (2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, "source": os.path.basename(path),
+                        "source_hash": want[:16]}
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return {"bytes": None, "refused": stale[:3]} if stale else None
 
 
-def issue_model(model_name, gauss):
+def issue_model(model_name, gauss, f64=False):
     """ISA-level ceiling of the shipped library's step loop (tools/isa_mix.py), if the committed file matches the .so."""
     from bayesflow_nddms_amd.build import SO_PATH
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -296,8 +311,8 @@ def issue_model(model_name, gauss):
         digest = isa_mix.code_object(SO_PATH)[1]                # hash of the library's gfx950 code object
     except Exception:                                           # noqa: BLE001 -- reported as "does not match"
         digest = None
-    key = model_name + {"fast": "", "exact": "_exact", "packed": "_packed"}[gauss]
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), reverse=True):
+    key = model_name + {"fast": "", "exact": "_exact", "packed": "_packed"}[gauss] + ("_f64" if f64 else "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), key=_round_key, reverse=True):
         try:
             d = json.load(open(path))
             k = d["kernels"][key]
@@ -321,22 +336,25 @@ def em_steps_of(summary, tau, dt, max_k, bridge):
     return float((mean_k * n_resp + s[:, 2] * max_k).sum().item())
 
 
-def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry, model_name=None):
+def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry, model_name=None, dt=None, max_steps=None,
+                    state_f64=False):
     """The step loop with every lane useful: the SAME kernel (variant and grid of the timed launch: `geometry` =
     engine.last_launch() after a timed step) on a workload whose trials all run to the step cap (no refill, no idle lanes,
     same residency).  Runs outside the timed region.  Returns E-M steps/s and the lane efficiency it was measured at
     (executed-block counter of the kernel)."""
-    max_k = engine.max_k_of(a.max_steps)
+    dt = a.dt if dt is None else dt
+    max_steps = a.max_steps if max_steps is None else max_steps
+    max_k = engine.max_k_of(max_steps)
     N = a.trials
-    B = int(max(2048, min(400_000, 4.8e10 / (N * max_k))))
+    B = int(max(2048, min(400_000, (1.6e10 if (state_f64 or not fast) else 4.8e10) / (N * max_k))))
     p = torch.tensor([LOCKSTEP_ROW[model_name or a.model]] * B, dtype=torch.float32, device=dev)
     summ = torch.empty((B, engine.SUMMARY_K), dtype=torch.float32, device=dev)
     L = _lib.lib()
     # never leave the loop early (refill only when all lanes are done); the timed launch's kernel variant and grid
     _lib.check(L.nddm_set_tuning(1, 0, 64, 2 if geometry["vgpr_keys"] else 1, geometry["grid_waves"], 0))
     try:
-        run = lambda: engine.simulate(model_id, p, N, dt=a.dt, max_steps=a.max_steps, seed=7, set_offset=0, fast=fast,
-                                      out_summary=summ, want_trials=False, bridge=bridge, packed=packed)
+        run = lambda: engine.simulate(model_id, p, N, dt=dt, max_steps=max_steps, seed=7, set_offset=0, fast=fast,
+                                      out_summary=summ, want_trials=False, bridge=bridge, packed=packed, state_f64=state_f64)
         run()
         with engine.debug_trace(device=dev) as tr:
             run(); run()                              # back to back: the second launch's records are the ones that stay
@@ -356,6 +374,33 @@ def measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed,
     return {"steps_per_s": sps, "lane_efficiency": lane_eff, "steps_per_s_all_lanes_useful": sps / lane_eff,
             "kernel_ms": best, "clock_ghz_in_kernel": clock, "launch": engine.last_launch(),
             "workload": f"{B} sets x {N} trials, every trial runs to the cap of {max_k} steps"}
+
+
+def valu_roofline(achieved_steps, simds, spb, ceiling, im):
+    """The binding resource's roofline object.  `frac` is the fraction of the HARDWARE-derived ceiling: the ISA issue model of the
+    shipped library's step loop (every VALU instruction of the loop body at its isolated issue cost, tools/isa_mix.py x
+    tools/ubench_valu: what the SIMDs could issue at the nominal clock if every lane of every block were useful and nothing but the
+    loop body ran).  `frac_vs_lockstep` is the same rate against this kernel variant's own lockstep run measured in this process --
+    a ceiling that shares the kernel's code and therefore measures divergence and refill loss, not distance from the hardware."""
+    rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
+    if im:
+        peak_im = simds * CLOCK_GHZ * 1e9 / im["cycles_per_block"] * 64.0 * im["steps_per_block"]
+        rv.update({"peak": peak_im / 1e9, "frac": achieved_steps / peak_im,
+                   "ceiling": "ISA issue model of the shipped library's step loop at the nominal clock (hardware-derived; see frac_vs_lockstep "
+                              "for the kernel's own lockstep run)", "issue_model": im})
+    if ceiling:
+        peak = ceiling["steps_per_s_all_lanes_useful"]
+        rv.update({"peak_lockstep": peak / 1e9, "frac_vs_lockstep": achieved_steps / peak,
+                   "lockstep": "this kernel variant's step loop with every lane useful, measured in this run (a workload whose trials all run "
+                               "to the step cap): shares the kernel's code, so it prices divergence and refills, not the hardware",
+                   "ceiling_measured_steps_per_s": ceiling["steps_per_s"], "ceiling_lane_efficiency": ceiling["lane_efficiency"],
+                   "ceiling_kernel_ms": ceiling["kernel_ms"], "ceiling_workload": ceiling["workload"],
+                   "ceiling_clock_ghz_in_kernel": ceiling["clock_ghz_in_kernel"], "ceiling_launch": ceiling["launch"],
+                   "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 64.0 * spb / peak, "steps_per_block": spb})
+        if "frac" not in rv:
+            rv.update({"peak": peak / 1e9, "frac": achieved_steps / peak,
+                       "ceiling": "no issue model matches this library: frac falls back to the lockstep ceiling (frac_vs_lockstep)"})
+    return rv
 
 
 _JSON_OUT = None      # the process's real standard output, kept for the ONE JSON line
@@ -576,8 +621,6 @@ def toolchain(torch):
     the vendor yardstick (tools/ubench_rocrand.hip) was built against."""
     import ctypes
     import re
-    import shutil
-    import subprocess
     out = {"torch": torch.__version__, "torch_hip": torch.version.hip, "hip_runtime": None, "hip_runtime_library": None, "hipcc": None,
            "rccl": None, "rocrand": None}
     try:
@@ -590,10 +633,9 @@ def toolchain(torch):
             out["hip_runtime_library"] = paths[0]
     except Exception:                                               # noqa: BLE001
         pass
-    try:
-        exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        m = re.search(r"HIP version:\s*(\S+)", subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout)
-        out["hipcc"] = m.group(1) if m else None
+    try:                                         # the compiler that built the library, from the library's own build record -- nothing is
+        from bayesflow_nddms_amd import _lib     # started from this (GPU-initialised, possibly profiled) process to find out
+        out["hipcc"] = _lib.lib().nddm_build_info().decode().split("hipcc=", 1)[1] or None
     except Exception:                                               # noqa: BLE001
         pass
     try:
@@ -610,23 +652,29 @@ def toolchain(torch):
     return out
 
 
-def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False):
-    """One of the other BASELINE simulator configs as a SIDE LEG of the default line, outside the headline's timed region: the same
-    1M x 300 workload shape on model `name` (parameters from ITS reference prior, resident in HBM), `--leg-launches` launches timed
-    one by one with events on the launch stream; the same objects the model's own `--model` line carries -- rate, kernel time, HBM and
-    VALU rooflines (lockstep ceiling of THIS kernel variant, measured here), KS against the reference fixtures with its bar."""
+def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False, dt=None, max_steps=None, gauss="fast", state_f64=False,
+                  ks=True, ceiling=True):
+    """One of the other BASELINE simulator configs -- or another SHAPE of the headline's model -- as a SIDE LEG of the default line,
+    outside the headline's timed region: the same 1M x 300 workload shape on model `name` (parameters from ITS reference prior,
+    resident in HBM) at step size `dt` / cap `max_steps` (default: the bench's) with Gaussian transform `gauss` and, optionally, the
+    float64 state arithmetic; `--leg-launches` launches timed one by one with events on the launch stream; the same objects the
+    model's own `--model` line carries -- rate, kernel time, HBM and VALU rooflines (frac = issue-model fraction, the lockstep
+    ceiling of THIS kernel variant measured here beside it), KS against the reference fixtures with its bar."""
     dev, torch, engine, _lib, prior_util = (ctx[k] for k in ("dev", "torch", "engine", "_lib", "prior_util"))
     B, N, L = a.sets, a.trials, max(1, a.leg_launches)
+    dt = a.dt if dt is None else dt
+    max_steps = a.max_steps if max_steps is None else max_steps
+    fast = gauss != "exact"
     model_attr, bridge, prior_fn, _, tau_i = MODELS[name]
     model_id = getattr(engine, model_attr)
     p_host = getattr(prior_util, prior_fn)(B, 2023)
     p_dev = torch.as_tensor(p_host).to(dev)
-    max_k = engine.max_k_of(a.max_steps)
+    max_k = engine.max_k_of(max_steps)
 
     def timed(want_trials):
-        run = lambda i: engine.simulate(model_id, p_dev, N, dt=a.dt, max_steps=a.max_steps, seed=2023, set_offset=i * B, fast=True,
+        run = lambda i: engine.simulate(model_id, p_dev, N, dt=dt, max_steps=max_steps, seed=2023, set_offset=i * B, fast=fast,
                                         out_trials=out_trials if want_trials else None, out_summary=out_summary,
-                                        want_trials=want_trials, bridge=bridge)
+                                        want_trials=want_trials, bridge=bridge, state_f64=state_f64)
         run(0)
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
@@ -637,34 +685,37 @@ def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False
 
     ms = timed(True)
     geometry = engine.last_launch()
-    em_steps = em_steps_of(out_summary, p_dev[:, tau_i], a.dt, max_k, bridge)          # of the last launch
+    em_steps = em_steps_of(out_summary, p_dev[:, tau_i], dt, max_k, bridge)          # of the last launch
     alg_bytes = B * N * 8 + B * (p_host.shape[1] * 4 + engine.SUMMARY_K * 4)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    nm = "single_trial_alpha_not_scaled" if name == "single" else name
-    leg = {"metric": f"simulated DDM trials/sec at n_trials={N} dt={a.dt:g} ({nm}, max_steps={a.max_steps:g})",
-           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": KERNEL_NAME[name] % "fast",
-           "workload": f"{nm} HIP simulator, {B} parameter sets x {N} trials per launch, dt={a.dt}, max_steps={a.max_steps:g}, params ~ its "
+    nm = "single_trial_alpha_not_scaled" if name == "single" else ("basic_ddm_dc" if name == "basic" else name)
+    variant = gauss + (", state_f64" if state_f64 else "")
+    leg = {"metric": f"simulated DDM trials/sec at n_trials={N} dt={dt:g} ({nm}, max_steps={max_steps:g})",
+           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": KERNEL_NAME[name] % variant,
+           "workload": f"{nm} HIP simulator, {B} parameter sets x {N} trials per launch, dt={dt}, max_steps={max_steps:g}, params ~ its "
                        f"reference prior (default_rng 2023); trials f32[B,N,2] + fused summaries f32[B,10]",
+           "gauss": gauss, "state_f64": bool(state_f64), "dt": dt, "max_steps": max_steps,
            "em_steps_per_trial": em_steps / (B * N), "p_missing": float((out_summary[:, 2].sum() / (B * N)).item()), "launch": geometry,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "traffic": None}}
-    tr = pmc_traffic(name, B, N)
-    if tr:
-        leg["roofline"].update(traffic=tr["bytes"], traffic_source=tr["source"])
+    tr = None if state_f64 else pmc_traffic(name, B, N, dt, gauss)
+    if tr and tr.get("bytes") is not None:
+        leg["roofline"].update(traffic=tr["bytes"], traffic_source=tr["source"], traffic_source_hash=tr["source_hash"])
+    elif tr:
+        leg["roofline"]["traffic_refused"] = tr["refused"]
     achieved_steps = em_steps / (ms * 1e-3)
-    rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s"}
-    if not a.no_ceiling:
-        c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, True, False, geometry, model_name=name)
-        rv.update({"peak": c["steps_per_s_all_lanes_useful"] / 1e9, "frac": achieved_steps / c["steps_per_s_all_lanes_useful"],
-                   "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
-                   "ceiling_lane_efficiency": c["lane_efficiency"], "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"]})
-    leg["roofline_valu"] = rv
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    c = None
+    if ceiling and not a.no_ceiling:
+        c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, False, geometry, model_name=name, dt=dt,
+                            max_steps=max_steps, state_f64=state_f64)
+    leg["roofline_valu"] = valu_roofline(achieved_steps, simds, 8 if bridge else 4, c, issue_model(name, gauss, state_f64))
     if with_summary_only:                                # configs[3]'s second form: the fused reduction alone, no 8 B per trial
         ms_s = timed(False)
         leg["summary_only"] = {"value": B * N / (ms_s * 1e-3), "unit": "trials/s", "kernel_ms": ms_s,
                                "outputs": "fused summaries f32[B,10] only", "launches": L}
-    if not a.no_ks:
-        leg["ks_vs_ref"] = ks_vs_golden(engine, name, a.dt, a.max_steps, True, False)
+    if ks and not a.no_ks:
+        leg["ks_vs_ref"] = ks_vs_golden(engine, name, dt, max_steps, fast, False, state_f64=state_f64)
     return leg
 
 
@@ -811,10 +862,11 @@ def simulate_bench(a, ctx):
         "em_steps_per_trial": em_steps / (B * N), "em_steps_per_s_per_gpu": em_steps / (kern_ms * 1e-3),
         "p_missing": p_missing,
     }
-    tr = None if (a.summary_only or codes) else pmc_traffic(a.model, B, N)
-    if tr:
-        res["roofline"]["traffic"] = tr["bytes"]
-        res["roofline"]["traffic_source"] = tr["source"]
+    tr = None if (a.summary_only or codes) else pmc_traffic(a.model, B, N, a.dt, a.gauss)
+    if tr and tr.get("bytes") is not None:
+        res["roofline"].update(traffic=tr["bytes"], traffic_source=tr["source"], traffic_source_hash=tr["source_hash"])
+    elif tr:
+        res["roofline"]["traffic_refused"] = tr["refused"]      # counters of another build of the library: not quoted
     res["host_prior_seconds_rank0"] = t_prior
     res["toolchain"] = toolchain(torch)
     if ident is not None:
@@ -827,24 +879,12 @@ def simulate_bench(a, ctx):
         res["n1_only"] = ["roofline_valu", "occupancy", "ks_vs_ref", "packed_gauss", "cpu_baseline", "gpu_over_cpu_1core", "legs"]
     if world == 1:
         achieved_steps = em_steps / (kern_ms * 1e-3)
-        rv = {"bound": "valu", "achieved": achieved_steps / 1e9, "unit": "G E-M steps/s", "clock_ghz": CLOCK_GHZ}
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
         spb = 8 if (packed or bridge) else 4         # Euler-Maruyama steps per pass of the step loop (packed: one Philox block; bridge: two + one of crossing uniforms)
-        if not a.no_ceiling:
-            c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry)
-            peak = c["steps_per_s_all_lanes_useful"]
-            rv.update({"peak": peak / 1e9, "frac": achieved_steps / peak,
-                       "ceiling": "this kernel's step loop with every lane useful, measured in this run (lockstep workload)",
-                       "ceiling_measured_steps_per_s": c["steps_per_s"], "ceiling_lane_efficiency": c["lane_efficiency"],
-                       "ceiling_kernel_ms": c["kernel_ms"], "ceiling_workload": c["workload"],
-                       "ceiling_clock_ghz_in_kernel": c["clock_ghz_in_kernel"], "ceiling_launch": c["launch"],
-                       "issue_cycles_per_block": simds * CLOCK_GHZ * 1e9 * 64.0 * spb / peak, "steps_per_block": spb})
-        im = issue_model(a.model, a.gauss)
-        if im:
-            peak_im = simds * CLOCK_GHZ * 1e9 / im["cycles_per_block"] * 64.0 * im["steps_per_block"]
-            rv.update({"issue_model": im, "peak_issue_model": peak_im / 1e9, "frac_vs_issue_model": achieved_steps / peak_im})
-            if "frac" not in rv:
-                rv.update({"peak": peak_im / 1e9, "frac": achieved_steps / peak_im, "ceiling": "ISA issue model (no lockstep run)"})
+        c = None if a.no_ceiling else measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, packed, geometry)
+        rv = valu_roofline(achieved_steps, simds, spb, c, issue_model(a.model, a.gauss))
+        if "issue_model" in rv:                      # (the names rounds 2-5 used, kept for readers of older lines)
+            rv.update({"peak_issue_model": rv["peak"], "frac_vs_issue_model": rv["frac"]})
         # an OUTSIDE yardstick beside the two self-measured ceilings: the vendor's device API doing what north_star names
         # ("hiprandStatePhilox per lane": rocrand_state_philox4x32_10 + rocrand_normal4 in a loop), measured on this chip by
         # tools/ubench_rocrand.hip and read from the tracked file, like `traffic`
@@ -874,9 +914,12 @@ def simulate_bench(a, ctx):
                    "clock_ghz_in_kernel": clock})
         if "ceiling_clock_ghz_in_kernel" in rv and clock > 0:
             # the shader clock the two launches actually ran at (s_memtime / s_memrealtime inside the kernel): short
-            # launches of the refill-heavy mix run at a lower clock than the long lockstep launch, which `frac` (a ratio of
-            # rates) counts against the kernel; this is the same ratio in SIMD cycles
-            rv["frac_in_cycles"] = rv["frac"] * rv["ceiling_clock_ghz_in_kernel"] / clock
+            # launches of the refill-heavy mix run at a lower clock than the long lockstep launch, which a ratio of rates
+            # counts against the kernel; this is the lockstep ratio in SIMD cycles
+            rv["frac_vs_lockstep_in_cycles"] = rv["frac_vs_lockstep"] * rv["ceiling_clock_ghz_in_kernel"] / clock
+        if "issue_model" in rv and clock > 0:
+            # ... and the issue-model fraction at the clock the kernel actually ran at instead of the nominal 2.4 GHz
+            rv["frac_at_measured_clock"] = rv["frac"] * CLOCK_GHZ / clock
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         # waves actually resident: sum of the waves' lifetimes (100 MHz s_memrealtime) over kernel time x SIMDs
         rec = d["records"]
@@ -925,7 +968,25 @@ def simulate_bench(a, ctx):
                     return {"error": f"{type(e).__name__}: {e}"[:400]}
 
             legs = {"single": guarded(simulator_leg, a, ctx, "single", out_trials, out_summary, with_summary_only=True),
-                    "alpha_ns_bridge": guarded(simulator_leg, a, ctx, "alpha_ns_bridge", out_trials, out_summary)}
+                    "alpha_ns_bridge": guarded(simulator_leg, a, ctx, "alpha_ns_bridge", out_trials, out_summary),
+                    # the REFERENCE'S OWN default shape (basic_ddm_dc.py:87: dt=.01, max_steps=400; every training run of the
+                    # reference uses it): the kernel's worst -- a trial lasts 7 blocks, so every per-trial instruction weighs
+                    # nine times what it does at dt=.001
+                    "basic_dt01": guarded(simulator_leg, a, ctx, "basic", out_trials, out_summary, dt=0.01, max_steps=400.0),
+                    # the headline workload with NDDM_GAUSS_EXACT: the ONLY mode that is bit-equal to the oracle (every -m gpu
+                    # parity test runs it); the headline's fast transform is pinned to it by per-trial agreement and KS
+                    "exact_gauss": guarded(simulator_leg, a, ctx, "basic", out_trials, out_summary, gauss="exact")}
+            # NDDM_STATE_F64: the reference's float64 recurrence on the device (bit-equal to the float64 oracle with the exact
+            # transform), as a side number with its cost against the float32 state of the same transform
+            f64 = {g: guarded(simulator_leg, a, ctx, "basic", out_trials, out_summary, gauss=g, state_f64=True, ceiling=False, ks=(g == "exact"))
+                   for g in ("exact", "fast")}
+            for g, base in (("exact", legs["exact_gauss"].get("value")), ("fast", value)):
+                if "value" in f64[g] and base:
+                    f64[g]["rate_vs_f32_state_same_transform"] = f64[g]["value"] / base
+            legs["state_f64"] = dict(f64["exact"], fast_transform=f64["fast"],
+                                     what="flags |= NDDM_STATE_F64 (include/nddm.h) on the headline workload: evidence and range test in float64 "
+                                          "exactly as basic_ddm_dc.py:91-103; with the exact transform every (step, choice) equals "
+                                          "oracle_philox_simulate_f64's (tests/test_gpu_parity.py::test_state_f64_bit_parity)")
             from bayesflow_nddms_amd import _train_lib
             one, gat = guarded(training_leg, a, ctx, False), guarded(training_leg, a, ctx, True)
             legs["train"] = {"metric": "training iterations/sec, online simulation feeding the amortizer (BASELINE configs[4])",

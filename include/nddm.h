@@ -63,7 +63,8 @@ extern "C" {
 /* 3: memory behind captured launches has an owner (nddm_graph_arena_create / _bind / _info / _release); nddm_release_graph_memory
  *    frees only what was captured with no arena bound (up to ABI 2: every captured launch's memory on the device, whoever's graph
  *    replayed into it); a `stream` the HIP runtime does not know is refused with NDDM_ERR_HIP (validated with hipStreamGetDevice at entry).  The random stream is ABI 2's. */
-#define NDDM_ABI_VERSION 3
+/* 4: NDDM_STATE_F64 (flag 8), nddm_build_info, nddm_simulratcliff.  The random stream and every ABI-3 entry point are unchanged. */
+#define NDDM_ABI_VERSION 4
 #define NDDM_SUMMARY_K 10
 
 /* summary_stats[b, :] (single_trial_alpha_not_scaled.py:205-211,
@@ -106,6 +107,16 @@ enum nddm_flags {
                                  Box-Muller pair (16-bit radius uniform + 16-bit angle) instead of two, i.e. 8 normals per
                                  Philox block instead of 4 -- ~25 % faster.  The path noise then has |z| <= 5.65 and a 2^-16
                                  grid in the radius; a different (equally reproducible) random stream than the default */
+    NDDM_STATE_F64 = 8,       /* (ABI 4; NDDM_BASIC_DDM_DC and NDDM_SINGLE_TRIAL, not with NDDM_BRIDGE / NDDM_GAUSS_PACKED / the wire format)
+                                 the REFERENCE'S state arithmetic: the evidence is a float64 in its natural units,
+                                 evidence += drift*dt + sqrt(dt)*dc*normal (basic_ddm_dc.py:91-103; single_trial_alpha_not_scaled.py:113-128),
+                                 every operation a separate IEEE double operation in the reference's order, the loop condition
+                                 (evidence > 0) && (evidence < boundary) on doubles; `normal` is the exact double product of the float32
+                                 Box-Muller radius and cosine / sine of the same random stream.  With NDDM_GAUSS_EXACT the (step index,
+                                 choice) of every trial equals oracle_philox_simulate_f64's bit for bit (oracle/ddm_oracle.c), i.e. the
+                                 float32-state deviation stated at the top of this file becomes a measured option; the single-trial
+                                 model's boundary is formed in double from the same auxiliary normals, its external datum z1 stays the
+                                 float32 expression.  Costs ~25-30 % of the rate (4 extra double operations per step). */
     NDDM_BRIDGE = 2           /* (alpha_not_scaled only) Brownian-bridge boundary correction: between two grid points
                                  inside (0, a) the path crosses a boundary with probability exp(-2 d0 d1 / (sigma^2 dt));
                                  removes the O(sqrt(dt)) late-detection bias of plain Euler-Maruyama against the exact
@@ -257,6 +268,9 @@ int nddm_draw_prior_indirect(int32_t model, int64_t B, uint64_t seed, uint64_t s
 /* sha256 (hex) of the sources the library was built from, as build.py computed it ("unknown" for a hand-made build): the
  * Python binding refuses a library whose sources have changed since */
 const char *nddm_source_hash(void);
+
+/* "hipcc=<version>": the compiler that built this library, recorded at build time */
+const char *nddm_build_info(void);
 
 /* ---- debugging aid used by the parity tests: the 4 normals of Philox block (c0..c3) under key (k0,k1) --- */
 int nddm_debug_normals(const uint32_t *counters /* device u32 [n,4] */, int64_t n, uint32_t k0, uint32_t k1,

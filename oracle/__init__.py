@@ -73,7 +73,7 @@ def lib():
         L.oracle_philox_simulate.restype = ctypes.c_int
         ip = ctypes.POINTER(ctypes.c_int32)
         L.oracle_philox_simulate_f64.argtypes = [ctypes.c_int, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
-                                                 ctypes.c_uint64, ctypes.c_uint64, ip, ip, ctypes.c_int]
+                                                 ctypes.c_uint64, ctypes.c_uint64, ip, ip, fp, fp, ctypes.c_int]
         L.oracle_philox_simulate_f64.restype = ctypes.c_int
         L.oracle_philox_normals4.argtypes = [ctypes.c_uint32] * 6 + [fp]
         L.oracle_philox_block.argtypes = [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_uint32)]
@@ -179,10 +179,12 @@ def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, s
     return res
 
 
-def philox_simulate_f64(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, set_offset=0, threads=1):
+def philox_simulate_f64(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, set_offset=0, threads=1, want_outputs=False):
     """The REFERENCE'S float64 recurrence (basic_ddm_dc.py:91-103; single_trial_alpha_not_scaled.py:113-128) on the device
     stream's normals: (k i32[B,N], choice i32[B,N]) -- compare with philox_simulate(want_k=True) trial by trial to state how
-    often the float32 integrator of the product ends on another (step, choice) than the float64 one."""
+    often the float32 integrator of the product ends on another (step, choice) than the float64 one.
+    want_outputs=True: a dict instead -- 'k', 'choice', and 'trials' f32[B,N,2] / 'summary' f32[B,10] exactly as the device writes
+    them under NDDM_STATE_F64 (the checker of that option)."""
     L = lib()
     P = L.oracle_model_nparams(model)
     p = np.ascontiguousarray(params, dtype=np.float32)
@@ -193,10 +195,14 @@ def philox_simulate_f64(model, params, n_trials, dt=0.01, max_steps=400.0, seed=
     k = np.empty((B, n_trials), np.int32)
     c = np.empty((B, n_trials), np.int32)
     ip = ctypes.POINTER(ctypes.c_int32)
+    trials = np.empty((B, n_trials, 2), np.float32) if want_outputs else None
+    summ = np.empty((B, SUMMARY_K), np.float32) if want_outputs else None
     rc = L.oracle_philox_simulate_f64(model, _fptr(p), B, n_trials, np.float32(dt), int(np.ceil(max_steps)), seed, set_offset,
-                                      k.ctypes.data_as(ip), c.ctypes.data_as(ip), threads)
+                                      k.ctypes.data_as(ip), c.ctypes.data_as(ip), _fptr(trials), _fptr(summ), threads)
     if rc != 0:
         raise ValueError(f"oracle_philox_simulate_f64 rc={rc}")
+    if want_outputs:
+        return {"k": k, "choice": c, "trials": trials, "summary": summ}
     return k, c
 
 

@@ -40,8 +40,10 @@ def battery():
             r = oracle.philox_simulate(oracle.M_EXPLICIT, basic[:4, [0, 2, 3, 4]], n, dt=dt, max_steps=cap, seed=9, bounds=bounds)
             take(r["trials"], r["summary"])
     take(oracle.philox_simulate(oracle.M_BASIC, basic, 1200, dt=0.01, max_steps=400.0, seed=1, threads=3)["summary"])      # > 512 trials per set, OpenMP
-    f = oracle.philox_simulate_f64(oracle.M_BASIC, basic, 50, dt=0.001, max_steps=4000.0, seed=2)
-    take(*[v for v in (f.values() if isinstance(f, dict) else f)])
+    take(*oracle.philox_simulate_f64(oracle.M_BASIC, basic, 50, dt=0.001, max_steps=4000.0, seed=2))
+    for m, par in ((oracle.M_BASIC, basic), (oracle.M_SINGLE, single)):               # ... with the outputs NDDM_STATE_F64 writes
+        f = oracle.philox_simulate_f64(m, par, 33, dt=0.01, max_steps=403.0, seed=3, want_outputs=True)
+        take(f["k"], f["choice"], f["trials"], f["summary"])
     take(oracle.philox_normals4(1, 2, 3, 4, 5, 6), oracle.philox_block(1, 2, 3, 4, 5, 6))
     oracle.mt_seed(2023)
     take(np.array([oracle.mt_gauss(), oracle.mt_double()]), oracle.mt_basic([1.5, 1.2, .5, .35, 1.0], 40),

@@ -129,6 +129,41 @@ def test_packed_layout_bit_parity(model, dt, max_steps):
     assert (g4["trials"][..., 0] != g["trials"][..., 0]).mean() > 0.5
 
 
+@pytest.mark.parametrize("model", ["basic", "single"])
+@pytest.mark.parametrize("dt,max_steps,N", [(0.01, 400.0, 300), (0.001, 4000.0, 300), (0.01, 403.0, 77), (0.0005, 20000.0, 40),
+                                            (0.001, 4000.0, 1200)])
+def test_state_f64_bit_parity(model, dt, max_steps, N):
+    """NDDM_STATE_F64: the reference's float64 recurrence (basic_ddm_dc.py:91-103; single_trial_alpha_not_scaled.py:113-128) on the
+    device -- every trial's (step, choice), the float pairs and the fused summaries equal oracle_philox_simulate_f64's bit for bit,
+    at both step sizes, with a cap that is not a multiple of 4, with a cap >= 2^14 (the 32-bit staging kernels) and with tiled sets."""
+    import oracle
+    from bayesflow_nddms_amd import engine
+    B = 96
+    p = _params(model, B, 1234 + B)
+    g = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=2025, set_offset=7, fast=False, state_f64=True)
+    o = oracle.philox_simulate_f64(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=2025, set_offset=7, threads=8, want_outputs=True)
+    gt, gs = g["trials"].cpu().numpy(), g["summary"].cpu().numpy()
+    assert np.array_equal(gt.view(np.uint32), o["trials"].view(np.uint32))
+    assert np.array_equal(np.isnan(gs), np.isnan(o["summary"]))
+    assert np.array_equal(np.nan_to_num(gs).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32))
+    # the float32 state (the default) ends nearly every trial on the same (step, choice); the few that differ are the stated deviation
+    f32 = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=2025, set_offset=7, fast=False)["trials"].cpu().numpy()
+    assert 0.995 < (f32[..., 0] == gt[..., 0]).mean() <= 1.0
+    # fast transform + float64 state: same stream, nearly every trial the same
+    ff = engine.simulate(MODELS[model], p, N, dt=dt, max_steps=max_steps, seed=2025, set_offset=7, fast=True, state_f64=True)["trials"].cpu().numpy()
+    assert (ff[..., 0] == gt[..., 0]).mean() > 0.99
+
+
+def test_state_f64_argument_checks():
+    from bayesflow_nddms_amd import engine
+    with pytest.raises(ValueError, match="NDDM_STATE_F64"):
+        engine.simulate(3, prior_util.alpha_ns_prior(2, 1), 10, state_f64=True)
+    with pytest.raises(ValueError, match="NDDM_STATE_F64"):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, state_f64=True, packed=True)
+    with pytest.raises(ValueError, match="NDDM_STATE_F64"):
+        engine.simulate(0, prior_util.basic_prior(2, 1), 10, state_f64=True, want_codes=True)
+
+
 def test_packed_layout_argument_checks():
     from bayesflow_nddms_amd import engine
     with pytest.raises(ValueError):

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/nddm.h but not exported"
     assert set(syms) <= set(_lib.EXPORTS)
-    assert _lib.lib().nddm_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().nddm_abi_version() == _lib.ABI_VERSION == 4
     assert _lib.lib().nddm_source_hash().decode() == build.source_hash()
     assert _lib.lib().nddm_summary_k() == 10
     assert [_lib.lib().nddm_model_nparams(m) for m in range(6)] == [5, 8, 8, 6, 4, -1]
@@ -41,6 +41,11 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 0, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_SHAPE
     assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, -0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_PARAM
     assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 7, dummy, None, None) == _lib.NDDM_ERR_PARAM
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 16, dummy, None, None) == _lib.NDDM_ERR_PARAM     # unknown flag
+    assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 8 | 4, dummy, None, None) == _lib.NDDM_ERR_PARAM  # STATE_F64 + packed
+    assert L.nddm_alpha_not_scaled_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 8, 0.1, 0, dummy, None, None, None) == _lib.NDDM_ERR_PARAM
+    assert b"NDDM_STATE_F64" in L.nddm_last_error()
+    assert L.nddm_build_info().startswith(b"hipcc=") and L.nddm_build_info() != b"hipcc=unknown"
     assert L.nddm_basic_ddm_dc_simulate(None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL
     assert L.nddm_basic_ddm_dc_simulate(dummy, 4, 10, 0.01, 400, 0, 0, 0, None, None, None) == _lib.NDDM_ERR_NULL
     assert L.nddm_explicit_boundary_simulate(dummy, None, 4, 10, 0.01, 400, 0, 0, 0, dummy, None, None) == _lib.NDDM_ERR_NULL

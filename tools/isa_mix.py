@@ -32,6 +32,9 @@ KERNELS = {"basic": (0, 1, 1, 0, 1, 0, 0), "single": (1, 1, 1, 0, 1, 0, 0), "sin
 KERNELS.update({k + "_exact": (m, 0, c, b, sm, pk, vk) for k, (m, f, c, b, sm, pk, vk) in list(KERNELS.items())})
 KERNELS.update({k + "_packed": (m, f, c, b, sm, 1, vk) for k, (m, f, c, b, sm, pk, vk) in list(KERNELS.items()) if not b})  # NDDM_GAUSS_PACKED
 KERNELS["basic_vkeys"] = (0, 1, 1, 0, 1, 0, 1)               # the small-launch variant: round keys in VGPRs
+KERNELS = {k: v + (0,) for k, v in KERNELS.items()}          # (..., F64 = false)
+for _k in ("basic", "single", "basic_exact", "single_exact"):
+    KERNELS[_k + "_f64"] = KERNELS[_k][:7] + (1,)            # NDDM_STATE_F64: the reference's float64 recurrence
 
 # fallback costs (profiles/r2_ubench_valu.txt, 8 waves/SIMD): cycles per wave64 instruction per SIMD
 COST = {"v_mad_u64_u32": 4.61, "v_xor_b32": 2.34, "v_cvt_f32_u32": 4.13, "v_cvt_f32_i32": 4.13, "v_log_f32": 8.21,
@@ -124,7 +127,7 @@ def disassemble(so_path=SO):
 
 def kernel_insts(txt, targs):
     """[(address, mnemonic, operand text, branch target or None)] of one sim_kernel instantiation."""
-    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dELb%dELb0EEEvNS_7SimArgsE" % targs      # (..., CODES = false)
+    sym = "_ZN4nddm10sim_kernelILi%dELb%dELb%dELb%dELb%dELb%dELb%dELb0ELb%dEEEvNS_7SimArgsE" % targs      # (..., CODES = false, F64)
     lines = txt.splitlines()
     start = next(i for i, l in enumerate(lines) if l.endswith(f"<{sym}>:"))
     insts = []

@@ -41,7 +41,7 @@ python3 bench.py --dist --backend nccl > "$OUT/r5_bench_dist_none_world1.json" 2
 # python3 tools/full_training_run.py 500 basic gpurun_out/basic_500.pt > "$OUT/r5_full_training_run.txt"; python3 tools/locate_tail_draws.py gpurun_out/basic_500.pt basic 500 100000 > "$OUT/r5_tail_draw_incidence.txt"
 python3 tools/resource_table.py --train --md > "$OUT/r5_train_resource_table.md" 2>/dev/null && echo "ok train_resource_table"
 # rocprofv3 kernel trace of the graph-replayed training loop -> kernels per iteration, GPU busy fraction
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/train_trace" -o train --output-format csv -- python3 "$ROOT/bench.py" --train --train-mode graph > "$OUT/train_trace_bench.json" 2> "$OUT/train_trace.err") && echo "ok train_trace"
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/train_trace" -o train --output-format csv -- "$(readlink -f "$(command -v python3)")" "$ROOT/bench.py" --train --train-mode graph > "$OUT/train_trace_bench.json" 2> "$OUT/train_trace.err") && echo "ok train_trace"
 python3 tools/train_trace_summary.py "$(dirname "$(find gpurun_out/train_trace -name '*kernel_trace.csv' | head -1)")" > "$OUT/r5_train_graph_trace.md" 2>&1 && echo "ok train_trace_summary"
 python3 tools/train_iteration_timeline.py "$(dirname "$(find gpurun_out/train_trace -name '*kernel_trace.csv' | head -1)")" --all > "$OUT/r5_train_timeline.txt" 2>&1 && echo "ok train_timeline"
 cp "$(find gpurun_out/train_trace -name '*kernel_stats.csv' | head -1)" "$OUT/r5_train_graph_kernel_stats.csv"

@@ -14,7 +14,7 @@ python3 bench.py --gpus 2 --share-device --backend gloo --train --train-iters 60
 python3 tools/resource_table.py --train --md > "$OUT/r5_train_resource_table.md" 2>/dev/null && echo "ok train_resource_table"
 for form in plain gather; do
   extra=""; [ $form = gather ] && extra="--dist --backend nccl"
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/train_trace_$form" -o train --output-format csv -- python3 "$ROOT/bench.py" --train --train-mode graph $extra > "$OUT/train_trace_bench_$form.json" 2> "$OUT/train_trace_$form.err") && echo "ok train_trace $form"
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/train_trace_$form" -o train --output-format csv -- "$(readlink -f "$(command -v python3)")" "$ROOT/bench.py" --train --train-mode graph $extra > "$OUT/train_trace_bench_$form.json" 2> "$OUT/train_trace_$form.err") && echo "ok train_trace $form"
   D="$(dirname "$(find gpurun_out/train_trace_$form -name '*kernel_trace.csv' | head -1)")"
   if [ $form = plain ]; then
     python3 tools/train_trace_summary.py "$D" > "$OUT/r5_train_graph_trace.md" 2>&1 && echo "ok train_trace_summary"

@@ -20,11 +20,11 @@ MODELS = {0: "basic", 1: "single", 2: "single_alt", 3: "alpha_ns", 4: "explicit"
 
 
 def pretty(name):
-    m = re.match(r"_ZN4nddm10sim_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+    m = re.match(r"_ZN4nddm10sim_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
     if m:
-        mod, fast, cap4, bridge, small, packed, vkeys, codes = (int(x) for x in m.groups())
+        mod, fast, cap4, bridge, small, packed, vkeys, codes, f64 = (int(x) for x in m.groups())
         return (f"sim_kernel<{MODELS[mod]}, {'fast' if fast else 'exact'}, cap4={cap4}, bridge={bridge}, small={small}, "
-                f"packed={packed}, vkeys={vkeys}{', codes' if codes else ''}>")
+                f"packed={packed}, vkeys={vkeys}{', codes' if codes else ''}{', state_f64' if f64 else ''}>")
     m = re.match(r"_ZN(?:4nddm|10nddm_train|12nddm_deepset|11nddm_update)(\d+)", name)
     if m:
         n = int(m.group(1))

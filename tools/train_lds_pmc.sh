@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/pmc_train
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$OUT"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES \
-    -d "$OUT" -o t --output-format csv -- python3 "$ROOT/bench.py" --train --train-mode graph --train-iters 20 \
+    -d "$OUT" -o t --output-format csv -- "$(readlink -f "$(command -v python3)")" "$ROOT/bench.py" --train --train-mode graph --train-iters 20 \
     > "$ROOT/gpurun_out/pmc_train.json" 2> "$ROOT/gpurun_out/pmc_train.err" || { tail -3 "$ROOT/gpurun_out/pmc_train.err"; exit 1; }
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, sys
