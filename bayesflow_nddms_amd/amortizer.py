@@ -546,13 +546,37 @@ class AmortizedPosterior(nn.Module):
         return (0.5 * (z ** 2).sum(-1) - log_det).mean()
 
     @torch.no_grad()
-    def sample(self, input_dict, n_samples, to_numpy=True):
+    def sample(self, input_dict, n_samples, to_numpy=True, reject_outside=None, max_redraws=16):
         """amortizer.sample(dict, n_samples) (basic_ddm_dc.py:223): [n_samples, P] for a single data set,
-        [B, n_samples, P] for a batch."""
+        [B, n_samples, P] for a batch.
+
+        reject_outside: None (the default: every draw of the flow is returned, which is what the reference's call gets) or a
+        (low, high) pair of length-P sequences -- draws with a component outside [low, high] (or non-finite) are REDRAWN from fresh
+        base normals, i.e. the sample is from q(theta | data) restricted to the box.  Why one might want it: a sharply trained
+        coupling flow carries ~1e-6 of its mass in a far tail (one draw in 1e5-1e6 lands 1e4-1e6 prior widths away, DESIGN.md
+        section 8), and a posterior MEAN over 10 000 draws -- the statistic the reference's recovery plots use, basic_ddm_dc.py:
+        230-236 -- is carried off by one such draw; `priors.prior_box(model)` is a generous box (the prior's support widened by
+        its own width on each side) that removes them and nothing else.  The number of redrawn draws of the last call is kept in
+        `self.last_redrawn` (0 with the option off)."""
         cond = self._conditions(input_dict)
         B = cond.shape[0]
-        z = torch.randn(B * n_samples, self.inference_net.num_params, device=cond.device)
-        out = self.inference_net.inverse(z, cond.repeat_interleave(n_samples, dim=0))
+        P = self.inference_net.num_params
+        z = torch.randn(B * n_samples, P, device=cond.device)
+        cond_rep = cond.repeat_interleave(n_samples, dim=0)
+        out = self.inference_net.inverse(z, cond_rep)
+        self.last_redrawn = 0
+        if reject_outside is not None:
+            lo, hi = (torch.as_tensor(np.asarray(v, dtype=np.float32), device=out.device) for v in reject_outside)
+            if lo.shape != (P,) or hi.shape != (P,):
+                raise ValueError(f"reject_outside must be a (low, high) pair of length-{P} sequences")
+            for _ in range(int(max_redraws)):
+                bad = ((out < lo) | (out > hi) | ~torch.isfinite(out)).any(dim=-1)
+                idx = bad.nonzero(as_tuple=False)[:, 0]
+                if idx.numel() == 0:
+                    break
+                self.last_redrawn += int(idx.numel())
+                out[idx] = self.inference_net.inverse(torch.randn(idx.numel(), P, device=out.device), cond_rep[idx])
+            out = torch.minimum(torch.maximum(torch.nan_to_num(out, nan=0.0), lo), hi)      # (what max_redraws rounds did not cure: clipped)
         out = out.reshape(B, n_samples, -1)
         if B == 1:
             out = out[0]

@@ -65,6 +65,20 @@ def draw_prior_scale():
     return np.hstack((p, gamma))
 
 
+# the supports of the priors above (drift ~ N(0, 2): +- 5 sd), per parameter in the reference's order
+PRIOR_SUPPORT = {"basic": ([-10.0, 0.0, 0.0, 0.0, 0.0], [10.0, 10.0, 1.0, 1.5, 10.0]),
+                 "single": ([-10.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], [10.0, 10.0, 1.0, 1.5, 3.0, 10.0, 5.0])}
+
+
+def prior_box(model="basic", widen=1.0):
+    """(low, high): the prior's support widened by `widen` times its own width on each side -- the generous box
+    `AmortizedPosterior.sample(..., reject_outside=prior_box(model))` redraws outside of.  A posterior draw beyond it is not a
+    parameter value the model could have produced the data with; the reference itself counts "model fits in the prior range"
+    before plotting (basic_ddm_dc.py:239-241)."""
+    lo, hi = (np.asarray(v, dtype=np.float64) for v in PRIOR_SUPPORT[model])
+    return lo - widen * (hi - lo), hi + widen * (hi - lo)
+
+
 class DevicePrior:
     """Batched on-device draw_prior: `DevicePrior('basic')(B)` -> torch float32 [B, P] on the GPU.
 

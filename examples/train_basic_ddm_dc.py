@@ -36,10 +36,14 @@ def main():
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # device_id: the communicator is created eagerly on THIS rank's card (as bench.py does); without it the first collective
+        # picks a device from the rank number, which is the wrong card whenever LOCAL_RANK != RANK % gpus
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.manual_seed(0)                                   # identical initial weights on every rank
 
     if a.graph:

@@ -463,3 +463,72 @@ def test_recovery_statistics_are_the_reference_plots_numbers():
     assert conv.dtype == bool and conv.sum() == ((est[:, 3] > 0) & (est[:, 3] < 1)).sum()
     with pytest.raises(ValueError):
         dg.recovery_statistics(true, est[:, :4])
+
+
+def test_bench_plan_for_eight_gpus_touches_no_gpu():
+    """`bench.py --plan --gpus 8`: the pre-flight of the N > 1 run the builder cannot make -- what every rank allocates and moves per step
+    under each gather mode, printed without importing torch or touching a GPU (this box has none), so that the first 8-GPU run does
+    not discover an out-of-memory or a link-bound default."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH="")
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "8"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert " torch" not in r.stderr                                                     # (-X importtime lists every import on stderr)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["plan"] is True and d["n_gpus"] == 8 and d["sets_per_gpu"] == 1_000_000 and d["n_trials"] == 300
+    g = d["gather"]
+    # gather=trials: 2.4 GB per shard, 8 shards gathered, two buffers of it; 16.8 GB received per rank per step
+    assert g["trials"]["buffers"]["gathered trials x2"] == 2 * 8 * 2_400_000_000
+    assert g["trials"]["received_bytes_per_rank_per_step"] == 7 * 2_400_000_000
+    assert g["trials"]["hidden_behind_simulate"]["if_one_ring"] is False and g["trials"]["link_bound_even_on_all_links"] is True
+    # the 2-byte codes: a quarter of the bytes on the wire (+ the parameter rows), the decoded floats exist on every rank
+    assert g["codes"]["sent_bytes_per_rank_per_step"] == 1_000_000 * (300 * 2 + 5 * 4)
+    assert g["codes"]["buffers"]["decoded trials f32[W,B,N,2] x2"] == 2 * 8 * 2_400_000_000
+    assert g["summary"]["received_bytes_per_rank_per_step"] == 7 * 40_000_000 and g["summary"]["hidden_behind_simulate"]["if_one_ring"] is True
+    assert all(v["fits_hbm"] for v in g.values()) and max(v["hbm_fraction"] for v in g.values()) < 0.25
+    # the driver's plain command gathers nothing; its side legs are the two forms that fit and stay hidden
+    pc = d["plain_command"]
+    assert pc["gather"] == "none" and set(pc["side_legs"]) == {"summary", "codes"} and pc["strong"]["sets_per_gpu"] == 125_000
+    assert all(v["runs_if_free_memory_exceeds"] < 0.3 * d["hbm_bytes_per_gpu"] for v in pc["side_legs"].values())
+    # a shape that does NOT fit says so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "8", "--sets", "8000000"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    big = json.loads(r.stdout.strip().splitlines()[-1])["gather"]
+    assert big["trials"]["fits_hbm"] is False and big["none"]["fits_hbm"] is True
+
+
+def test_host_shim_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """SURVEY section 5's `-fsanitize=address` host shim, on the PRODUCT: the host side of csrc/nddm_kernels.hip -- launch slots, graph
+    arenas, the per-thread bind, free_list, the knob snapshots under one mutex, every entry point's validation and its no-device error
+    path -- built with AddressSanitizer + UndefinedBehaviorSanitizer (`-Xarch_host`: host code only, the gfx950 code object is the
+    product's; sanitizers never go to the GPU pool) and driven by tests/host_shim_battery.py in a child process that loads the
+    library the way a C program would: no report, and the same return codes and error strings as the normal build."""
+    import glob
+    import subprocess
+    import sys
+    from bayesflow_nddms_amd import build
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import host_shim_battery
+    build.build_hip()
+    want, n_checks = host_shim_battery.battery(build.SO_PATH)
+    assert n_checks > 800
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rts:
+        pytest.skip("this ROCm has no clang AddressSanitizer runtime")
+    so = str(tmp_path / "libnddm_hip_san.so")
+    flags = [f for f in build.HIPCC_FLAGS if f != "-O3"] + ["-O1", "-fno-omit-frame-pointer"]
+    for f in ("-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fsanitize-address-use-after-scope"):
+        flags += ["-Xarch_host", f]
+    cc = subprocess.run([build._hipcc()] + flags + [f'-DNDDM_SOURCE_HASH="{build.source_hash()}"', "-o", so] + build.SOURCES,
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert "__asan_init" in syms and "__ubsan_handle" in syms                   # the host code really is instrumented
+    env = dict(os.environ, LD_PRELOAD=rts[0], NDDM_HIP_LIB=so, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_shim_battery.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == f"SHIM {want} ({n_checks} checks)"

@@ -79,6 +79,19 @@ def test_issue_model_reads_the_shipped_library():
         assert sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
     t = im.tally(im.step_loop(im.kernel_insts(txt, im.KERNELS["basic_packed"])), cost, sgpr_cost)
     assert 95 <= t["valu"] <= 105 and sum(m["n"] for m in t["mix"] if m["op"] == "v_mad_u64_u32") == 16
+    # NDDM_STATE_F64: the same generator + per step two double multiplies, two double adds, two double compares, a conversion
+    t = im.tally(im.step_loop(im.kernel_insts(txt, im.KERNELS["basic_f64"])), cost, sgpr_cost)
+    n = {m["op"]: m["n"] for m in t["mix"]}
+    assert n["v_mad_u64_u32"] == 16 and n["v_mul_f64"] == 8 and n["v_add_f64"] == 8 and 75 <= t["valu"] <= 95, t["valu"]
+    # the TRACKED issue model bench.py quotes (roofline_valu.frac) is the one of THIS library: regenerate it with
+    # tools/refresh_issue_model.sh whenever the kernels change
+    import glob
+    import json
+    import re
+    newest = max(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
+    d = json.load(open(newest))
+    assert d["library_sha256_16"] == digest, (newest, "stale: run tools/refresh_issue_model.sh")
+    assert {"basic", "single", "alpha_ns_bridge", "basic_exact", "basic_exact_f64", "basic_f64"} <= set(d["kernels"])
 
 
 @pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc missing")

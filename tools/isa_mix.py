@@ -62,7 +62,8 @@ UBENCH_ROWS = {"v_fma_f32 (3 regs)": ["v_fma_f32", "v_med3_f32"], "v_fmamk_f32":
                "v_cndmask_e64 (s)": ["v_cndmask_b32"], "v_pk_fma_f32": ["v_pk_fma_f32"], "v_pk_mul_f32": ["v_pk_mul_f32"],
                "v_pk_add_f32": ["v_pk_add_f32"], "v_bitop3_b32 (3 regs)": ["v_bitop3_b32"], "v_fmac_f32": ["v_fmac_f32"],
                "v_mad_u64_u32 (sgpr)": ["v_mad_u64_u32"],
-               "v_add_co_u32_e64": ["v_add_co_u32", "v_addc_co_u32"]}
+               "v_add_co_u32_e64": ["v_add_co_u32", "v_addc_co_u32"],
+               "v_add_f64": ["v_add_f64"], "v_mul_f64": ["v_mul_f64"], "v_fma_f64 (3 regs)": ["v_fma_f64"], "v_cvt_f64_f32": ["v_cvt_f64_f32"], "v_cmp_lt_f64": ["v_cmp_f64"]}
 
 
 def load_ubench(path):
@@ -175,7 +176,7 @@ def tally(body, cost, sgpr_cost):
     for _, op, args, _ in body:
         op = re.sub(r"_e(32|64)$", "", op)
         if op.startswith("v_cmp"):
-            op = "v_cmp"
+            op = "v_cmp_f64" if op.endswith("_f64") else "v_cmp"
         if op in FULL_RATE and re.search(r"\bs\d+\b|s\[|vcc|exec", args.split(",", 1)[1] if "," in args else ""):
             op += " (sgpr)"
         t[op] += 1

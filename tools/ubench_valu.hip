@@ -166,6 +166,22 @@ DEF_KERNEL(k_mad64_s, US8, OP8_MADS, SINKU)
 DEF_KERNEL(k_fmac, F8, OP8("v_fmac_f32"), SINKF)
 DEF_KERNEL(k_add_co, U8, asm volatile("v_add_co_u32_e64 %0, s[20:21], 1, %0\n v_add_co_u32_e64 %1, s[22:23], 1, %1\n v_add_co_u32_e64 %2, s[20:21], 1, %2\n v_add_co_u32_e64 %3, s[22:23], 1, %3\n v_add_co_u32_e64 %4, s[20:21], 1, %4\n v_add_co_u32_e64 %5, s[22:23], 1, %5\n v_add_co_u32_e64 %6, s[20:21], 1, %6\n v_add_co_u32_e64 %7, s[22:23], 1, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20", "s21", "s22", "s23");, SINKU)
 
+// float64 rows (NDDM_STATE_F64: the reference's double recurrence): add / mul / fma on 64-bit register pairs, the f32 -> f64
+// conversion, a double compare
+#define D8 double a0 = threadIdx.x + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; double c = 1.0000001; double d = 0.9999999
+#define SINKD out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7)
+DEF_KERNEL(k_add_f64, D8, OP8("v_add_f64"), SINKD)
+DEF_KERNEL(k_mul_f64, D8, OP8("v_mul_f64"), SINKD)
+DEF_KERNEL(k_fma_f64, D8, OP8_3D("v_fma_f64", ""), SINKD)
+#define OP8_CVT64 \
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a0) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a1) : "v"(f1)); \
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a2) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a3) : "v"(f1)); \
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a4) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a5) : "v"(f1)); \
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a6) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a7) : "v"(f1));
+#define D8F D8; float f0 = threadIdx.x + 0.5f, f1 = f0 + 1.0f
+DEF_KERNEL(k_cvt_f64_f32, D8F, OP8_CVT64, SINKD)
+DEF_KERNEL(k_cmp_f64, D8, asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %0\n v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %0\n v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %0\n v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %0" :: "v"(a0), "v"(c) : "vcc");, SINKD)
+
 typedef void (*kern_t)(float *, uint64_t *);
 struct Entry { const char *name; kern_t k; };
 
@@ -190,6 +206,8 @@ int main(int argc, char **argv)
                   {"v_bitop3_b32 (3 regs)", k_bitop3_3r}, {"v_add3_u32 (3 regs)", k_add3_3r}, {"v_fma_f32 (3 regs)", k_fma_3r},
                   {"v_fmamk_f32", k_fmamk}, {"v_mad_u64_u32 (sgpr)", k_mad64_s}, {"v_cmpx_le_f32", k_cmpx},
                   {"v_alignbit_b32 (vgpr, imm)", k_alignbit_v}, {"v_alignbit_b32 (3 vgprs)", k_alignbit_vv},
+                  {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}, {"v_fma_f64 (3 regs)", k_fma_f64},
+                  {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cmp_lt_f64", k_cmp_f64},
                   {"2 log + 6 xor", k_mix_log_xor},
                   {"2 sin + 6 mul_lo", k_mix_sin_mullo}};
     printf("%-28s", "instr \\ waves/SIMD");
