@@ -611,6 +611,8 @@ class Trainer:
         self.loss_history = []
         self.replay = []
         self._graph_pos = None             # graph=True: where the last train_* call left the random stream and the replay buffer
+        self._graph_opt = None             # graph=True: the running call's optimizer / schedule state at its last epoch checkpoint
+        self._graph_resume = None          # ... as load_pretrained_network found it in ckpt.pt: an interrupted call is continued
 
     def _simulate(self, batch_size):
         return self.configurator(self.generative_model(batch_size))
@@ -692,11 +694,23 @@ class Trainer:
                              "(it carries `graph_spec`), a ROCm device, and no caller-supplied optimizer")
         from .graph_trainer import TRAIN_OFFSET_BASE, GraphTrainer
         val = []
-        with GraphTrainer(self.amortizer, batch_size=batch_size, total_steps=epochs * iterations_per_epoch, learning_rate=self.lr,
+        total = epochs * iterations_per_epoch
+        resume, self._graph_resume = self._graph_resume, None
+        with GraphTrainer(self.amortizer, batch_size=batch_size, total_steps=total, learning_rate=self.lr,
                           device=self.device, offset_base=TRAIN_OFFSET_BASE, **spec) as gt:
+            done_epochs = 0
+            if (resume is not None and int(resume["total_steps"]) == total and int(resume["iterations_per_epoch"]) == iterations_per_epoch
+                    and int(resume["batch_size"]) == batch_size and bool(resume["replay"]) == bool(replay) and 0 < int(resume["iteration"]) < total):
+                # The checkpoint was written BETWEEN TWO EPOCHS of a call of this very shape: that call is continued -- Adam's moments
+                # and step count, the place on the cosine schedule, the losses so far -- and only its remaining epochs run, so an
+                # interrupted run + its resumption equal the uninterrupted run.  (Any other call after a load is a run of its own,
+                # as every train_* call is: fresh Adam, its own schedule.)
+                gt.load_optimizer_state(resume)
+                done_epochs = int(resume["iteration"]) // iterations_per_epoch
+                self.loss_history = self.loss_history[:max(0, len(self.loss_history) - int(resume["iteration"]))]      # (gt brings them back)
             if self._graph_pos is not None:
                 gt.set_position(self._graph_pos)
-            for _ in range(epochs):
+            for _ in range(done_epochs, epochs):
                 if replay:
                     gt.train_experience_replay(iterations_per_epoch, capacity_in_batches=capacity_in_batches)
                 else:
@@ -705,10 +719,15 @@ class Trainer:
                     val.append(gt.validation_loss(self.configurator(validation_sims)))
                 if save_checkpoint and self.checkpoint_path:
                     self._graph_pos = gt.position()
+                    self._graph_opt = dict(gt.optimizer_state(), iterations_per_epoch=int(iterations_per_epoch), batch_size=int(batch_size),
+                                           replay=bool(replay))
                     self.loss_history_graph = gt.loss_history()
                     self.save_checkpoint(extra_losses=self.loss_history_graph)
             self._graph_pos = gt.position()
+            self._graph_opt = None             # the call is complete: nothing to continue
             self.loss_history += gt.loss_history()
+        if save_checkpoint and self.checkpoint_path:
+            self.save_checkpoint()             # ... and the checkpoint says so (a later load starts a run of its own)
         self._optimizer_spent = True
         return val
 
@@ -769,7 +788,10 @@ class Trainer:
             state["stream_state"] = self.stream_state.get_state()
         if self._graph_pos is not None:
             state["graph_position"] = self._graph_pos
-        torch.save(state, os.path.join(self.checkpoint_path, "ckpt.pt"))
+        if self._graph_opt is not None:        # graph=True, written between two epochs of a call: what continues that call
+            state["graph_optimizer"] = self._graph_opt
+        from .graph_trainer import plain_state
+        torch.save(plain_state(state), os.path.join(self.checkpoint_path, "ckpt.pt"))      # plain data only: loads with weights_only=True
         with open(os.path.join(self.checkpoint_path, "history.pkl"), "wb") as f:
             pickle.dump({"loss_history": state["loss_history"]}, f)
 
@@ -777,7 +799,7 @@ class Trainer:
         path = os.path.join(self.checkpoint_path or "", "ckpt.pt")
         if not os.path.exists(path):
             return False
-        state = torch.load(path, map_location=self.device, weights_only=False)       # (our own file: the replay generator's state is a dict)
+        state = torch.load(path, map_location=self.device, weights_only=True)        # (plain_state(): tensors, numbers, strings -- no pickle code)
         self.amortizer.load_state_dict(state["model"])
         self.optimizer.load_state_dict(state["optimizer"])
         self._optimizer_spent = False      # the loaded moments serve the next train_* call (which sets its own schedule)
@@ -785,6 +807,7 @@ class Trainer:
         if self.stream_state is not None and "stream_state" in state:
             self.stream_state.set_state(state["stream_state"])
         self._graph_pos = state.get("graph_position", self._graph_pos)      # graph=True: the next call continues the stream
+        self._graph_resume = state.get("graph_optimizer", None)             # ... and, if the file was written mid-call, that call
         return True
 
 

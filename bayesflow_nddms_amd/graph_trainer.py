@@ -49,6 +49,26 @@ from .distributed import shared_prior_N
 # basic_ddm_dc.py:62-80 draws 5 parameters; single_trial_alpha_not_scaled.py:78-102 draws 7, the kernel takes an eighth (gamma = 1)
 _PRIOR_MODEL = {"basic": (engine.BASIC_DDM_DC, 5, 5), "single": (engine.SINGLE_TRIAL, 8, 7)}
 
+def plain_state(obj):
+    """A checkpoint's content reduced to what torch.load(weights_only=True) accepts -- tensors, Python numbers, strings, dicts, lists,
+    tuples -- so that loading a checkpoint never runs arbitrary pickle code: NumPy scalars and arrays (a generator's state, a loss
+    history) become Python numbers / lists, everything else must already be plain."""
+    import numpy as np
+    if isinstance(obj, dict):
+        return {str(k) if not isinstance(k, (str, int)) else k: plain_state(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(plain_state(v) for v in obj)
+    if isinstance(obj, np.generic):
+        return obj.item()
+    if isinstance(obj, np.ndarray):
+        return obj.tolist()
+    if obj is None or isinstance(obj, (bool, int, float, str, torch.Tensor)):
+        return obj
+    if hasattr(obj, "items"):                              # (OrderedDict of a state_dict)
+        return {k: plain_state(v) for k, v in obj.items()}
+    raise TypeError(f"checkpoint content of type {type(obj).__name__} is not plain data")
+
+
 # Where TRAINING runs that share a seed with a generative model start in the 60-bit space of global set indices (csrc/nddm_sim.h:
 # low word + 28 high bits): the model modules' own DevicePrior counts up from 0 -- `generative_model(B)` for validation_sims and the
 # recovery loop's fresh data sets (basic_ddm_dc.py:186-188, 218-223) -- so evaluation never sees a parameter row training has seen.
@@ -805,13 +825,40 @@ class GraphTrainer:
             self._replay = ([(p.to(self.dev), t.to(self.dev), n) for p, t, n in st["replay"]["ring"]], rng, st["replay"]["capacity"])
         self._sync_replicas()          # more than one rank: whatever each rank loaded, all continue from rank 0's state
 
+    def optimizer_state(self):
+        """The part of state_dict() that is neither weights nor position: Adam's two moments, the step counters, the learning rate,
+        this run's iteration count and loss history, and the length of its schedule -- what amortizer.Trainer(graph=True) keeps in
+        ckpt.pt so that a run interrupted between two epochs is CONTINUED (same moments, same place on the cosine schedule) rather
+        than restarted with a fresh Adam."""
+        st = self.state_dict()
+        out = {k: st[k] for k in ("optimizer", "iteration", "step_i", "step_f", "lr", "loss_buf", "loss_host")}
+        out["total_steps"] = int(self.T)
+        return out
+
+    def load_optimizer_state(self, st):
+        """optimizer_state() of an interrupted run with the same total_steps: moments, counters, rate, iteration and losses.  Call
+        BEFORE set_position (the key of the batch-shared N is counted from the iteration)."""
+        self._stream.synchronize()
+        with torch.no_grad():
+            m, v = self._moments()
+            m.copy_(st["optimizer"]["exp_avg"])
+            v.copy_(st["optimizer"]["exp_avg_sq"])
+            if self.optimizer is not None:
+                self.optimizer.state[self._flat_param]["step"].copy_(st["step_i"].to(torch.float32).view(()))
+            self.step_i.copy_(st["step_i"]); self.step_f.copy_(st["step_f"]); self.lr_t.copy_(st["lr"])
+            n = min(self.loss_buf.numel(), st["loss_buf"].numel())
+            self.loss_buf[:n].copy_(st["loss_buf"][:n])
+        self.iteration = int(st["iteration"])
+        self._loss_host = list(st["loss_host"])
+        self._sync_replicas()
+
     def save_checkpoint(self, path):
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save(self.state_dict(), path)
+        torch.save(plain_state(self.state_dict()), path)
 
     def load_checkpoint(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))       # (plain_state: tensors, numbers, strings only)
 
     @property
     def n_graphs(self):

@@ -75,6 +75,9 @@ def lib():
         L.oracle_philox_simulate_f64.argtypes = [ctypes.c_int, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                                  ctypes.c_uint64, ctypes.c_uint64, ip, ip, fp, fp, ctypes.c_int]
         L.oracle_philox_simulate_f64.restype = ctypes.c_int
+        L.oracle_philox_ratcliff.argtypes = [fp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, ctypes.c_int,
+                                             fp, fp, fp, ctypes.c_int]
+        L.oracle_philox_ratcliff.restype = ctypes.c_int
         L.oracle_philox_normals4.argtypes = [ctypes.c_uint32] * 6 + [fp]
         L.oracle_philox_block.argtypes = [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
@@ -172,6 +175,29 @@ def philox_simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=0, s
         res["trials"] = trials
     if want_k:
         res["k"] = k
+    if want_summary:
+        res["summary"] = summ
+    if want_ext:
+        res["ext"] = ext
+    return res
+
+
+def philox_ratcliff(params, n_trials, seed=0, set_offset=0, ext_sigma=0.0, ext_mode=0, want_summary=True, want_ext=False, threads=1):
+    """Section D: simulratcliff (pyhddmjagsutils.py:47-176) on the device stream in float32 -- the element-wise checker of
+    nddm_simulratcliff.  params [B, 6] = Nu, Alpha, Beta, Tau, Eta, Varsigma.  dict(trials f32[B,N,2] = (y, acc), summary, ext)."""
+    p = np.ascontiguousarray(params, dtype=np.float32)
+    if p.ndim == 1:
+        p = p[None]
+    assert p.shape[1] == 6
+    B = p.shape[0]
+    trials = np.empty((B, n_trials, 2), np.float32)
+    summ = np.empty((B, SUMMARY_K), np.float32) if want_summary else None
+    ext = np.empty((B,), np.float32) if want_ext else None
+    rc = lib().oracle_philox_ratcliff(_fptr(p), B, int(n_trials), seed, set_offset, np.float32(ext_sigma), int(ext_mode), _fptr(trials),
+                                      _fptr(summ), _fptr(ext), threads)
+    if rc != 0:
+        raise ValueError(f"oracle_philox_ratcliff rc={rc}")
+    res = {"trials": trials}
     if want_summary:
         res["summary"] = summ
     if want_ext:

@@ -436,6 +436,62 @@ def test_trainer_graph_calls_continue_the_stream_and_a_resumed_run_does_too(tmp_
     assert not torch.isclose(ev[:, None, 0], first_training_rows[None, :, 0]).any()
 
 
+def test_trainer_graph_interrupted_call_is_continued_with_its_adam_state_and_schedule(tmp_path):
+    """Trainer(graph=True) at a learning rate > 0: a call of 3 epochs that dies after the checkpoint of its second epoch, then a NEW
+    Trainer that loads ckpt.pt and makes the same call.  ckpt.pt carries the running call's Adam moments, step counters, learning rate
+    and iteration beside the stream position, so the new call CONTINUES the interrupted one -- only the third epoch runs -- and the
+    two together equal the uninterrupted run: same losses, same final weights.  (With the moments dropped -- the file as round 5
+    wrote it -- the resumed epoch starts from a fresh Adam at the top of a new cosine schedule and its losses differ.)  The file holds
+    plain data only and is read with torch.load(weights_only=True)."""
+    import os
+    import torch
+    from bayesflow_nddms_amd import basic_ddm_dc
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork, Trainer
+
+    def fresh(ck):
+        torch.manual_seed(0)
+        gm = basic_ddm_dc.make_generative_model(batched=True, device_prior=True, as_numpy=False)
+        am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork())
+        return am, Trainer(am, gm, basic_ddm_dc.configurator, checkpoint_path=ck, learning_rate=1e-3, graph=True)
+
+    call = lambda tr: tr.train_experience_replay(epochs=3, iterations_per_epoch=25, batch_size=32, capacity_in_batches=6)
+    am_a, a = fresh(str(tmp_path / "straight"))
+    call(a)
+    ha = np.array(a.loss_history)
+    assert ha.shape == (75,) and np.all(np.isfinite(ha))
+    ck = str(tmp_path / "interrupted")
+    am_b, b = fresh(ck)
+    saves, real_save = [], b.save_checkpoint
+
+    def dying_save(*args, **kw):
+        real_save(*args, **kw)
+        saves.append(1)
+        if len(saves) == 2:
+            raise KeyboardInterrupt("the job is killed after the checkpoint of epoch 2")
+
+    b.save_checkpoint = dying_save
+    with pytest.raises(KeyboardInterrupt):
+        call(b)
+    state = torch.load(os.path.join(ck, "ckpt.pt"), weights_only=True)             # plain data: the safe unpickler reads it
+    assert state["graph_optimizer"]["iteration"] == 50 and state["graph_optimizer"]["total_steps"] == 75
+    assert float(state["graph_optimizer"]["optimizer"]["exp_avg"].abs().sum()) > 0
+    am_c, c = fresh(ck)
+    assert c.load_pretrained_network() and c._graph_resume is not None
+    call(c)
+    hc = np.array(c.loss_history)
+    assert hc.shape == (75,) and np.allclose(hc, ha, rtol=1e-5, atol=1e-5), np.abs(hc - ha).max()
+    for (k, va), vc in zip(am_a.state_dict().items(), am_c.state_dict().values()):
+        assert torch.allclose(va, vc, rtol=1e-5, atol=1e-6), k
+    # the completed call leaves nothing to continue: a load now starts a run of its own (fresh Adam, its own schedule)
+    am_d, d = fresh(ck)
+    assert d.load_pretrained_network() and d._graph_resume is None and len(d.loss_history) == 75
+    # and a call of ANOTHER shape after an interrupted one is a run of its own too
+    am_e, e = fresh(ck)
+    e._graph_resume = dict(state["graph_optimizer"])
+    e.train_online(epochs=1, iterations_per_epoch=10, batch_size=32)
+    assert len(e.loss_history) == 10 and np.all(np.isfinite(e.loss_history))
+
+
 def test_pipelined_loops_feed_the_training_graph_the_right_batch_soak():
     """Integrity soak of the pipelined loop (tests/train_soak_worker.py): learning rate 0, so the loss of iteration k depends on
     batch k alone -- 1200 online + 400 experience-replay iterations at dt=.001 (a 200 us simulate launch beside every training
