@@ -5,7 +5,7 @@ HIPFLAGS = -O3 -ffp-contract=off --offload-arch=gfx950 -std=c++17 -fPIC -shared
 all: lib oracle ubench demo
 
 lib: bayesflow_nddms_amd/libnddm_hip.so
-bayesflow_nddms_amd/libnddm_hip.so: bayesflow_nddms_amd/csrc/nddm_kernels.hip bayesflow_nddms_amd/csrc/nddm_sim.h bayesflow_nddms_amd/csrc/nddm_prepass.h bayesflow_nddms_amd/csrc/nddm_rng.h include/nddm.h
+bayesflow_nddms_amd/libnddm_hip.so: bayesflow_nddms_amd/csrc/nddm_kernels.hip bayesflow_nddms_amd/csrc/nddm_sim.h bayesflow_nddms_amd/csrc/nddm_prepass.h bayesflow_nddms_amd/csrc/nddm_ratcliff.h bayesflow_nddms_amd/csrc/nddm_rng.h include/nddm.h
 	python -m bayesflow_nddms_amd.build    # (hipcc $(HIPFLAGS) + the content hash of the sources, -DNDDM_SOURCE_HASH)
 
 # test infrastructure only (CPU oracle); never linked into the product

@@ -35,6 +35,7 @@ def _declare(L):
         getattr(L, name).argtypes = [fp] + common + [fp, fp, vp]
     L.nddm_alpha_not_scaled_simulate.argtypes = [fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_explicit_boundary_simulate.argtypes = [fp, fp] + common + [fp, fp, vp]
+    L.nddm_simulratcliff.argtypes = [fp, c.c_int64, c.c_int32, c.c_uint64, c.c_uint64, c.c_uint32, c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_simulate.argtypes = [c.c_int32, fp, fp] + common + [c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_simulate_indirect.argtypes = [c.c_int32, fp, fp] + common[:-1] + [fp, c.c_uint32, c.c_float, c.c_int32, fp, fp, fp, vp]
     L.nddm_simulate_codes.argtypes = [c.c_int32, fp] + common[:-1] + [fp, c.c_uint32, fp, fp, fp, vp]
@@ -62,6 +63,7 @@ EXPORTS = [
     "nddm_release_graph_memory", "nddm_debug_set_slot_limit", "nddm_debug_last_launch",
     "nddm_simulate_indirect", "nddm_draw_prior_indirect", "nddm_source_hash", "nddm_simulate_codes", "nddm_decode_codes",
     "nddm_graph_arena_create", "nddm_graph_arena_bind", "nddm_graph_arena_info", "nddm_graph_arena_release", "nddm_build_info",
+    "nddm_simulratcliff",
 ]
 
 

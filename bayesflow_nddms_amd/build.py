@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("NDDM_HIP_LIB") or os.path.join(_HERE, "libnddm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "nddm_kernels.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "nddm_rng.h"), os.path.join(_HERE, "csrc", "nddm_sim.h"),
-           os.path.join(_HERE, "csrc", "nddm_prepass.h"), os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
+           os.path.join(_HERE, "csrc", "nddm_prepass.h"), os.path.join(_HERE, "csrc", "nddm_ratcliff.h"),
+           os.path.join(os.path.dirname(_HERE), "include", "nddm.h")]
 # -ffp-contract=off: the exact Gaussian transform spells out every fma; contraction would change roundings
 HIPCC_FLAGS = ["-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"]
 

@@ -46,6 +46,7 @@
 
 #include "../../include/nddm.h"
 #include "nddm_prepass.h"
+#include "nddm_ratcliff.h"
 #include "nddm_rng.h"
 #include "nddm_sim.h"
 
@@ -943,6 +944,64 @@ int nddm_simulate_indirect(int32_t model, const float *params, const float *boun
     return nddm::simulate(model, params, model == NDDM_EXPLICIT_BOUNDARY ? bounds : nullptr, B, n_trials, dt, max_steps,
                           seed, set_offset, set_offset_dev, flags, ext_sigma, ext_mode, out_trials, out_summary,
                           model == NDDM_ALPHA_NOT_SCALED ? out_extdata : nullptr, stream);
+}
+
+/* simulratcliff (pyhddmjagsutils.py:47-176) as called by alpha_not_scaled.py:95-108: the exact first-passage sampler, no dt.
+ * csrc/nddm_ratcliff.h. */
+int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_t seed, uint64_t set_offset, uint32_t flags,
+                       float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata, void *stream)
+{
+    using namespace nddm;
+    g_err[0] = 0;
+    if (B < 0 || n_trials <= 0) return fail(NDDM_ERR_SHAPE, "B < 0 or n_trials <= 0%s");
+    if (n_trials >= (1 << 30)) return fail(NDDM_ERR_SHAPE, "n_trials must be < 2^30%s");
+    if (set_offset >= (1ull << 60) || set_offset + (uint64_t)B > (1ull << 60))
+        return fail(NDDM_ERR_SHAPE, "set_offset + B must be <= 2^60 (the random stream is keyed by 60 bits of the set index)%s");
+    if (flags > 1u) return fail(NDDM_ERR_PARAM, "nddm_simulratcliff takes NDDM_GAUSS_EXACT or NDDM_GAUSS_FAST only (there is no step size, "
+                                                "hence no bridge, packed layout or float64 state)%s");
+    if (B == 0) return NDDM_OK;
+    if (!params) return fail(NDDM_ERR_NULL, "params is NULL%s");
+    if (!out_trials && !out_summary && !out_extdata) return fail(NDDM_ERR_NULL, "no output buffer given%s");
+    const int tile_n_max = 512;
+    int tiles = (n_trials + tile_n_max - 1) / tile_n_max;
+    const int tile_n = (n_trials + tiles - 1) / tiles;
+    tiles = (n_trials + tile_n - 1) / tile_n;
+    const long long vB = B * (long long)tiles;
+    if (vB >= (1ll << 31)) return fail(NDDM_ERR_SHAPE, "B * ceil(n_trials / 512) must be < 2^31 per launch%s");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (const int rc = check_stream(st)) return rc;
+    RatArgs A;
+    memset(&A, 0, sizeof A);
+    A.params = params; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_extdata;
+    A.n_vsets = vB; A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles;
+    A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32); A.set_offset = set_offset;
+    A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
+    // sets of more than 512 trials are split into tiles whose integer partial sums combine_partials_kernel adds up (stream-ordered
+    // scratch; such a launch cannot be captured into a hipGraph)
+    unsigned long long *partials = nullptr;
+    if (tiles > 1 && out_summary) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(NDDM_ERR_PARAM, "nddm_simulratcliff with summaries of more than 512 trials per set cannot be captured in a hipGraph%s");
+        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&partials), (size_t)vB * 5 * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
+        A.partials = partials;
+    }
+    const size_t lds = (size_t)tile_n * sizeof(float);
+    const dim3 grid((unsigned)vB), block(WAVE);
+    if (flags & NDDM_GAUSS_FAST) hipLaunchKernelGGL(ratcliff_kernel<true>, grid, block, lds, st, A);
+    else hipLaunchKernelGGL(ratcliff_kernel<false>, grid, block, lds, st, A);
+    hipError_t e = hipGetLastError();
+    int rc = e == hipSuccess ? NDDM_OK : fail(NDDM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (rc == NDDM_OK && partials) {
+        const int threads = 256;
+        hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st, partials, 5, params, 6,
+                           3, (long long)B, tiles, n_trials, 1.52587890625e-05f, out_summary);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(NDDM_ERR_HIP, "combine kernel launch failed: %s", hipGetErrorString(e));
+    }
+    if (partials) (void)hipFreeAsync(partials, st);
+    return rc;
 }
 
 static int draw_prior_impl(int32_t model, int64_t B, uint64_t seed, uint64_t set_offset, const uint64_t *set_offset_dev,

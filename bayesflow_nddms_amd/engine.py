@@ -233,6 +233,63 @@ def simulate(model, params, n_trials, dt=0.01, max_steps=400.0, seed=None, set_o
     return res
 
 
+def simulratcliff(params, n_trials, seed=None, set_offset=None, fast=None, ext_sigma=0.0, ext_mode=0, want_trials=True, want_summary=True,
+                  want_ext=False, out_trials=None, out_summary=None, stream_state=None, device=None):
+    """The EXACT first-passage sampler the reference generates alpha_not_scaled's data with -- simulratcliff, pyhddmjagsutils.py:47-176
+    as called at alpha_not_scaled.py:95-108 -- batched on the device (include/nddm.h: nddm_simulratcliff): no step size.
+
+    params: [B, 6] (or [6]) = Nu, Alpha, Beta, Tau, Eta, Varsigma.  Returns a dict of device tensors: 'trials' f32 [B, n_trials, 2] =
+    (y, acc) with y = +-(Tau + decision time), 'summary' f32 [B, 10], 'ext' f32 [B], plus 'seed' / 'set_offset' / 'params'.
+    fast=False: bit-equal to oracle section D."""
+    torch = require_device()
+    L = _lib.lib()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if not (isinstance(params, torch.Tensor) and params.is_cuda):
+        p_np = np.ascontiguousarray(params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else params, dtype=np.float64)
+        if p_np.ndim == 1:
+            p_np = p_np[None]
+        if p_np.ndim != 2 or p_np.shape[1] != 6:
+            raise ValueError(f"params must have shape [B, 6] (Nu, Alpha, Beta, Tau, Eta, Varsigma), got {p_np.shape}")
+        validate_params_host(ALPHA_NOT_SCALED, p_np)
+        if np.any(p_np[:, 2] < 0) or np.any(p_np[:, 2] > 1) or np.any(p_np[:, 4] < 0):
+            raise ValueError("Beta must lie in [0, 1] and Eta must be >= 0")
+        p_dev = torch.as_tensor(p_np, dtype=torch.float32).contiguous().to(dev)
+    else:
+        p_dev = params[None] if params.ndim == 1 else params
+        if p_dev.ndim != 2 or p_dev.shape[1] != 6:
+            raise ValueError(f"params must have shape [B, 6], got {tuple(p_dev.shape)}")
+        p_dev = p_dev.to(dtype=torch.float32).contiguous()
+    B, n_trials = int(p_dev.shape[0]), int(n_trials)
+    if n_trials <= 0:
+        raise ValueError("n_trials must be positive")
+    if seed is None or set_offset is None:
+        s_seed, s_off = (stream_state or GLOBAL_STREAM).take(B)
+        seed = s_seed if seed is None else seed
+        set_offset = s_off if set_offset is None else set_offset
+    seed, set_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(set_offset) & 0xFFFFFFFFFFFFFFFF
+    fast = DEFAULT_FAST if fast is None else bool(fast)
+    with torch.cuda.device(dev):
+        if want_trials and out_trials is None:
+            out_trials = torch.empty((B, n_trials, 2), dtype=torch.float32, device=dev)
+        if want_summary and out_summary is None:
+            out_summary = torch.empty((B, SUMMARY_K), dtype=torch.float32, device=dev)
+        out_ext = torch.empty((B,), dtype=torch.float32, device=dev) if want_ext else None
+        for t, shape in ((out_trials, (B, n_trials, 2)), (out_summary, (B, SUMMARY_K))):
+            if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+                raise ValueError(f"output buffer must be a contiguous float32 device tensor of shape {shape}")
+        pt = lambda t: None if t is None else t.data_ptr()
+        if B > 0:
+            _lib.check(L.nddm_simulratcliff(pt(p_dev), B, n_trials, seed, set_offset, _lib.GAUSS_FAST if fast else _lib.GAUSS_EXACT,
+                                            float(ext_sigma), int(ext_mode), pt(out_trials), pt(out_summary), pt(out_ext),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+            p_dev.record_stream(torch.cuda.current_stream(dev))
+    res = {"seed": seed, "set_offset": set_offset, "params": p_dev}
+    for k, v in (("trials", out_trials), ("summary", out_summary), ("ext", out_ext)):
+        if v is not None:
+            res[k] = v
+    return res
+
+
 def decode_codes(model, codes, params, dt, out_trials=None):
     """The 2-byte wire format back to the float pairs the simulator writes: codes int16 [B, n_trials] (uint16 content), params
     f32 [B, P] (tau is read from them), -> f32 [B, n_trials, 2], bit-identical to simulate()'s 'trials' (nddm_decode_codes)."""

@@ -819,6 +819,56 @@ def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False
     return leg
 
 
+def ratcliff_leg(a, ctx, out_trials, out_summary):
+    """BASELINE configs[2] with the reference's OWN generator: pyhddmjagsutils.simulratcliff (:47-176, the exact first-passage sampler
+    alpha_not_scaled.py:95-108 calls) on the device -- nddm_simulratcliff, no step size -- at the same 1M x 300 shape, parameters from
+    the generator's ranges (alpha_not_scaled.py:66-72): rate, kernel time by events, HBM roofline (8 B written per trial), KS against
+    the reference's own draws with its bar, and the exact transform (bit-equal to oracle section D) beside the fast one."""
+    dev, torch, engine, prior_util = (ctx[k] for k in ("dev", "torch", "engine", "prior_util"))
+    B, N, L = a.sets, a.trials, max(1, a.leg_launches)
+    p_host = prior_util.alpha_ns_prior_matrix(B, 2023)
+    p_dev = torch.as_tensor(p_host).to(dev)
+
+    def timed(fast):
+        run = lambda i: engine.simulratcliff(p_dev, N, seed=2023, set_offset=i * B, fast=fast, out_trials=out_trials, out_summary=out_summary)
+        run(0)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
+        for i, (e0, e1) in enumerate(ev):
+            e0.record(); run(1 + i); e1.record()
+        torch.cuda.synchronize()
+        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    ms = timed(True)
+    mean_rt = float(out_summary[:, 3].double().mean().item())
+    alg_bytes = B * N * 8 + B * (6 * 4 + engine.SUMMARY_K * 4)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    leg = {"metric": f"simulated DDM trials/sec at n_trials={N}, exact first-passage sampler (alpha_not_scaled's own generator, simulratcliff; no dt)",
+           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": "nddm::ratcliff_kernel<fast>",
+           "workload": f"simulratcliff on the device, {B} parameter sets x {N} trials per launch, params ~ alpha_not_scaled.py:66-72 (default_rng 2023); "
+                       f"(y, acc) f32[B,N,2] + fused summaries f32[B,10]",
+           "mean_rt_s": mean_rt, "p_missing": 0.0,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "traffic": None,
+                        "note": "VALU / transcendental bound (a theta-series rejection test per sphere); no issue model is quoted for this kernel"}}
+    ms_x = timed(False)
+    leg["exact_transform"] = {"value": B * N / (ms_x * 1e-3), "unit": "trials/s", "kernel_ms": ms_x,
+                              "what": "NDDM_GAUSS_EXACT: every rounding spelled out, bit-equal to oracle/ddm_oracle.c section D "
+                                      "(tests/test_gpu_parity.py::test_simulratcliff_bit_parity)"}
+    if not a.no_ks:
+        from bayesflow_nddms_amd import diagnostics as dg
+        path = os.path.join(ROOT, "tests", "golden", "ratcliff.npz")
+        if os.path.exists(path):
+            gold, per = np.load(path), []
+            for si, p in enumerate(gold["sets"]):
+                r = engine.simulratcliff(np.tile(p, (2048, 1)), 200, seed=777, set_offset=si * 4096, fast=True, want_summary=False)
+                per.append(round(dg.ks_quantile_table(r["trials"][..., 0].cpu().numpy().ravel(), gold[f"yq_s{si}"]), 5))
+            leg["ks_vs_ref"] = {"max": max(per), "per_set": per, "n_trials_per_side": "409600 vs 2e5", "bar": 0.01, "meets_bar": bool(max(per) < 0.01),
+                                "reference": "simulratcliff (pyhddmjagsutils.py:47-176) itself, tests/golden/ratcliff.npz: the same algorithm on "
+                                             "both sides, no discretisation in between"}
+    return leg
+
+
 def training_leg(a, ctx, gather_rccl):
     """BASELINE configs[4] as a side leg: graph_trainer.GraphTrainer on the reference's loop shape (basic_ddm_dc.py:199-202: batch 32,
     N ~ U{60..300} per batch), 10 + `--leg-train-iters` iterations with the graph captures, then `--leg-train-iters` timed, at the
@@ -1094,6 +1144,8 @@ def simulate_bench(a, ctx):
                     # the headline workload with NDDM_GAUSS_EXACT: the ONLY mode that is bit-equal to the oracle (every -m gpu
                     # parity test runs it); the headline's fast transform is pinned to it by per-trial agreement and KS
                     "exact_gauss": guarded(simulator_leg, a, ctx, "basic", out_trials, out_summary, gauss="exact")}
+            # configs[2] as the reference itself generates it: simulratcliff, the exact sampler, on the device
+            legs["alpha_ns_exact_sampler"] = guarded(ratcliff_leg, a, ctx, out_trials, out_summary)
             # NDDM_STATE_F64: the reference's float64 recurrence on the device (bit-equal to the float64 oracle with the exact
             # transform), as a side number with its cost against the float32 state of the same transform
             f64 = {g: guarded(simulator_leg, a, ctx, "basic", out_trials, out_summary, gauss=g, state_f64=True, ceiling=False, ks=(g == "exact"))

@@ -216,6 +216,22 @@ int nddm_alpha_not_scaled_simulate(const float *params, int64_t B, int32_t n_tri
                                    int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata,
                                    void *stream);
 
+/* replaces simulratcliff(N, Alpha, Tau, Nu, Beta, Eta=, Varsigma=), pyhddmjagsutils.py:47-176, as alpha_not_scaled.py:95-108 calls it
+ * (rangeTau = rangeBeta = 0): the EXACT first-passage sampler of the diffusion model with per-trial drift ~ N(Nu, Eta) and diffusion
+ * coefficient Varsigma (Tuerlinckx et al. 2001: random walk on spheres with rejection) -- the generator config 3's reference actually
+ * runs.  No step size: nothing to discretise, no KS caveat.  (ABI 4)
+ *   params       device f32 [B, 6] = Nu, Alpha, Beta, Tau, Eta, Varsigma (Nu is clipped to +-5 as :102-103 does)
+ *   flags        NDDM_GAUSS_EXACT (every rounding spelled out: equal bit for bit to oracle/ddm_oracle.c section D) or NDDM_GAUSS_FAST
+ *                (v_log_f32 / v_exp_f32); nothing else
+ *   out_trials   [B, n_trials, 2] = (y, acc): y = +-(Tau + decision time) signed by the response, acc = (sign + 1) / 2  (:98-102)
+ *   out_summary  [B, NDDM_SUMMARY_K] from integer sums of the decision time in 2^-16 s (n_missing is 0: the sampler has no timeout)
+ *   out_extdata  [B]: (ext_mode == 0 ? Alpha[b] : 1) + ext_sigma * N(0,1)  (alpha_not_scaled.py:103-106), as nddm_alpha_not_scaled_simulate
+ * Randomness: per-trial drift = auxiliary normal 0 of (set, trial) -- the draw the Euler-Maruyama form uses -- and stream 3 of the
+ * trial for the sampler's uniforms; a pure function of (seed, set_offset + row, trial).  Sets of more than 512 trials are tiled
+ * (same bits); with summaries such a launch cannot be captured into a hipGraph. */
+int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_t seed, uint64_t set_offset, uint32_t flags,
+                       float ext_sigma, int32_t ext_mode, float *out_trials, float *out_summary, float *out_extdata, void *stream);
+
 /* replaces the per-trial loop over diffusion_trial(drift, bound_trial, beta, ter, dc),
  * imputation_from_stahl_not_scaled.py:120-148, :207-213.  bounds: device f32 [B, n_trials].
  * out_trials[b, i, :] = (choicert, bound_trial).  A negative (or NaN) boundary is the reference's ValueError

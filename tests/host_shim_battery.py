@@ -62,12 +62,17 @@ def battery(path):
         note(L.nddm_draw_prior(model, B, 1, 0, 1.0, d, None), err())
         note(L.nddm_draw_prior_indirect(model, B, 1, 0, d, 1.0, d, None), err())
     note(L.nddm_draw_prior(0, 4, 1, 0, 1.0, None, None), err())
+    for B, N, flags in ((-1, 10, 0), (4, 0, 0), (4, 1 << 30, 0), (4, 10, 2), (4, 10, 8), (1 << 30, 100000, 1), (0, 10, 1)):
+        note(L.nddm_simulratcliff(d, B, N, 1, 0, flags, 0.1, 0, d, d, d, None), err())
+    note(L.nddm_simulratcliff(None, 4, 10, 1, 0, 0, 0.1, 0, d, d, d, None), err(), L.nddm_simulratcliff(d, 4, 10, 1, 0, 0, 0.1, 0, None, None, None, None), err(),
+         L.nddm_simulratcliff(d, 4, 10, 1, 1 << 60, 0, 0.1, 0, d, None, None, None), err())
     note(L.nddm_debug_normals(d, -1, 1, 2, 0, d, None), L.nddm_debug_normals(d, 0, 1, 2, 0, d, None), L.nddm_debug_normals(None, 3, 1, 2, 1, d, None), err())
     # ---- valid arguments: the call reaches the HIP runtime, which has no device here -> an error code and its text, never a crash
     if no_gpu:
         rcs = [L.nddm_basic_ddm_dc_simulate(d, 4, 10, .01, 400, 0, 0, 1, d, d, None), L.nddm_single_trial_simulate(d, 4, 10, .001, 4000, 0, 0, 8, d, d, None),
                L.nddm_alpha_not_scaled_simulate(d, 4, 10, .01, 400, 0, 0, 3, .1, 0, d, d, d, None), L.nddm_decode_codes(0, d, d, 4, 10, .01, d, None),
                L.nddm_draw_prior(0, 4, 1, 0, 1.0, d, None), L.nddm_debug_normals(d, 3, 1, 2, 1, d, None), L.nddm_release_graph_memory(),
+               L.nddm_simulratcliff(d, 4, 600, 1, 0, 1, 0.1, 0, d, d, d, None),
                L.nddm_set_device(0)]
         assert all(rc in (_lib.NDDM_ERR_HIP, _lib.NDDM_ERR_NO_DEVICE) for rc in rcs), rcs
         assert len(err()) > 0

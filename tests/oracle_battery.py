@@ -44,6 +44,9 @@ def battery():
     for m, par in ((oracle.M_BASIC, basic), (oracle.M_SINGLE, single)):               # ... with the outputs NDDM_STATE_F64 writes
         f = oracle.philox_simulate_f64(m, par, 33, dt=0.01, max_steps=403.0, seed=3, want_outputs=True)
         take(f["k"], f["choice"], f["trials"], f["summary"])
+    for n in (1, 64, 257, 700):                              # section D: simulratcliff on the device stream
+        r = oracle.philox_ratcliff(alpha, n, seed=11, set_offset=(1 << 35) + 5, ext_sigma=0.2, ext_mode=n & 1, want_ext=True, threads=3)
+        take(r["trials"], r["summary"], r["ext"])
     take(oracle.philox_normals4(1, 2, 3, 4, 5, 6), oracle.philox_block(1, 2, 3, 4, 5, 6))
     oracle.mt_seed(2023)
     take(np.array([oracle.mt_gauss(), oracle.mt_double()]), oracle.mt_basic([1.5, 1.2, .5, .35, 1.0], 40),

@@ -70,6 +70,10 @@ def _check_legs(d):
     f64 = legs["state_f64"]
     assert f64["state_f64"] is True and f64["gauss"] == "exact" and f64["ks_vs_ref"]["max"] < 0.01
     assert 0.3 < f64["rate_vs_f32_state_same_transform"] < 1.02 and 0.3 < f64["fast_transform"]["rate_vs_f32_state_same_transform"] < 1.02
+    # configs[2] with the reference's own generator (simulratcliff) on the device: no step size, KS against the reference's draws
+    ex = legs["alpha_ns_exact_sampler"]
+    assert ex["unit"] == "trials/s" and ex["value"] > 1e8 and ex["ks_vs_ref"]["max"] < ex["ks_vs_ref"]["bar"] == 0.01
+    assert 0 < ex["exact_transform"]["value"] <= 1.05 * ex["value"] and 0.2 < ex["mean_rt_s"] < 2.0
     so = legs["single"]["summary_only"]
     assert so["value"] >= 0.95 * legs["single"]["value"] and so["kernel_ms"] > 0          # no 8 B per trial: never slower
     tr = legs["train"]

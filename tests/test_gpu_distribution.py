@@ -230,6 +230,45 @@ def test_alpha_not_scaled_bridge_vs_exact_sampler():
     print("bridge KS vs simulratcliff:", worst)
 
 
+def test_simulratcliff_device_vs_the_references_own_draws():
+    """Config 3 with the reference's OWN generator on the device (nddm_simulratcliff: the exact first-passage sampler, no dt, no
+    bridge): KS of the signed RT against 2e5 draws of pyhddmjagsutils.simulratcliff per set (tests/golden/ratcliff.npz) < 0.01 on
+    every set, fast and exact transform, P(upper) within 0.01, and the fused mean RT equal to the mean of the written RTs."""
+    from bayesflow_nddms_amd import diagnostics as dg, engine
+    gold = _gold("ratcliff.npz")
+    worst = 0.0
+    for si, p in enumerate(gold["sets"]):
+        for fast in (True, False):
+            r = engine.simulratcliff(np.tile(p, (2048, 1)), 200, seed=45, set_offset=si * 10000, fast=fast)
+            t = r["trials"].cpu().numpy()
+            y = t[..., 0].ravel()
+            ks = dg.ks_quantile_table(y, gold[f"yq_s{si}"])
+            worst = max(worst, ks)
+            assert ks < 0.01, (si, fast, ks)
+            assert abs((y > 0).mean() - gold[f"pupper_s{si}"][0]) < 0.01
+            s = r["summary"].cpu().numpy()
+            assert np.all(s[:, 2] == 0) and np.abs(s[:, 3] - np.abs(t[..., 0]).mean(axis=1)).max() < 2e-5
+    print("simulratcliff on the device, KS vs the reference's draws:", worst)
+
+
+def test_generate_data_with_the_exact_sampler():
+    """alpha_not_scaled.generate_data(method="exact"): the reference's data-generation block (alpha_not_scaled.py:52-128) with its own
+    generator on the device -- same keys and participant draws as the Euler-Maruyama form, RT / accuracy per participant in line with
+    it (the two are the same process), and pyhddmjagsutils.simulratcliff's call shape as a function."""
+    from bayesflow_nddms_amd import alpha_not_scaled as ans
+    ex = ans.generate_data(test_num=2, nparts=100, ntrials=400, method="exact", sim_seed=3)
+    em = ans.generate_data(test_num=2, nparts=100, ntrials=400, method="em", sim_seed=3)
+    assert set(ex) == set(em) and ex["N"] == 40000 and np.array_equal(ex["alpha"], em["alpha"])
+    assert np.array_equal(ex["extdata"], em["extdata"])                        # the per-participant datum is the same draw in both
+    acc_ex, acc_em = ex["acc"].reshape(100, 400).mean(1), em["acc"].reshape(100, 400).mean(1)
+    rt_ex, rt_em = ex["rt"].reshape(100, 400).mean(1), em["rt"].reshape(100, 400).mean(1)
+    assert np.abs(acc_ex - acc_em).max() < 0.12 and np.corrcoef(rt_ex, rt_em)[0, 1] > 0.98 and np.abs(rt_ex - rt_em).mean() < 0.03
+    y = ans.simulratcliff(N=500, Alpha=1.2, Tau=.4, Nu=3.5, Beta=.5, Eta=1.0, Varsigma=1.2, seed=1, set_offset=0)
+    assert y.shape == (500,) and y.dtype == np.float64 and np.all(np.abs(y) > 0.4) and 0.85 < (y > 0).mean() < 0.99
+    with pytest.raises(ValueError):
+        ans.simulratcliff(N=5, rangeTau=0.1)
+
+
 def test_device_prior_marginals():
     """On-device draw_prior vs 1e5 draws of the reference's draw_prior: KS per marginal < 0.01."""
     from bayesflow_nddms_amd import diagnostics as dg

@@ -164,6 +164,39 @@ def test_state_f64_argument_checks():
         engine.simulate(0, prior_util.basic_prior(2, 1), 10, state_f64=True, want_codes=True)
 
 
+@pytest.mark.parametrize("N", [1, 63, 300, 513, 1200])
+def test_simulratcliff_bit_parity(N):
+    """nddm_simulratcliff -- the reference's own generator for config 3, pyhddmjagsutils.simulratcliff (:47-176), on the device: the exact
+    first-passage sampler, no step size -- in exact mode equals oracle section D bit for bit: signed RTs and accuracies, the fused
+    summaries (integer sums of the decision time in 2^-16 s), the per-set external datum; ragged and tiled trial counts; parameter rows
+    from the generator's ranges (alpha_not_scaled.py:66-72) plus the corners (a start on a boundary, Nu beyond +-5, Eta = 0)."""
+    import oracle
+    from bayesflow_nddms_amd import engine
+    p = prior_util.alpha_ns_prior(93, 77)
+    p = np.concatenate([p, np.array([[8.0, 1.0, 0.0, 0.3, 0.0, 1.0], [-9.0, 1.0, 1.0, 0.3, 0.0, 1.0], [0.0, 0.8, 0.5, 0.15, 0.0, 1.4]], np.float32)])
+    so = (1 << 36) + 11
+    g = engine.simulratcliff(p, N, seed=2026, set_offset=so, fast=False, ext_sigma=0.1, ext_mode=0, want_ext=True)
+    o = oracle.philox_ratcliff(p, N, seed=2026, set_offset=so, ext_sigma=0.1, ext_mode=0, want_ext=True, threads=8)
+    for k in ("trials", "summary", "ext"):
+        a = g[k].cpu().numpy()
+        assert np.array_equal(np.nan_to_num(a).view(np.uint32), np.nan_to_num(o[k]).view(np.uint32)), k
+    # results do not depend on how a set is tiled or on its neighbours: the first trials of the 1200-trial launch are these
+    if N == 300:
+        big = engine.simulratcliff(p, 1200, seed=2026, set_offset=so, fast=False, want_summary=False)["trials"].cpu().numpy()
+        assert np.array_equal(big[:, :300], g["trials"].cpu().numpy())
+        sub = engine.simulratcliff(p[10:20], 300, seed=2026, set_offset=so + 10, fast=False, want_summary=False)["trials"].cpu().numpy()
+        assert np.array_equal(sub, g["trials"].cpu().numpy()[10:20])
+        # the fast transform (v_log_f32 / v_exp_f32): the same stream, nearly every trial ends on the same boundary at nearly the same time
+        f = engine.simulratcliff(p, N, seed=2026, set_offset=so, fast=True, want_summary=False)["trials"].cpu().numpy()
+        gt = g["trials"].cpu().numpy()
+        same = np.sign(f[..., 0]) == np.sign(gt[..., 0])
+        assert same.mean() > 0.995 and np.median(np.abs(f[..., 0] - gt[..., 0])[same]) < 1e-5
+        # the per-trial drift is the draw the Euler-Maruyama form of the model uses: with Eta = 0 and a strong drift both agree on the response
+    with pytest.raises(ValueError, match="GAUSS"):
+        from bayesflow_nddms_amd import _lib
+        _lib.check(_lib.lib().nddm_simulratcliff(g["params"].data_ptr(), 4, 10, 1, 0, 2, 0.0, 0, g["trials"].data_ptr(), None, None, None))
+
+
 def test_packed_layout_argument_checks():
     from bayesflow_nddms_amd import engine
     with pytest.raises(ValueError):
