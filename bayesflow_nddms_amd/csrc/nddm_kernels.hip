@@ -283,9 +283,10 @@ static char *graph_alloc(int dev, size_t bytes, hipError_t *err)
     return static_cast<char *>(p);
 }
 
-// zeroes the 64 counting-sort counters / the queue words of a captured launch (a kernel, not hipMemsetAsync: memset NODES
-// of a captured launch were observed not to take effect on graph replay -- HIP runtime 7.0.51831, the copy PyTorch 2.10.0+rocm7.0
-// loads; the library itself is built by hipcc 7.2.26015.  Probe: tools/probe_graph_memset_node.py, profiles/r5_probe_graph_memset_node.txt)
+// zeroes the 64 counting-sort counters / the queue words of a captured launch (a kernel, not hipMemsetAsync: a memset NODE of <= 4 KB
+// in a captured launch zeroes on the first replay only -- from the second replay on the buffer holds constant garbage (min -2^31, max
+// 434269841: the replayed node writes a wrong value), 1 MB nodes are fine -- HIP runtime 7.0.51831, the copy PyTorch 2.10.0+rocm7.0
+// loads; the library itself is built by hipcc 7.2.26015.  Probe: tools/probe_graph_memset_node.py, profiles/r6_probe_graph_memset_node.txt)
 __global__ void zero_words_kernel(unsigned int *ws) { ws[threadIdx.x] = 0u; }
 
 // resident waves of a kernel instantiation on the current device (persistent grid size)

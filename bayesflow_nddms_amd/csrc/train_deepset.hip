@@ -190,8 +190,9 @@ struct RowTile {
         : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile_base), 0, (n_rows > 0 ? n_rows : 0) * HS * 4, 0x00020000)) {}
     __device__ __forceinline__ void put(int row, int col, float v) const
     { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (row * HS + col) * 4, 0, 0); }
-    // (dword accesses only: hipcc 7.2.26015 compiles __builtin_amdgcn_raw_buffer_load_b128 to ONE buffer_load_dword -- y, z, w read as
-    //  zero.  Probe: tools/probe_buffer_load_b128.hip, its MI355X output profiles/r5_probe_buffer_load_b128.txt; the ISA side of the
+    // (dword accesses only: hipcc 7.2.26015 compiles __builtin_amdgcn_raw_buffer_load_b128 to ONE buffer_load_dword -- x is loaded, y, z,
+    //  w are not their dwords of the source (3 of every 4 floats wrong on the MI355X; the probe prints what they held).  Probe:
+    //  tools/probe_buffer_load_b128.hip, its MI355X output profiles/r6_probe_buffer_load_b128.txt; the ISA side of the
     //  claim is asserted without a GPU by tests/test_kernel_resources.py::test_toolchain_probes_compile)
     __device__ __forceinline__ float get(int row, int col) const
     { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * HS + col) * 4, 0, 0)); }

@@ -1035,6 +1035,8 @@ def simulate_bench(a, ctx):
     elif tr:
         res["roofline"]["traffic_refused"] = tr["refused"]      # counters of another build of the library: not quoted
     res["host_prior_seconds_rank0"] = t_prior
+    res["library"] = {"source_hash": _lib.lib().nddm_source_hash().decode(), "build": _lib.lib().nddm_build_info().decode(),
+                      "abi": int(_lib.lib().nddm_abi_version())}      # the library that RAN (profiles/*_pmc.json are keyed by this hash)
     res["pass_allocated_bytes"] = pass_allocated          # what simulate_pass() allocated on this rank (== pass_buffers(): --plan's figure)
     res["toolchain"] = toolchain(torch)
     if ident is not None:

@@ -1,13 +1,14 @@
 // Probe behind the workaround at csrc/train_deepset.hip (struct RowTile: "dword accesses only"): what does
 // __builtin_amdgcn_raw_buffer_load_b128 compile to, and what does it return?
 //
-// Finding (hipcc 7.2.26015, clang 22.0.0git roc-7.2.0, --offload-arch=gfx950): the builtin is compiled to ONE buffer_load_dword -- the
-// x component is loaded, y / z / w read as zero -- instead of a buffer_load_dwordx4.  Checkable WITHOUT a GPU from the ISA:
+// Finding (hipcc 7.2.26015, clang 22.0.0git roc-7.2.0, --offload-arch=gfx950): the builtin is compiled to ONE buffer_load_dword instead of a
+// buffer_load_dwordx4: only the x component is loaded; y / z / w are NOT their dwords of the source (what they hold instead is whatever
+// the three registers held -- the probe prints the first values it got beside the source, so the failure mode is on record).  Checkable WITHOUT a GPU from the ISA:
 //     hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only -o - tools/probe_buffer_load_b128.hip | grep buffer_load
 // (tests/test_kernel_resources.py::test_toolchain_probes_compile asserts exactly that, so a toolchain that fixes it makes the test --
 // and with it the workaround -- stand out), and at run time on the MI355X:
 //     hipcc -O3 --offload-arch=gfx950 -o /tmp/probe_b128 tools/probe_buffer_load_b128.hip && /tmp/probe_b128
-// prints, per tile height, how many of the 4096 floats copied through a b128 load differ from the source (profiles/r5_probe_buffer_load_b128.txt).
+// prints, per tile height, how many of the 4096 floats copied through a b128 load differ from the source (profiles/r6_probe_buffer_load_b128.txt).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
@@ -60,7 +61,12 @@ int main()
                 if (g[i] != want) { if (first < 0) first = i; ++bad; }
             }
             printf("%s, %d valid rows of 64: %d of 4096 floats differ from the source", form == 0 ? "raw_buffer_load_b128" : "raw_buffer_load_b32 ", rows, bad);
-            if (first >= 0) printf(" (first at %d: got %g, source %g)", first, g[first], first / 64 < rows ? h[first] : 0.0f);
+            if (first >= 0) {
+                printf(" (first at %d: got %g, source %g)\n    first 8 values got   :", first, g[first], first / 64 < rows ? h[first] : 0.0f);
+                for (int i = 0; i < 8; ++i) printf(" %g", g[i]);
+                printf("\n    first 8 of the source:");
+                for (int i = 0; i < 8; ++i) printf(" %g", h[i]);
+            }
             printf("\n");
             if (form == 0 && bad > worst) worst = bad;
         }

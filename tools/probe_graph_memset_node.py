@@ -5,8 +5,10 @@ captured stream take effect on every replay of the graph?
 The simulator's launch zeroes 64 counting-sort counters / its queue words before the kernels that use them.  With hipMemsetAsync in a
 launch that torch.cuda.graph captures, replays were observed reading stale counters (round 3; results of replay k depended on replay
 k - 1).  This probe captures   hipMemsetAsync(buf, 0, n) ; buf += 1   on a stream, replays the graph R times and reports what the
-buffer holds after each replay: 1 every time if the memset node runs per replay, k after replay k if it does not.  Sizes: the 256
-bytes of the counters, 4 KB, 1 MB.  Run on the MI355X:  python tools/probe_graph_memset_node.py  (output: profiles/r5_probe_graph_memset_node.txt)."""
+buffer holds after each replay: 1 everywhere every time if the memset node zeroes per replay.  (A node that simply did nothing would
+leave k after replay k; what the MI355X runs of rounds 5 and 6 show for nodes of <= 4 KB is neither: from the second replay on the
+buffer holds CONSTANT GARBAGE -- min -2147483648, max 434269841 -- i.e. the replayed node writes a wrong value; the probe prints
+the first words.)  Sizes: the 256 bytes of the counters, 4 KB, 1 MB.  Run on the MI355X:  python tools/probe_graph_memset_node.py  (output: profiles/r6_probe_graph_memset_node.txt)."""
 import ctypes
 import sys
 
@@ -41,15 +43,17 @@ def main():
                 with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
                     rc = hip.hipMemsetAsync(buf.data_ptr(), 0, nbytes, torch.cuda.current_stream().cuda_stream)
                     buf.add_(1)
-            after = []
+            after, words = [], None
             for _ in range(4):
                 g.replay()
                 torch.cuda.synchronize()
                 after.append((int(buf.min()), int(buf.max())))
+                if after[-1] != (1, 1) and words is None:
+                    words = buf[:6].tolist()
             ok = all(a == (1, 1) for a in after)
             stale += not ok
             print(f"memset node of {nbytes:8d} bytes, capture mode {mode:12s}: hipMemsetAsync rc {rc}; (min, max) of the buffer after replays 1..4: {after}"
-                  f"  -> {'the memset ran on every replay' if ok else 'STALE: the memset node did not take effect on replay'}")
+                  f"  -> {'the memset zeroed on every replay' if ok else f'WRONG: the replayed memset node left other values than zero behind; first words after the first bad replay: {words}'}")
             del g
     print("=> " + ("memset nodes of a captured stream are NOT reliable on this runtime: the product zeroes with a kernel (csrc/nddm_kernels.hip: zero_words_kernel)"
                    if stale else "memset nodes took effect on every replay in this probe: the observation behind zero_words_kernel did not reproduce here "

@@ -88,6 +88,9 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
     f.write("\n## bench line of the traced run\n\n```json\n" + json.dumps(bench) + "\n```\n")
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w") as f:
     json.dump({"command": command, "model": model, "kernel": sim["Name"],
+               # what the counters belong to: bench.py quotes this file only for the same step size / transform AND the same library
+               "dt": bench["config"]["dt"], "max_steps": bench["config"]["max_steps"], "gauss": bench["config"]["gauss"],
+               "source_hash": bench.get("library", {}).get("source_hash"),
                "kernel_avg_ms_rocprof_timed_steps": sum(timed) / len(timed) if timed else None,
                "kernel_avg_ms_rocprof_lockstep": sum(lock) / len(lock) if lock else None,
                "kernel_avg_ms_bench_events": km, "lockstep_ms_bench_events": ceil_ms,
