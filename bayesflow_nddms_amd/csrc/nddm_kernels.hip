@@ -988,8 +988,16 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
         if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
         A.partials = partials;
     }
-    const size_t lds = (size_t)tile_n * sizeof(float);
-    const dim3 grid((unsigned)vB), block(WAVE);
+    // a workgroup works through a GROUP of consecutive tiles at a time (~2048 trials: the drain at the end of a group costs ~67
+    // trials' worth of time whatever its size), at most 64 (one lane states one tile's constants) and at most 16 KB of LDS
+    int group = 2048 / tile_n;
+    group = group < 1 ? 1 : (group > 64 ? 64 : group);
+    if ((long long)group > vB) group = (int)vB;
+    A.group = group;
+    A.tile_magic = (uint32_t)((0x100000000ull + (unsigned long long)tile_n - 1ull) / (unsigned long long)tile_n);
+    const size_t lds = ((size_t)WAVE * 8 + (size_t)group * (size_t)tile_n + (size_t)group * RT_WORDS) * sizeof(float);   // uniform rings | table | staged results
+    const long long n_groups = (vB + group - 1) / group;
+    const dim3 grid((unsigned)n_groups), block(WAVE);
     if (flags & NDDM_GAUSS_FAST) hipLaunchKernelGGL(ratcliff_kernel<true>, grid, block, lds, st, A);
     else hipLaunchKernelGGL(ratcliff_kernel<false>, grid, block, lds, st, A);
     hipError_t e = hipGetLastError();

@@ -14,10 +14,13 @@
 //   exponent); the series stops when a term no longer changes the float32 sum (<= 64 terms); a < 2^-6 is rejected without it (the bound
 //   is below 2^-33, the smallest uniform); the sphere's time is -ln(s1) / lambda.  Caps that make every loop finite: 4096 attempts
 //   (then accepted), 4096 spheres (then ended on the nearer boundary).  Laid out for 64-lane waves:
-//   * one single-wave workgroup per tile (= one parameter set of <= 512 trials), PERSISTENT LANES inside it: the trial loop, the
-//     sphere loop and the rejection loop of the reference are flattened into ONE loop whose trip is one rejection attempt, and a lane
-//     whose trial ended takes the set's next trial at the top of the next trip (ballot + mbcnt), so the three data-dependent loop
-//     counts (1-10 spheres, 1-5 attempts, 2-18 series terms) do not multiply into idle lanes;
+//   * a single-wave workgroup works on a GROUP of consecutive tiles (a tile = one parameter set of <= 512 trials; ~2048 trials per
+//     group) with PERSISTENT LANES: the trial loop, the sphere loop and the rejection loop of the reference are flattened into ONE
+//     loop whose trip is one rejection attempt, and a lane whose trial ended takes the group's next trial at the top of the next trip
+//     (ballot + mbcnt; its set's constants come from a small LDS table), so the three data-dependent loop counts (1-10 spheres, 1-5
+//     attempts, 2-18 series terms) do not multiply into idle lanes, and the drain at the end -- lanes idle while the last trials
+//     finish -- is paid once per ~2048 trials instead of once per set (measured: 67 trials' worth; 20 % of the time at 300 trials
+//     per set, 67 % at the 100 trials per participant of alpha_not_scaled.py:55);
 //   * randomness: counter-based like every other stream of the library -- the per-trial drift is auxiliary normal 0 of the trial
 //     (stream 1: the very draw the Euler-Maruyama form of the model uses), the uniforms are stream 3 of the trial, consumed in order;
 //   * results are staged in LDS as one float per trial (the decision time with the response as its sign bit) and flushed as whole
@@ -44,6 +47,8 @@ struct RatArgs {
     unsigned long long set_offset;
     float ext_sigma;
     int ext_mode;
+    int group;                      // tiles one workgroup works on at a time (their trials are handed out as ONE sequence)
+    uint32_t tile_magic;            // ceil(2^32 / n_trials): slot / n_trials by a multiply-high (slots < 2^16)
 };
 
 template <bool FAST> __device__ __forceinline__ float rat_neg_log(float u)        // -ln u, u in (0, 1]
@@ -57,57 +62,85 @@ template <bool FAST> __device__ __forceinline__ float rat_exp_neg(float y)      
     else return exact_expf_neg(-y);
 }
 
-// uniform j of (set, trial): word j & 3 of block j >> 2 of stream 3
+// uniform j of (set, trial): word j & 3 of block j >> 2 of stream 3.  A lane keeps a WINDOW of two blocks in an 8-word LDS ring of its
+// own (uniform j sits at ring word j & 7): refill() -- the one place a Philox block of this stream is generated -- runs at the top of
+// a trip of the kernel's loop and makes sure blocks j >> 2 and (j >> 2) + 1 are present, i.e. at least the four uniforms a trip can
+// consume (one for a sphere's direction at hand-out, two for the attempt, one for the next sphere's direction).  (Generating the block
+// inside next() put five inlined Philox bodies into the loop: 106 SGPRs, ten of them spilled to scratch.)
 struct UnifStream {
-    uint32_t set_lo, trial, c2, blk, q;
-    u32x4 x;
+    uint32_t set_lo, trial, c2, q, gen;                  // q: uniforms consumed, gen: blocks generated
+    uint32_t *ring;                                      // this lane's 8 words in LDS
     __device__ __forceinline__ void init(uint32_t set_lo_, uint32_t set_hi28, uint32_t trial_)
     {
-        set_lo = set_lo_; trial = trial_; c2 = set_hi28 | 0x30000000u; blk = 0xffffffffu; q = 0u;
-        x = {0u, 0u, 0u, 0u};
+        set_lo = set_lo_; trial = trial_; c2 = set_hi28 | 0x30000000u; q = 0u; gen = 0u;
     }
-    __device__ __forceinline__ float next(uint32_t k0, uint32_t k1)
+    __device__ __forceinline__ void refill(uint32_t k0, uint32_t k1)
     {
-        const uint32_t b = q >> 2;
-        if (b != blk) { x = philox4x32_10(set_lo, trial, c2, b, k0, k1); blk = b; }
-        const uint32_t j = q & 3u;
-        const uint32_t w = j == 0u ? x.x : (j == 1u ? x.y : (j == 2u ? x.z : x.w));
+        while (gen < (q >> 2) + 2u) {                    // (the slot of block gen held block gen - 2 < q >> 2: consumed)
+            const u32x4 x = philox4x32_10(set_lo, trial, c2, gen, k0, k1);
+            *reinterpret_cast<uint4 *>(ring + (gen & 1u) * 4u) = make_uint4(x.x, x.y, x.z, x.w);
+            gen++;
+        }
+    }
+    __device__ __forceinline__ float next()
+    {
+        const uint32_t w = ring[q & 7u];
         q++;
         return uniform01(w);
     }
 };
 
+// per-tile constants in LDS (RT_WORDS dwords per tile of the group), written by lane l for tile l when a group opens
+enum { RT_NU = 0, RT_ETA, RT_INVD, RT_CLAM2, RT_DU0, RT_DL0, RT_TAU, RT_ALPHA, RT_SETLO, RT_SETHI, RT_NHERE, RT_T0, RT_WORDS };
+
 template <bool FAST>
 __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
 {
     extern __shared__ uint32_t lds_raw[];
-    float *const staged = reinterpret_cast<float *>(lds_raw);          // [n_trials]: copysign(decision time, response)
+    const int G = A.group;                                             // tiles per workgroup pass (<= 64)
+    uint32_t *const tbl = lds_raw + WAVE * 8;                          // [G][RT_WORDS]  (behind the lanes' uniform rings: 16-byte aligned)
+    float *const staged = reinterpret_cast<float *>(tbl + G * RT_WORDS);          // [G][n_trials]: copysign(decision time, response)
     const int lane = threadIdx.x;
-    for (long long vset = blockIdx.x; vset < A.n_vsets; vset += gridDim.x) {
+    const long long n_groups = (A.n_vsets + G - 1) / G;
+    for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const long long v0 = grp * G;
+        const int g_here = (int)((A.n_vsets - v0) < G ? (A.n_vsets - v0) : G);
         const int TPS = A.tiles_per_set;
-        const long long set = TPS == 1 ? vset : vset / TPS;
-        const int t0 = TPS == 1 ? 0 : (int)(vset - set * TPS) * A.n_trials;
-        const int n_here = (A.n_total - t0) < A.n_trials ? (A.n_total - t0) : A.n_trials;
-        // ---- per-set constants
-        const float *p = A.params + set * 6;
-        float Nu = p[0];
-        if (Nu < -5.0f || Nu > 5.0f) Nu = Nu > 0.0f ? 5.0f : -5.0f;                    // pyhddmjagsutils.py:102-103
-        const float Alpha = p[1], Beta = p[2], Tau = p[3], Eta = p[4], Vs = p[5];
-        const float D = (Vs * Vs) * 0.5f, inv_D = 1.0f / D;                             // :117
-        const float c_lam2 = (0.25f * D) * 9.86960440108935862f;                        // 0.25 D pi^2
-        const float zz = Beta * Alpha, du0 = Alpha - zz, dl0 = zz;
-        const unsigned long long gset = A.set_offset + (unsigned long long)set;
-        const uint32_t set_lo = (uint32_t)gset, set_hi = (uint32_t)(gset >> 32) & 0x0fffffffu;
+        __syncthreads();                                               // (the previous group's flush has read the table)
+        // ---- per-tile constants: lane l states tile l's
+        if (lane < g_here) {
+            const long long vset = v0 + lane;
+            const long long set = TPS == 1 ? vset : vset / TPS;
+            const int t0 = TPS == 1 ? 0 : (int)(vset - set * TPS) * A.n_trials;
+            const int n_here = (A.n_total - t0) < A.n_trials ? (A.n_total - t0) : A.n_trials;
+            const float *p = A.params + set * 6;
+            float Nu = p[0];
+            if (Nu < -5.0f || Nu > 5.0f) Nu = Nu > 0.0f ? 5.0f : -5.0f;                // pyhddmjagsutils.py:102-103
+            const float Alpha = p[1], Beta = p[2], Tau = p[3], Eta = p[4], Vs = p[5];
+            const float D = (Vs * Vs) * 0.5f, inv_D = 1.0f / D;                         // :117
+            const float c_lam2 = (0.25f * D) * 9.86960440108935862f;                    // 0.25 D pi^2
+            const float zz = Beta * Alpha, du0 = Alpha - zz, dl0 = zz;
+            const unsigned long long gset = A.set_offset + (unsigned long long)set;
+            uint32_t *t = tbl + lane * RT_WORDS;
+            t[RT_NU] = __float_as_uint(Nu); t[RT_ETA] = __float_as_uint(Eta); t[RT_INVD] = __float_as_uint(inv_D);
+            t[RT_CLAM2] = __float_as_uint(c_lam2); t[RT_DU0] = __float_as_uint(du0); t[RT_DL0] = __float_as_uint(dl0);
+            t[RT_TAU] = __float_as_uint(Tau); t[RT_ALPHA] = __float_as_uint(Alpha);
+            t[RT_SETLO] = (uint32_t)gset; t[RT_SETHI] = (uint32_t)(gset >> 32) & 0x0fffffffu;
+            t[RT_NHERE] = (uint32_t)n_here; t[RT_T0] = (uint32_t)t0;
+        }
+        __syncthreads();
 
         // ---- per-lane trial state
-        bool has = false;
-        int slot = 0;                                     // the trial's index within the tile
-        float du = 0.0f, dl = 0.0f, total = 0.0f, lam1 = 0.0f, g1 = 0.0f, x1 = 0.0f, lam = 1.0f, F = 0.0f;
+        bool has = false, fresh = false;                 // fresh: handed out in this trip, its first sphere not set up yet
+        int slot = 0;                                     // index of the trial's staged result: tile * n_trials + trial within the tile
+        float du = 0.0f, dl = 0.0f, total = 0.0f, lam1 = 0.0f, g1 = 0.0f, x1 = 0.0f, lam = 1.0f, F = 0.0f, c_lam2 = 0.0f;
         bool up = false;
         int sphere = 0, att = 0;
         UnifStream us;
         us.init(0u, 0u, 0u);
-        int next = 0;                                     // wave-uniform: the tile's next unassigned trial
+        us.ring = lds_raw + lane * 8;
+        int next = 0;                                     // wave-uniform: the group's next unassigned slot
+        const int n_slots = g_here * A.n_trials;
 
         // the sphere that starts at the current position: its constants and its direction (one uniform) -- or the end of the
         // trial, when the position lies on a boundary (Beta = 0 or 1) or the safety cap is reached; returns "the trial goes on"
@@ -118,45 +151,55 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 return false;
             }
             lam = lam1 + c_lam2 / (radius * radius);                                     // :138
-            const float G = radius * g1;
-            F = 1.0f / __builtin_fmaf(G, G, 1.0f);                                       // :140-141, F0^2 / (1 + F0^2) with F0 = 1 / G
+            const float Gr = radius * g1;
+            F = 1.0f / __builtin_fmaf(Gr, Gr, 1.0f);                                     // :140-141, F0^2 / (1 + F0^2) with F0 = 1 / G
             const float x = radius * x1;
             const float e = rat_exp_neg<FAST>(__builtin_fabsf(x));
             const float p_up = (x >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);         // :143-144
-            up = us.next(A.k0, A.k1) < p_up;                                             // :145
+            up = us.next() < p_up;                                                       // :145
             att = 0;
             return true;
         };
 
         while (true) {
-            // ---- hand out the tile's next trials to the lanes that hold none
+            // ---- hand out the group's next trials to the lanes that hold none (the slots of a tile are its trials; a tile
+            // shorter than n_trials -- the last tile of a split set -- leaves holes that are skipped)
             const unsigned long long want = __builtin_amdgcn_ballot_w64(!has);
-            if (next < n_here && want) {
-                const int tr = next + (int)lane_rank(want);
-                const bool take = !has && tr < n_here;
-                if (take) {
-                    slot = tr;
-                    const uint32_t trial = (uint32_t)(t0 + tr);
-                    float z[4];
-                    normals4<FAST>(set_lo, trial, set_hi | 0x10000000u, 0u, A.k0, A.k1, z);     // auxiliary normal 0 of the trial
-                    const float mu = __builtin_fmaf(Eta, z[0], Nu);                              // :124-125
-                    lam1 = (0.25f * (mu * mu)) * inv_D;
-                    g1 = mu * (inv_D * 0.318309886183790672f);
-                    x1 = mu * inv_D;
-                    du = du0; dl = dl0; total = 0.0f; sphere = 0;
-                    us.init(set_lo, set_hi, trial);
-                    has = setup_sphere();
+            if (next < n_slots && want) {
+                const int idx = next + (int)lane_rank(want);
+                if (!has && idx < n_slots) {
+                    // idx / n_trials (tile_magic = ceil(2^32 / n_trials), exact for idx * n_trials < 2^32; one trial per tile: 2^32 does not fit a word)
+                    const int tile = A.n_trials == 1 ? idx : (int)(((unsigned long long)(uint32_t)idx * A.tile_magic) >> 32);
+                    const int tr = idx - tile * A.n_trials;
+                    const uint32_t *t = tbl + tile * RT_WORDS;
+                    if (tr < (int)t[RT_NHERE]) {
+                        slot = idx;
+                        const uint32_t trial = t[RT_T0] + (uint32_t)tr, set_lo = t[RT_SETLO], set_hi = t[RT_SETHI];
+                        const float inv_D = __uint_as_float(t[RT_INVD]);
+                        float z[4];
+                        normals4<FAST>(set_lo, trial, set_hi | 0x10000000u, 0u, A.k0, A.k1, z);          // auxiliary normal 0 of the trial
+                        const float mu = __builtin_fmaf(__uint_as_float(t[RT_ETA]), z[0], __uint_as_float(t[RT_NU]));     // :124-125
+                        lam1 = (0.25f * (mu * mu)) * inv_D;
+                        g1 = mu * (inv_D * 0.318309886183790672f);
+                        x1 = mu * inv_D;
+                        c_lam2 = __uint_as_float(t[RT_CLAM2]);
+                        du = __uint_as_float(t[RT_DU0]); dl = __uint_as_float(t[RT_DL0]); total = 0.0f; sphere = 0;
+                        us.init(set_lo, set_hi, trial);
+                        fresh = true;
+                    }
                 }
                 const int n_want = (int)__popcll(want);
-                next = next + n_want < n_here ? next + n_want : n_here;
+                next = next + n_want < n_slots ? next + n_want : n_slots;
             }
+            if (has || fresh) us.refill(A.k0, A.k1);
+            if (fresh) { has = setup_sphere(); fresh = false; }
             if (!__builtin_amdgcn_ballot_w64(has)) {
-                if (next >= n_here) break;
-                continue;                                 // (every lane that took a trial ended it at once: start on a boundary)
+                if (next >= n_slots) break;
+                continue;                                 // (every lane that took a trial ended it at once, or met a hole)
             }
             // ---- one rejection attempt of every lane that holds a trial (:147-159)
             if (has) {
-                const float s2 = us.next(A.k0, A.k1), s1 = us.next(A.k0, A.k1);
+                const float s2 = us.next(), s1 = us.next();
                 const float nl = rat_neg_log<FAST>(s1);
                 const float a = F * nl;
                 bool accept = false;
@@ -190,43 +233,50 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
             }
         }
         __syncthreads();
-        // ---- flush: whole float2 lines + the fused summary (integer sums, decision time in 2^-16 s)
-        float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set * A.n_total + t0 : nullptr;
-        int n_up = 0;
-        unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
-        for (int j = lane; j < n_here; j += WAVE) {
-            const float s = staged[j];
-            const bool upper = (__float_as_uint(s) >> 31) == 0u;
-            const float tot = __builtin_fabsf(s);
-            const float rt = Tau + tot;
-            if (out) { float2 o; o.x = upper ? rt : -rt; o.y = upper ? 1.0f : 0.0f; out[j] = o; }
-            if (A.out_summary) {
-                const uint32_t tfix = (uint32_t)__builtin_fmaf(fminf(tot, 1024.0f), 65536.0f, 0.5f);
-                const unsigned long long sq = (unsigned long long)tfix * tfix;
-                sk += tfix; sk2 += sq;
-                if (upper) { n_up++; sk_up += tfix; sk2_up += sq; }
-            }
-        }
-        if (A.out_summary) {
-            n_up = wave_sum(n_up);
-            sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-            if (lane == 0) {
-                if (A.partials) {
-                    unsigned long long *q = A.partials + vset * 5;
-                    q[0] = (unsigned long long)n_up | ((unsigned long long)(n_here - n_up) << 21);
-                    q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
-                } else {
-                    finalize_summary(A.out_summary + set * NDDM_SUMMARY_K, n_up, n_here - n_up, 0, sk, sk2, sk_up, sk2_up, 0, 0, A.n_total,
-                                     1.52587890625e-05f, Tau);
+        // ---- flush, tile by tile: whole float2 lines + the fused summary (integer sums, decision time in 2^-16 s)
+        for (int tile = 0; tile < g_here; ++tile) {
+            const uint32_t *t = tbl + tile * RT_WORDS;
+            const long long vset = v0 + tile;
+            const long long set = TPS == 1 ? vset : vset / TPS;
+            const int n_here = (int)t[RT_NHERE], t0 = (int)t[RT_T0];
+            const float Tau = __uint_as_float(t[RT_TAU]);
+            const float *st = staged + tile * A.n_trials;
+            float2 *out = A.out_trials ? reinterpret_cast<float2 *>(A.out_trials) + set * A.n_total + t0 : nullptr;
+            int n_up = 0;
+            unsigned long long sk = 0, sk2 = 0, sk_up = 0, sk2_up = 0;
+            for (int j = lane; j < n_here; j += WAVE) {
+                const float sv = st[j];
+                const bool upper = (__float_as_uint(sv) >> 31) == 0u;
+                const float tot = __builtin_fabsf(sv);
+                const float rt = Tau + tot;
+                if (out) { float2 o; o.x = upper ? rt : -rt; o.y = upper ? 1.0f : 0.0f; out[j] = o; }
+                if (A.out_summary) {
+                    const uint32_t tfix = (uint32_t)__builtin_fmaf(fminf(tot, 1024.0f), 65536.0f, 0.5f);
+                    const unsigned long long sq = (unsigned long long)tfix * tfix;
+                    sk += tfix; sk2 += sq;
+                    if (upper) { n_up++; sk_up += tfix; sk2_up += sq; }
                 }
             }
+            if (A.out_summary) {
+                n_up = wave_sum(n_up);
+                sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
+                if (lane == 0) {
+                    if (A.partials) {
+                        unsigned long long *q = A.partials + vset * 5;
+                        q[0] = (unsigned long long)n_up | ((unsigned long long)(n_here - n_up) << 21);
+                        q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
+                    } else {
+                        finalize_summary(A.out_summary + set * NDDM_SUMMARY_K, n_up, n_here - n_up, 0, sk, sk2, sk_up, sk2_up, 0, 0, A.n_total,
+                                         1.52587890625e-05f, Tau);
+                    }
+                }
+            }
+            if (A.out_ext && lane == 0 && t0 == 0) {
+                float z[4];
+                normals4<FAST>(t[RT_SETLO], 0xffffffffu, t[RT_SETHI] | 0x10000000u, 0u, A.k0, A.k1, z);     // the set's external datum (alpha_not_scaled.py:103-106)
+                A.out_ext[set] = __builtin_fmaf(A.ext_sigma, z[0], (A.ext_mode == 0) ? __uint_as_float(t[RT_ALPHA]) : 1.0f);
+            }
         }
-        if (A.out_ext && lane == 0 && t0 == 0) {
-            float z[4];
-            normals4<FAST>(set_lo, 0xffffffffu, set_hi | 0x10000000u, 0u, A.k0, A.k1, z);       // the set's external datum (alpha_not_scaled.py:103-106)
-            A.out_ext[set] = __builtin_fmaf(A.ext_sigma, z[0], (A.ext_mode == 0) ? Alpha : 1.0f);
-        }
-        __syncthreads();
     }
 }
 

@@ -184,7 +184,7 @@ class GraphTrainer:
         # The pipelined loop needs its streams on DIFFERENT hardware queues (HIP multiplexes all streams of a priority onto four;
         # which one a stream gets is not ours to choose): a communication stream that shared the training stream's queue ran the
         # all-gather of batch i + 1 behind the training graph of batch i instead of beside it (+ 45 us per iteration,
-        # HISTORY.md §B.6, "Config 5, round 4").  So the side streams are CHOSEN by a probe: independent of the streams before them.
+        # HISTORY.md §C.6, "Config 5, round 4").  So the side streams are CHOSEN by a probe: independent of the streams before them.
         # (A high-priority stream has a queue of its own by construction, but its mere existence slowed every kernel that ran
         # beside the simulator by 2-7 x on this chip: measured, not used.)
         self.independent_queues = []       # one entry per probed side stream: did the probe find a queue of its own?
@@ -563,7 +563,7 @@ class GraphTrainer:
         # Host order of an iteration.  The producer of batch i + 1 goes to its streams BEFORE the training graph of batch i goes
         # to its own: a cross-stream wait is resolved against what the other stream holds when the wait is ISSUED -- enqueued
         # after the training graph, the simulate graph (which only depends on batch i's staging copies) was seen starting
-        # 300-400 us into it, and at dt=.001 (a 200 us launch) finishing after it (HISTORY.md §B.6, "Config 5, round 4"; the pipelined timelines: profiles/r4_train_timeline*.txt).  Only a
+        # 300-400 us into it, and at dt=.001 (a 200 us launch) finishing after it (HISTORY.md §C.6, "Config 5, round 4"; the pipelined timelines: profiles/r4_train_timeline*.txt).  Only a
         # HOST-blocking exchange (gloo) turns the order round: the host then waits in the collective while the device trains.
         produce_first = not (gather and self.backend != "nccl")
 

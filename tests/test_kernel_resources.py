@@ -39,7 +39,7 @@ def test_fast_kernels_fit_eight_waves_per_simd():
         v, s = sims[name]["VGPRs"], sims[name]["TotalSGPRs"]
         assert min(rt.waves_by_vgpr(v), rt.waves_by_sgpr(s)) >= (8 if "<basic" in name else 7), (name, v, s)
     # the bridge kernel (alpha_not_scaled, 32-bit staging; three Philox blocks per pass): SGPRs for 8 waves, VGPRs for 7 -- at 64
-    # VGPRs (a scheduling barrier between its generators) it measured no faster than at 66-68 (A/B on one box, HISTORY.md section B.5.1)
+    # VGPRs (a scheduling barrier between its generators) it measured no faster than at 66-68 (A/B on one box, HISTORY.md section C.5.1)
     for name in sims:
         if ", fast," in name and "bridge=1" in name:
             assert rt.waves_by_sgpr(sims[name]["TotalSGPRs"]) == 8 and rt.waves_by_vgpr(sims[name]["VGPRs"]) >= 7, name

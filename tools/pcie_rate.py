@@ -1,4 +1,4 @@
-"""The host-inclusive rate of the headline workload (DESIGN.md §6 "Host-inclusive"; HISTORY.md §B.6 "PCIe note"): simulate 1M sets x 300 trials on the device, then bring
+"""The host-inclusive rate of the headline workload (DESIGN.md §6 "Host-inclusive"; HISTORY.md §C.6 "PCIe note"): simulate 1M sets x 300 trials on the device, then bring
 the 2.4 GB of (rt, choice) pairs to the host -- what a caller pays who wants NumPy arrays back (the per-set drop-in form).  Three
 forms: a copy into PINNED host memory, a copy into pageable memory (torch's `.cpu()`), and the copy CHUNKED and overlapped with the
 simulation of the next chunk (two streams, pinned memory).  Never the bench line's `value`.   usage: python tools/pcie_rate.py [sets]"""

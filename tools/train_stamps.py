@@ -2,7 +2,7 @@
 """Where does a training kernel's time go?  Builds csrc/train_*.hip with -DNDDM_TRAIN_STAMPS (thread 0 of one workgroup writes
 (phase id, 100 MHz wall clock) pairs at the kernels' barriers), runs the flow / the summary network forward and backward once
 at the training loop's shape (32 sets, 300 trials) and prints the time between consecutive stamps, grouped by phase pair.
-The numbers quoted in HISTORY.md section B.6 (forward 7.8 us and backward 19 -> 10 us per half-layer, ...) come from here.
+The numbers quoted in HISTORY.md section C.6 (forward 7.8 us and backward 19 -> 10 us per half-layer, ...) come from here.
 
 usage (on the GPU box): python tools/train_stamps.py [flow|deepset] [workgroup]"""
 import collections
