@@ -17,9 +17,9 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     import oracle
     import prior_util
-    from test_gpu_fuzz import _case
+    from test_gpu_fuzz import _case, round6_case
     from bayesflow_nddms_amd import _lib, engine
-    t0, n, per_model, chunk = time.time(), 0, [0] * 5, first
+    t0, n, per_model, chunk, n6 = time.time(), 0, [0] * 5, first, 0
     try:
         while time.time() - t0 < 60 * minutes:
             rng = np.random.default_rng(chunk)
@@ -53,12 +53,19 @@ def main():
                     return 1
                 n += 1
                 per_model[model] += 1
+            try:                                              # ... and one case of each round-6 path per chunk (NDDM_STATE_F64, nddm_simulratcliff)
+                round6_case(rng)
+                n6 += 2
+            except AssertionError as e:
+                print("MISMATCH (round-6 paths)", chunk, str(e)[:300], flush=True)
+                return 1
             chunk += 1
             if (chunk - first) % 20 == 0:
                 print(f"{n} cases bit-equal ({time.time() - t0:.0f} s)", flush=True)
     finally:
         _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
-    print(f"fuzz_long: {n} cases (seeds {first}..{chunk - 1}; per model {per_model}) bit-equal to the oracle in {time.time() - t0:.0f} s: no mismatch")
+    print(f"fuzz_long: {n} cases (seeds {first}..{chunk - 1}; per model {per_model}) + {n6} cases of the round-6 paths (NDDM_STATE_F64 against the "
+          f"float64 restatement, nddm_simulratcliff against section D) bit-equal to the oracle in {time.time() - t0:.0f} s: no mismatch")
     return 0
 
 

@@ -60,37 +60,44 @@ def test_fuzz_bit_parity(chunk):
         _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 
 
-@pytest.mark.parametrize("chunk", range(3))
-def test_fuzz_bit_parity_of_the_round_6_paths(chunk):
-    """The same randomised check for the two device paths added in round 6: NDDM_STATE_F64 (basic / single, every tuning knob, odd caps,
-    offsets beyond 2^32) against the float64 oracle, and nddm_simulratcliff (random batch and trial counts, tiled sets, parameter rows
-    from the generator's ranges with the corners mixed in) against the oracle's section D -- every bit of trials, summaries, datum."""
+def round6_case(rng):
+    """One random case of each device path added in round 6, GPU exact mode against the oracle, every bit: NDDM_STATE_F64 (basic /
+    single, every tuning knob, odd caps, offsets beyond 2^32) against the float64 restatement, and nddm_simulratcliff (random batch and
+    trial counts, tiled sets, parameter rows from the generator's ranges with the corners mixed in) against section D.  Raises
+    AssertionError with the case's parameters on a mismatch.  (tests/fuzz_long.py draws these by the thousand.)"""
     import oracle
     from bayesflow_nddms_amd import _lib, engine
+    model, B, N, dt, max_steps, seed, off, tune, _ = _case(rng)
+    model = model % 2                                  # basic or single
+    pseed = int(rng.integers(0, 10**6))
+    p = prior_util.basic_prior(B, pseed) if model == 0 else prior_util.single_prior(B, pseed, gamma=float(rng.choice([1.0, 2.0, 0.3])))
+    _lib.check(_lib.lib().nddm_set_tuning(*tune))
+    g = engine.simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, fast=False, state_f64=True)
+    o = oracle.philox_simulate_f64(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, threads=8, want_outputs=True)
+    ctx = ("state_f64", model, B, N, dt, max_steps, seed, off, tune)
+    assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32)), ctx
+    assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32)), ctx
+    _lib.check(_lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0))
+    Br, Nr = int(rng.integers(1, 90)), int(rng.choice([1, 2, 7, 64, 65, 300, 512, 513, 1500]))
+    pr = prior_util.alpha_ns_prior(Br, pseed)
+    for row in rng.integers(0, Br, size=min(3, Br)):      # corners: a start on a boundary, a clipped drift, no drift variability
+        pr[row] = rng.choice(np.array([[8.0, 1.0, 0.0, 0.3, 0.0, 1.0], [-9.0, 1.2, 1.0, 0.2, 0.5, 0.9], [0.0, 0.8, 0.5, 0.15, 0.0, 1.4],
+                                       [4.9, 1.4, 0.31, 0.6, 2.0, 0.8]], np.float32))
+    em = int(rng.integers(0, 2))
+    g = engine.simulratcliff(pr, Nr, seed=seed, set_offset=off, fast=False, ext_sigma=0.3, ext_mode=em, want_ext=True)
+    o = oracle.philox_ratcliff(pr, Nr, seed=seed, set_offset=off, ext_sigma=0.3, ext_mode=em, want_ext=True, threads=8)
+    for k in ("trials", "summary", "ext"):
+        assert np.array_equal(np.nan_to_num(g[k].cpu().numpy()).view(np.uint32), np.nan_to_num(o[k]).view(np.uint32)), ("simulratcliff", k, Br, Nr, seed, off)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_fuzz_bit_parity_of_the_round_6_paths(chunk):
+    """The randomised check for the two device paths added in round 6 (round6_case): 30 cases of each."""
+    from bayesflow_nddms_amd import _lib
     rng = np.random.default_rng(7000 + chunk)
     try:
         for _ in range(10):
-            model, B, N, dt, max_steps, seed, off, tune, _ = _case(rng)
-            model = model % 2                                  # basic or single
-            pseed = int(rng.integers(0, 10**6))
-            p = prior_util.basic_prior(B, pseed) if model == 0 else prior_util.single_prior(B, pseed, gamma=float(rng.choice([1.0, 2.0, 0.3])))
-            _lib.check(_lib.lib().nddm_set_tuning(*tune))
-            g = engine.simulate(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, fast=False, state_f64=True)
-            o = oracle.philox_simulate_f64(model, p, N, dt=dt, max_steps=max_steps, seed=seed, set_offset=off, threads=8, want_outputs=True)
-            ctx = ("state_f64", model, B, N, dt, max_steps, seed, off, tune)
-            assert np.array_equal(g["trials"].cpu().numpy().view(np.uint32), o["trials"].view(np.uint32)), ctx
-            assert np.array_equal(np.nan_to_num(g["summary"].cpu().numpy()).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32)), ctx
-            _lib.check(_lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0))
-            Br, Nr = int(rng.integers(1, 90)), int(rng.choice([1, 2, 7, 64, 65, 300, 512, 513, 1500]))
-            pr = prior_util.alpha_ns_prior(Br, pseed)
-            for row in rng.integers(0, Br, size=min(3, Br)):      # corners: a start on a boundary, a clipped drift, no drift variability
-                pr[row] = rng.choice(np.array([[8.0, 1.0, 0.0, 0.3, 0.0, 1.0], [-9.0, 1.2, 1.0, 0.2, 0.5, 0.9], [0.0, 0.8, 0.5, 0.15, 0.0, 1.4],
-                                               [4.9, 1.4, 0.31, 0.6, 2.0, 0.8]], np.float32))
-            em = int(rng.integers(0, 2))
-            g = engine.simulratcliff(pr, Nr, seed=seed, set_offset=off, fast=False, ext_sigma=0.3, ext_mode=em, want_ext=True)
-            o = oracle.philox_ratcliff(pr, Nr, seed=seed, set_offset=off, ext_sigma=0.3, ext_mode=em, want_ext=True, threads=8)
-            for k in ("trials", "summary", "ext"):
-                assert np.array_equal(np.nan_to_num(g[k].cpu().numpy()).view(np.uint32), np.nan_to_num(o[k]).view(np.uint32)), ("simulratcliff", k, Br, Nr, seed, off)
+            round6_case(rng)
     finally:
         _lib.lib().nddm_set_tuning(0, 0, 0, 0, 0, 0)
 

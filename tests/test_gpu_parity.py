@@ -422,6 +422,38 @@ def test_hipgraph_capture_and_replay(B):
         assert torch.equal(torch.nan_to_num(summ), torch.nan_to_num(ref_s))
 
 
+def test_simulratcliff_capture_and_replay():
+    """nddm_simulratcliff under hipGraph capture: one kernel, no library memory (sets of <= 512 trials), every replay bit-equal to the
+    eager launch; a tiled launch WITH summaries (stream-ordered scratch) is refused under capture with ValueError and the library
+    stays usable."""
+    import torch
+    from bayesflow_nddms_amd import engine
+    B, N = 700, 100
+    p = torch.as_tensor(prior_util.alpha_ns_prior(B, 4)).cuda()
+    out, summ = torch.empty((B, N, 2), device="cuda"), torch.empty((B, 10), device="cuda")
+    kw = dict(seed=3, set_offset=7, fast=True, out_trials=out, out_summary=summ)
+    engine.simulratcliff(p, N, **kw)
+    torch.cuda.synchronize()
+    ref_t, ref_s = out.clone(), summ.clone()
+    g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            engine.simulratcliff(p, N, **kw)
+    for _ in range(4):
+        out.zero_(); summ.fill_(-7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_t) and torch.equal(torch.nan_to_num(summ), torch.nan_to_num(ref_s))
+    big = torch.empty((8, 1200, 2), device="cuda")
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(ValueError, match="captured"):
+            with torch.cuda.graph(g2, stream=side):
+                engine.simulratcliff(p[:8], 1200, seed=3, set_offset=7, out_trials=big)
+    r = engine.simulratcliff(p[:8], 1200, seed=3, set_offset=7)                 # (eager: fine)
+    assert torch.isfinite(r["summary"]).all()
+
+
 def test_large_launch_under_capture():
     """A captured launch gets memory of its own for ALL of its scratch (order, partial sums), so mid-size launches are
     capturable too and replay bit-identically; only a launch that would pin more than 64 MB is refused -- with ValueError,

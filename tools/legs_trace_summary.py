@@ -21,9 +21,18 @@ def main():
           "workload launches; the others are the lockstep-ceiling and KS launches of the same kernel) beside bench.py's HIP events.\n")
     print("| config | kernel (rocprofv3 name) | workload launches | rocprofv3 mean ms | bench.py HIP events ms | trials/s in the line |\n|---|---|---|---|---|---|")
     legs = bench.get("legs", {})
-    rows = [("configs[1] basic_ddm_dc (headline)", "sim_kernel<0,", None, bench["roofline"]["kernel_ms"], bench["value"]),
-            ("configs[3] single_trial + fused summaries", "sim_kernel<1,", None, legs.get("single", {}).get("kernel_ms"), legs.get("single", {}).get("value")),
-            ("configs[2] alpha_not_scaled + bridge", "sim_kernel<3,", "true, true, true,", legs.get("alpha_ns_bridge", {}).get("kernel_ms"), legs.get("alpha_ns_bridge", {}).get("value"))]
+    g = lambda k, f: legs.get(k, {}).get(f)
+    # (label, substring of the kernel's name, second substring or None, the leg's HIP-event ms, its trials/s).  The template arguments
+    # after the model are FAST, CAP4, BRIDGE, SMALL, PACKED, VKEYS, CODES, F64.
+    rows = [("configs[1] basic_ddm_dc (headline)", "sim_kernel<0, true,", "false, false>", bench["roofline"]["kernel_ms"], bench["value"]),
+            ("configs[3] single_trial + fused summaries", "sim_kernel<1, true,", None, g("single", "kernel_ms"), g("single", "value")),
+            ("configs[2] alpha_not_scaled + bridge", "sim_kernel<3,", "true, true, true,", g("alpha_ns_bridge", "kernel_ms"), g("alpha_ns_bridge", "value")),
+            ("configs[2] with the reference's own generator (nddm_simulratcliff)", "ratcliff_kernel<true>", None, g("alpha_ns_exact_sampler", "kernel_ms"), g("alpha_ns_exact_sampler", "value")),
+            ("basic, the reference's default dt=.01 / 400", "sim_kernel<0, true,", "false, false>", g("basic_dt01", "kernel_ms"), g("basic_dt01", "value")),
+            ("basic with NDDM_GAUSS_EXACT (the bit-pinned transform)", "sim_kernel<0, false,", "false, false>", g("exact_gauss", "kernel_ms"), g("exact_gauss", "value")),
+            ("basic with NDDM_STATE_F64, exact transform", "sim_kernel<0, false,", "false, true>", g("state_f64", "kernel_ms"), g("state_f64", "value")),
+            ("basic with NDDM_STATE_F64, fast transform", "sim_kernel<0, true,", "false, true>", (legs.get("state_f64", {}).get("fast_transform") or {}).get("kernel_ms"),
+             (legs.get("state_f64", {}).get("fast_transform") or {}).get("value"))]
     for label, key, extra, km, val in rows:
         if km is None:
             continue
@@ -31,7 +40,7 @@ def main():
             if key in name and (extra is None or extra in name):
                 near = [x for x in durs if abs(x - km) / km < 0.15]
                 if near:
-                    print(f"| {label} | `{name[:70]}` | {len(near)} of {len(durs)} | {sum(near) / len(near):.3f} | {km:.3f} | {val:.3e} |")
+                    print(f"| {label} | `{name[:78]}` | {len(near)} of {len(durs)} | {sum(near) / len(near):.3f} | {km:.3f} | {val:.3e} |")
     tr = legs.get("train")
     if tr:
         print("\nTraining legs (configs[4]): kernels of `libnddm_train.so` and the simulator's small-launch kernels in the trace:\n")
