@@ -988,14 +988,18 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
         if (e != hipSuccess) return fail(NDDM_ERR_HIP, "hipMallocAsync(partial sums): %s", hipGetErrorString(e));
         A.partials = partials;
     }
-    // a workgroup works through a GROUP of consecutive tiles at a time (~2048 trials: the drain at the end of a group costs ~67
-    // trials' worth of time whatever its size), at most 64 (one lane states one tile's constants) and at most 16 KB of LDS
-    int group = 2048 / tile_n;
+    // a workgroup works through a GROUP of consecutive tiles at a time: the drain at the end of a group costs ~67 trials' worth of time
+    // whatever its size, and the group's staged results (4 B per trial) decide how many workgroups a CU holds (~1000 trials: 6.4 KB of
+    // LDS with the rings and the FIFO, six workgroups per SIMD; profiles/r6_ratcliff_shapes.txt).  <= 64 tiles (one lane
+    // states one tile's constants).  NDDM_RATCLIFF_GROUP_TRIALS: developer override of the target (A/B runs).
+    static const int group_target = [] { const char *e = getenv("NDDM_RATCLIFF_GROUP_TRIALS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 8192 ? v : 1024; }();      // (measured at 300 trials per set: 600 / 900 / 1200 / 1600 / 2048 / 3000 -> 9.7 / 9.2 / 9.4 / 10.0 / 10.5 / 13.5 ms)
+    int group = group_target / tile_n;
     group = group < 1 ? 1 : (group > 64 ? 64 : group);
     if ((long long)group > vB) group = (int)vB;
     A.group = group;
     A.tile_magic = (uint32_t)((0x100000000ull + (unsigned long long)tile_n - 1ull) / (unsigned long long)tile_n);
-    const size_t lds = ((size_t)WAVE * 8 + (size_t)group * (size_t)tile_n + (size_t)group * RT_WORDS) * sizeof(float);   // uniform rings | table | staged results
+    // uniform rings | drift FIFO | table | staged results
+    const size_t lds = ((size_t)WAVE * 8 + RATCLIFF_FIFO + (size_t)group * RT_WORDS + (size_t)group * (size_t)tile_n) * sizeof(float);
     const long long n_groups = (vB + group - 1) / group;
     const dim3 grid((unsigned)n_groups), block(WAVE);
     if (flags & NDDM_GAUSS_FAST) hipLaunchKernelGGL(ratcliff_kernel<true>, grid, block, lds, st, A);

@@ -14,15 +14,16 @@
 //   exponent); the series stops when a term no longer changes the float32 sum (<= 64 terms); a < 2^-6 is rejected without it (the bound
 //   is below 2^-33, the smallest uniform); the sphere's time is -ln(s1) / lambda.  Caps that make every loop finite: 4096 attempts
 //   (then accepted), 4096 spheres (then ended on the nearer boundary).  Laid out for 64-lane waves:
-//   * a single-wave workgroup works on a GROUP of consecutive tiles (a tile = one parameter set of <= 512 trials; ~2048 trials per
+//   * a single-wave workgroup works on a GROUP of consecutive tiles (a tile = one parameter set of <= 512 trials; ~1000 trials per
 //     group) with PERSISTENT LANES: the trial loop, the sphere loop and the rejection loop of the reference are flattened into ONE
 //     loop whose trip is one rejection attempt, and a lane whose trial ended takes the group's next trial at the top of the next trip
 //     (ballot + mbcnt; its set's constants come from a small LDS table), so the three data-dependent loop counts (1-10 spheres, 1-5
 //     attempts, 2-18 series terms) do not multiply into idle lanes, and the drain at the end -- lanes idle while the last trials
-//     finish -- is paid once per ~2048 trials instead of once per set (measured: 67 trials' worth; 20 % of the time at 300 trials
+//     finish -- is paid once per ~1000 trials instead of once per set (measured: 67 trials' worth; 20 % of the time at 300 trials
 //     per set, 67 % at the 100 trials per participant of alpha_not_scaled.py:55);
 //   * randomness: counter-based like every other stream of the library -- the per-trial drift is auxiliary normal 0 of the trial
-//     (stream 1: the very draw the Euler-Maruyama form of the model uses), the uniforms are stream 3 of the trial, consumed in order;
+//     (stream 1: the very draw the Euler-Maruyama form of the model uses; drawn for 64 slots at a time by all lanes into an LDS FIFO,
+//     the way the simulator draws its per-trial latents), the uniforms are stream 3 of the trial, consumed in order;
 //   * results are staged in LDS as one float per trial (the decision time with the response as its sign bit) and flushed as whole
 //     float2 (y, acc) lines with the fused summary reduction (integer sums of the decision time in 2^-16 s: bit-reproducible).
 // The path is VALU / transcendental bound (two exp per series term); 8 B are written per trial.
@@ -32,6 +33,7 @@
 namespace nddm {
 
 constexpr int RATCLIFF_MAX_TERMS = 64, RATCLIFF_MAX_ATTEMPTS = 4096, RATCLIFF_MAX_SPHERES = 4096;
+constexpr int RATCLIFF_FIFO = 128;          // entries of the drift-normal FIFO (a power of two >= 2 * WAVE)
 
 struct RatArgs {
     const float *params;            // [B, 6]: Nu, Alpha, Beta, Tau, Eta, Varsigma
@@ -62,11 +64,12 @@ template <bool FAST> __device__ __forceinline__ float rat_exp_neg(float y)      
     else return exact_expf_neg(-y);
 }
 
-// uniform j of (set, trial): word j & 3 of block j >> 2 of stream 3.  A lane keeps a WINDOW of two blocks in an 8-word LDS ring of its
-// own (uniform j sits at ring word j & 7): refill() -- the one place a Philox block of this stream is generated -- runs at the top of
-// a trip of the kernel's loop and makes sure blocks j >> 2 and (j >> 2) + 1 are present, i.e. at least the four uniforms a trip can
-// consume (one for a sphere's direction at hand-out, two for the attempt, one for the next sphere's direction).  (Generating the block
-// inside next() put five inlined Philox bodies into the loop: 106 SGPRs, ten of them spilled to scratch.)
+// uniform j of (set, trial): word j & 3 of block j >> 2 of stream 3.  A lane keeps its uniforms in an 8-word LDS ring of its own
+// (uniform j sits at ring word j & 7): refill() -- the one place a Philox block of this stream is generated -- runs at the top of a
+// trip of the kernel's loop and makes sure at least FOUR uniforms are ahead of the lane, what a trip can consume (one for a sphere's
+// direction when the trial was just handed out, two for the attempt, one for the next sphere's direction): ONE block whenever fewer
+// than four are left -- also the first block of a trial handed out in this trip, so new and running trials share the instruction
+// stream.  (Generating the block inside next() put five inlined Philox bodies into the loop: 106 SGPRs, ten spilled to scratch.)
 struct UnifStream {
     uint32_t set_lo, trial, c2, q, gen;                  // q: uniforms consumed, gen: blocks generated
     uint32_t *ring;                                      // this lane's 8 words in LDS
@@ -76,7 +79,7 @@ struct UnifStream {
     }
     __device__ __forceinline__ void refill(uint32_t k0, uint32_t k1)
     {
-        while (gen < (q >> 2) + 2u) {                    // (the slot of block gen held block gen - 2 < q >> 2: consumed)
+        if (4u * gen - q < 4u) {                         // (block gen goes where block gen - 2 was: q > 4 (gen - 1), so that one is consumed)
             const u32x4 x = philox4x32_10(set_lo, trial, c2, gen, k0, k1);
             *reinterpret_cast<uint4 *>(ring + (gen & 1u) * 4u) = make_uint4(x.x, x.y, x.z, x.w);
             gen++;
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
 {
     extern __shared__ uint32_t lds_raw[];
     const int G = A.group;                                             // tiles per workgroup pass (<= 64)
-    uint32_t *const tbl = lds_raw + WAVE * 8;                          // [G][RT_WORDS]  (behind the lanes' uniform rings: 16-byte aligned)
+    float *const zfifo = reinterpret_cast<float *>(lds_raw + WAVE * 8);            // [RATCLIFF_FIFO]: the drift normals of the next slots, drawn 64 at a time
+    uint32_t *const tbl = lds_raw + WAVE * 8 + RATCLIFF_FIFO;          // [G][RT_WORDS]  (behind the rings and the FIFO: 16-byte aligned)
     float *const staged = reinterpret_cast<float *>(tbl + G * RT_WORDS);          // [G][n_trials]: copysign(decision time, response)
     const int lane = threadIdx.x;
     const long long n_groups = (A.n_vsets + G - 1) / G;
@@ -140,7 +144,10 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
         us.init(0u, 0u, 0u);
         us.ring = lds_raw + lane * 8;
         int next = 0;                                     // wave-uniform: the group's next unassigned slot
+        int drawn = 0;                                    // wave-uniform: slots [next, drawn) have their drift normal in the FIFO
         const int n_slots = g_here * A.n_trials;
+        // slot -> (tile, trial within the tile); a slot beyond its tile's n_here is a hole
+        auto slot_tile = [&](int idx) { return A.n_trials == 1 ? idx : (int)(((unsigned long long)(uint32_t)idx * A.tile_magic) >> 32); };
 
         // the sphere that starts at the current position: its constants and its direction (one uniform) -- or the end of the
         // trial, when the position lies on a boundary (Beta = 0 or 1) or the safety cap is reached; returns "the trial goes on"
@@ -166,29 +173,45 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
             // shorter than n_trials -- the last tile of a split set -- leaves holes that are skipped)
             const unsigned long long want = __builtin_amdgcn_ballot_w64(!has);
             if (next < n_slots && want) {
+                const int n_want = (int)__popcll(want);
+                if (next + n_want > drawn && drawn < n_slots) {
+                    // the drift normals of the next 64 slots, by ALL lanes (auxiliary normal 0 of each slot's trial: one Philox block
+                    // and one Box-Muller pair per trial, ~95 instructions whatever the number of lanes a hand-out serves)
+                    const int ds = drawn + lane;
+                    if (ds < n_slots) {
+                        const int tile = slot_tile(ds);
+                        const uint32_t *t = tbl + tile * RT_WORDS;
+                        const int tr = ds - tile * A.n_trials;
+                        float z0 = 0.0f;
+                        if (tr < (int)t[RT_NHERE]) {
+                            float z[4];
+                            normals4<FAST>(t[RT_SETLO], t[RT_T0] + (uint32_t)tr, t[RT_SETHI] | 0x10000000u, 0u, A.k0, A.k1, z);
+                            z0 = z[0];
+                        }
+                        zfifo[ds & (RATCLIFF_FIFO - 1)] = z0;
+                    }
+                    drawn = drawn + WAVE < n_slots ? drawn + WAVE : n_slots;
+                    __builtin_amdgcn_wave_barrier();          // (the hand-out below reads other lanes' entries: a wave's LDS operations complete in order)
+                }
                 const int idx = next + (int)lane_rank(want);
                 if (!has && idx < n_slots) {
-                    // idx / n_trials (tile_magic = ceil(2^32 / n_trials), exact for idx * n_trials < 2^32; one trial per tile: 2^32 does not fit a word)
-                    const int tile = A.n_trials == 1 ? idx : (int)(((unsigned long long)(uint32_t)idx * A.tile_magic) >> 32);
+                    const int tile = slot_tile(idx);
                     const int tr = idx - tile * A.n_trials;
                     const uint32_t *t = tbl + tile * RT_WORDS;
                     if (tr < (int)t[RT_NHERE]) {
                         slot = idx;
-                        const uint32_t trial = t[RT_T0] + (uint32_t)tr, set_lo = t[RT_SETLO], set_hi = t[RT_SETHI];
+                        const uint32_t trial = t[RT_T0] + (uint32_t)tr;
                         const float inv_D = __uint_as_float(t[RT_INVD]);
-                        float z[4];
-                        normals4<FAST>(set_lo, trial, set_hi | 0x10000000u, 0u, A.k0, A.k1, z);          // auxiliary normal 0 of the trial
-                        const float mu = __builtin_fmaf(__uint_as_float(t[RT_ETA]), z[0], __uint_as_float(t[RT_NU]));     // :124-125
+                        const float mu = __builtin_fmaf(__uint_as_float(t[RT_ETA]), zfifo[idx & (RATCLIFF_FIFO - 1)], __uint_as_float(t[RT_NU]));     // :124-125
                         lam1 = (0.25f * (mu * mu)) * inv_D;
                         g1 = mu * (inv_D * 0.318309886183790672f);
                         x1 = mu * inv_D;
                         c_lam2 = __uint_as_float(t[RT_CLAM2]);
                         du = __uint_as_float(t[RT_DU0]); dl = __uint_as_float(t[RT_DL0]); total = 0.0f; sphere = 0;
-                        us.init(set_lo, set_hi, trial);
+                        us.init(t[RT_SETLO], t[RT_SETHI], trial);
                         fresh = true;
                     }
                 }
-                const int n_want = (int)__popcll(want);
                 next = next + n_want < n_slots ? next + n_want : n_slots;
             }
             if (has || fresh) us.refill(A.k0, A.k1);

@@ -190,8 +190,8 @@ struct RowTile {
         : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile_base), 0, (n_rows > 0 ? n_rows : 0) * HS * 4, 0x00020000)) {}
     __device__ __forceinline__ void put(int row, int col, float v) const
     { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (row * HS + col) * 4, 0, 0); }
-    // (dword accesses only: hipcc 7.2.26015 compiles __builtin_amdgcn_raw_buffer_load_b128 to ONE buffer_load_dword -- x is loaded, y, z,
-    //  w are not their dwords of the source (3 of every 4 floats wrong on the MI355X; the probe prints what they held).  Probe:
+    // (dword accesses only: hipcc 7.2.26015 compiles __builtin_amdgcn_raw_buffer_load_b128 to ONE buffer_load_dword -- x is loaded, and y,
+    //  z, w come back as COPIES OF x instead of their dwords of the source (got 1 1 1 1 5 5 5 5 for a source 1 2 3 4 5 6 7 8).  Probe:
     //  tools/probe_buffer_load_b128.hip, its MI355X output profiles/r6_probe_buffer_load_b128.txt; the ISA side of the
     //  claim is asserted without a GPU by tests/test_kernel_resources.py::test_toolchain_probes_compile)
     __device__ __forceinline__ float get(int row, int col) const

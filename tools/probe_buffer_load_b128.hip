@@ -2,8 +2,8 @@
 // __builtin_amdgcn_raw_buffer_load_b128 compile to, and what does it return?
 //
 // Finding (hipcc 7.2.26015, clang 22.0.0git roc-7.2.0, --offload-arch=gfx950): the builtin is compiled to ONE buffer_load_dword instead of a
-// buffer_load_dwordx4: only the x component is loaded; y / z / w are NOT their dwords of the source (what they hold instead is whatever
-// the three registers held -- the probe prints the first values it got beside the source, so the failure mode is on record).  Checkable WITHOUT a GPU from the ISA:
+// buffer_load_dwordx4: only the x component is loaded; y / z / w come back as COPIES OF x instead of their dwords of the source (MI355X:
+// got 1 1 1 1 5 5 5 5 for a source 1 2 3 4 5 6 7 8 -- the probe prints the first values it got beside the source).  Checkable WITHOUT a GPU from the ISA:
 //     hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only -o - tools/probe_buffer_load_b128.hip | grep buffer_load
 // (tests/test_kernel_resources.py::test_toolchain_probes_compile asserts exactly that, so a toolchain that fixes it makes the test --
 // and with it the workaround -- stand out), and at run time on the MI355X:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """nddm_simulratcliff at a fixed 3e8 trials per launch, cut into sets of different sizes: how much of the kernel's time is the tail of
-a tile (lanes idle while the tile's last trials finish).  Usage: python tools/ratcliff_shapes.py"""
+a tile (lanes idle while the tile's last trials finish).  Usage: python tools/ratcliff_shapes.py [--one]"""
 import os
 import sys
 
@@ -9,7 +9,8 @@ import torch  # noqa: E402
 from bayesflow_nddms_amd import engine, priors  # noqa: E402
 
 TOTAL = 300_000_000
-for N in (64, 128, 300, 512, 1024, 4096):
+SHAPES = (300,) if "--one" in sys.argv else (64, 128, 300, 512, 1024, 4096)       # --one: the bench leg's shape only (for the profiler)
+for N in SHAPES:
     B = TOTAL // N
     p = torch.as_tensor(priors.alpha_ns_prior_matrix(B, 2023)).cuda()
     tr = torch.empty((B, N, 2), dtype=torch.float32, device="cuda")
