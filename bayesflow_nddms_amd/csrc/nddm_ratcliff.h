@@ -64,6 +64,14 @@ template <bool FAST> __device__ __forceinline__ float rat_exp_neg(float y)      
     else return exact_expf_neg(-y);
 }
 
+// a / b: IEEE division in the exact mode (the checker's arithmetic), v_rcp_f32 (1 ulp) and a multiply in the fast one -- a sphere has
+// five quotients, ~10 instructions each as IEEE divisions
+template <bool FAST> __device__ __forceinline__ float rat_div(float a, float b)
+{
+    if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+
 // uniform j of (set, trial): word j & 3 of block j >> 2 of stream 3.  A lane keeps its uniforms in an 8-word LDS ring of its own
 // (uniform j sits at ring word j & 7): refill() -- the one place a Philox block of this stream is generated -- runs at the top of a
 // trip of the kernel's loop and makes sure at least FOUR uniforms are ahead of the lane, what a trip can consume (one for a sphere's
@@ -157,12 +165,12 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 staged[slot] = copysignf(total, du <= dl ? 1.0f : -1.0f);
                 return false;
             }
-            lam = lam1 + c_lam2 / (radius * radius);                                     // :138
+            lam = lam1 + rat_div<FAST>(c_lam2, radius * radius);                         // :138
             const float Gr = radius * g1;
-            F = 1.0f / __builtin_fmaf(Gr, Gr, 1.0f);                                     // :140-141, F0^2 / (1 + F0^2) with F0 = 1 / G
+            F = rat_div<FAST>(1.0f, __builtin_fmaf(Gr, Gr, 1.0f));                       // :140-141, F0^2 / (1 + F0^2) with F0 = 1 / G
             const float x = radius * x1;
             const float e = rat_exp_neg<FAST>(__builtin_fabsf(x));
-            const float p_up = (x >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);         // :143-144
+            const float p_up = rat_div<FAST>((x >= 0.0f) ? 1.0f : e, 1.0f + e);          // :143-144: 1 / (1 + e) or e / (1 + e)
             up = us.next() < p_up;                                                       // :145
             att = 0;
             return true;
@@ -229,20 +237,23 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 att++;
                 if (att >= RATCLIFF_MAX_ATTEMPTS) accept = true;
                 else if (!(a < 0.015625f)) {
-                    float tnew = 0.0f, told;
+                    // (k = 3, 5, 7, .. and the alternating sign are carried as floats: k + 2 and -sgn are exact, and fma(+-1, term, told)
+                    //  rounds exactly as told -+ term does -- the same bits as the checker's integer counter and its two branches)
+                    float tnew = 0.0f, told, k = 1.0f, sgn = 1.0f;
                     int uu = 0;
                     do {
                         told = tnew;
                         uu++;
-                        const float k = (float)(2 * uu + 1);
+                        k += 2.0f;
+                        sgn = -sgn;
                         const float term = k * rat_exp_neg<FAST>(a * (k * k));
-                        tnew = (uu & 1) ? told - term : told + term;
+                        tnew = __builtin_fmaf(sgn, term, told);
                     } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
                     const float ea = rat_exp_neg<FAST>(a);
                     accept = s2 * ea <= ea + tnew;
                 }
                 if (accept) {
-                    total += nl / lam;                                                   // :161-163
+                    total += rat_div<FAST>(nl, lam);                                     // :161-163
                     if (up ? (du <= dl) : (dl <= du)) {                                  // the nearer boundary is reached (:165-172)
                         staged[slot] = copysignf(total, up ? 1.0f : -1.0f);
                         has = false;
