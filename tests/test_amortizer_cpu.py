@@ -239,3 +239,34 @@ def test_the_flows_inverse_is_exact_in_the_tails_of_z():
     assert int(far.sum()) >= 1                                          # the runaway region exists in an UNtrained net too
     # each clamped log-scale is bounded by 1.9: |log det| <= layers * D * 1.9 + the ActNorms'
     assert float(log_det.abs().max()) <= 6 * 7 * 1.9 + float(sum(p.detach().abs().sum() for p in net.an_scale)) + 1e-6
+
+
+def test_sample_rejection_option_is_off_by_default_and_redraws_outside_the_box():
+    """AmortizedPosterior.sample(..., reject_outside=(low, high)): off by default (the reference's call, basic_ddm_dc.py:223, gets every
+    draw of the flow: same draws as before the option existed); with a box, every returned draw lies inside it, the draws that were
+    inside are untouched, `last_redrawn` counts the redrawn ones, and a box nothing falls out of changes nothing."""
+    import numpy as np
+    import torch
+    from bayesflow_nddms_amd import priors
+    from bayesflow_nddms_amd.amortizer import AmortizedPosterior, InvariantNetwork, InvertibleNetwork
+    torch.manual_seed(0)
+    am = AmortizedPosterior(InvertibleNetwork(num_params=5), InvariantNetwork()).eval()
+    conf = {"summary_conditions": torch.randn(3, 40, 2), "direct_conditions": torch.full((3, 1), float(np.log(40.0)))}
+    torch.manual_seed(1)
+    plain = am.sample(conf, 500, to_numpy=False)
+    assert plain.shape == (3, 500, 5) and am.last_redrawn == 0
+    torch.manual_seed(1)
+    wide = am.sample(conf, 500, to_numpy=False, reject_outside=([-1e9] * 5, [1e9] * 5))
+    assert torch.equal(wide, plain) and am.last_redrawn == 0
+    lo, hi = [-0.5] * 5, [0.5] * 5                              # an untrained flow is ~N(0, 1) per component: most draws fall outside
+    torch.manual_seed(1)
+    boxed = am.sample(conf, 500, to_numpy=False, reject_outside=(lo, hi), max_redraws=64)
+    assert bool(((boxed >= -0.5) & (boxed <= 0.5)).all()) and am.last_redrawn > 500
+    inside = ((plain >= -0.5) & (plain <= 0.5)).all(dim=-1)
+    assert inside.any() and torch.equal(boxed[inside], plain[inside])                   # draws that were inside are the same draws
+    with pytest.raises(ValueError):
+        am.sample(conf, 10, reject_outside=([0.0] * 4, [1.0] * 4))
+    b_lo, b_hi = priors.prior_box("basic")
+    assert np.allclose(b_lo, [-30, -10, -1, -1.5, -10]) and np.allclose(b_hi, [30, 20, 2, 3, 20])
+    s_lo, s_hi = priors.prior_box("single", widen=0.0)
+    assert len(s_lo) == 7 and np.allclose(s_hi, [10, 10, 1, 1.5, 3, 10, 5])
