@@ -810,6 +810,19 @@ def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False
         c = measure_ceiling(a, engine, _lib, torch, dev, model_id, bridge, fast, False, geometry, model_name=name, dt=dt,
                             max_steps=max_steps, state_f64=state_f64)
     leg["roofline_valu"] = valu_roofline(achieved_steps, simds, 8 if bridge else 4, c, issue_model(name, gauss, state_f64))
+    # where the distance to the ceiling goes, from the kernel's own per-wave counters (two more launches of the same batch, untimed):
+    # lane efficiency = useful lane-steps / executed lane-steps (idle lanes waiting for a refill + the unused steps of a trial's last
+    # block), and how many Philox blocks a wave runs between two refills
+    with engine.debug_trace(device=dev) as trc:
+        for i in (1, 2):
+            engine.simulate(model_id, p_dev, N, dt=dt, max_steps=max_steps, seed=2023, set_offset=L * B, fast=fast, out_trials=out_trials,
+                            out_summary=out_summary, bridge=bridge, state_f64=state_f64)
+    d = trc.read()
+    if d["blocks"] > 0:
+        lane_steps = d["blocks"] * 64.0 * (8 if bridge else 4)
+        leg["roofline_valu"].update({"lane_efficiency": em_steps_of(out_summary, p_dev[:, tau_i], dt, max_k, bridge) / lane_steps,
+                                     "philox_blocks_per_refill": d["blocks"] / max(d["refills"], 1.0),
+                                     "clock_ghz_in_kernel": 0.1 * d["cycles"] / max(d["ticks"], 1.0)})
     if with_summary_only:                                # configs[3]'s second form: the fused reduction alone, no 8 B per trial
         ms_s = timed(False)
         leg["summary_only"] = {"value": B * N / (ms_s * 1e-3), "unit": "trials/s", "kernel_ms": ms_s,

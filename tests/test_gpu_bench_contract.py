@@ -59,6 +59,7 @@ def _check_legs(d):
         rv = leg["roofline_valu"]
         assert 0 < rv["frac"] < 1.05 and 0 < rv["frac_vs_lockstep"] < 1.05 and rv["ceiling_lane_efficiency"] > 0.9
         assert rv["issue_model"]["library_matches"] is True and "ISA issue model" in rv["ceiling"]
+        assert 0.5 < rv["lane_efficiency"] <= 1.0 and rv["philox_blocks_per_refill"] > 1            # the kernel's own counters, per leg
         assert leg["roofline"]["bound"] == "hbm" and 0 < leg["roofline"]["frac"] < 1
         assert leg["em_steps_per_trial"] > (20 if name == "basic_dt01" else 50)
     # the reference's own default shape (dt=.01 / max_steps 400, basic_ddm_dc.py:87) and the bit-pinned transform are under this
