@@ -19,28 +19,30 @@ PARAM_NAMES = ("drift", "boundary", "beta", "tau", "dc")   # basic_ddm_dc.py:118
 num_params = 5
 
 
-def diffusion_trial(drift, boundary, beta, tau, dc, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None):
-    """One trial (basic_ddm_dc.py:85-112) -> (rt, choice).  choice is 0 on timeout (the reference leaves it unbound)."""
+def diffusion_trial(drift, boundary, beta, tau, dc, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None, state_f64=False):
+    """One trial (basic_ddm_dc.py:85-112) -> (rt, choice).  choice is 0 on timeout (the reference leaves it unbound).
+    state_f64=True (here and below): the evidence recurrence in the reference's float64 arithmetic (NDDM_STATE_F64)."""
     r = engine.simulate(MODEL, [drift, boundary, beta, tau, dc], 1, dt=dt, max_steps=max_steps, seed=seed,
-                        set_offset=set_offset, fast=fast, want_summary=False)
+                        set_offset=set_offset, fast=fast, want_summary=False, state_f64=state_f64)
     rt, choice = r["trials"][0, 0].tolist()
     return rt, int(choice)
 
 
-def simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None):
+def simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None, state_f64=False):
     """simulate_trials(params, n_trials) -> float64 [n_trials, 2] = (rt, choice)  (basic_ddm_dc.py:114-125)."""
     r = engine.simulate(MODEL, np.asarray(params, dtype=np.float64).reshape(1, 5), n_trials, dt=dt,
-                        max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=False)
+                        max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=False, state_f64=state_f64)
     return r["trials"][0].cpu().numpy().astype(np.float64)
 
 
 def batch_simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None,
-                          as_numpy=True, with_summary=True):
+                          as_numpy=True, with_summary=True, state_f64=False):
     """Whole batch in one launch: params [B, 5] (numpy or device tensor) -> {'sim_data': [B, n_trials, 2] float32,
     'summary_stats': [B, 10]} (numpy by default -- large batches then travel to pinned host memory chunk by chunk beside the
     simulation of the next chunk, engine.simulate_to_host; device tensors with as_numpy=False)."""
     run = engine.simulate_to_host if as_numpy else engine.simulate
-    r = run(MODEL, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=with_summary)
+    r = run(MODEL, params, n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast, want_summary=with_summary,
+            state_f64=state_f64)
     out = {"sim_data": r["trials"]}
     if with_summary:
         out["summary_stats"] = r["summary"]

@@ -33,10 +33,10 @@ def _with_gamma(params, gamma):
     return p
 
 
-def _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=False, to_host=False):
+def _run(model, params, n_trials, gamma, dt, max_steps, seed, set_offset, fast, want_summary=False, to_host=False, state_f64=False):
     run = engine.simulate_to_host if to_host else engine.simulate
     return run(model, _with_gamma(params, gamma), n_trials, dt=dt, max_steps=max_steps, seed=seed, set_offset=set_offset, fast=fast,
-               want_summary=want_summary)
+               want_summary=want_summary, state_f64=state_f64)
 
 
 def diffusion_trial(drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, dt=.01, max_steps=400., seed=None,
@@ -47,15 +47,16 @@ def diffusion_trial(drift, mu_alpha, beta, ter, std_alpha, dc, sigma1, dt=.01, m
     return tuple(r["trials"][0, 0].tolist())
 
 
-def simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None):
-    """(:144-155) -> float64 [n_trials, 2] = (choicert, z1); choicert = +-(ter + rt), 0 = missing response."""
-    r = _run(engine.SINGLE_TRIAL, params, n_trials, 1.0, dt, max_steps, seed, set_offset, fast)
+def simulate_trials(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None, state_f64=False):
+    """(:144-155) -> float64 [n_trials, 2] = (choicert, z1); choicert = +-(ter + rt), 0 = missing response.
+    state_f64=True: the evidence recurrence and the per-trial boundary in the reference's float64 arithmetic (NDDM_STATE_F64)."""
+    r = _run(engine.SINGLE_TRIAL, params, n_trials, 1.0, dt, max_steps, seed, set_offset, fast, state_f64=state_f64)
     return r["trials"][0].cpu().numpy().astype(np.float64)
 
 
-def simulate_trials_fine(params, n_trials, seed=None, set_offset=None, fast=None):
+def simulate_trials_fine(params, n_trials, seed=None, set_offset=None, fast=None, state_f64=False):
     """(:1710-1722): 1 ms resolution, max_steps=4000 keeps the 4 s tolerance."""
-    return simulate_trials(params, n_trials, dt=.001, max_steps=4000, seed=seed, set_offset=set_offset, fast=fast)
+    return simulate_trials(params, n_trials, dt=.001, max_steps=4000, seed=seed, set_offset=set_offset, fast=fast, state_f64=state_f64)
 
 
 def simulate_trials_alt(params, n_trials, dt=.01, max_steps=400., seed=None, set_offset=None, fast=None):

@@ -107,6 +107,38 @@ int main(int argc, char **argv)
     HIP_OK(hipStreamDestroy(dead));
     const int dead_stream_status = nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags, d_t, d_s, (void *)dead);
 
+    /* ABI 4 from C: (i) the same launch with NDDM_STATE_F64 -- the reference's float64 state arithmetic; (ii) the reference's exact
+     * first-passage sampler, nddm_simulratcliff (no dt): parameter rows Nu, Alpha, Beta, Tau, Eta, Varsigma.  Both are appended to
+     * the output file (trials of (i), then parameter rows, trials and summaries of (ii)) for the test to compare with the oracle. */
+    NDDM_CHECK(nddm_basic_ddm_dc_simulate(d_p, B, N, dt, max_steps, seed, 0, flags | NDDM_STATE_F64, d_t, d_s, (void *)st));
+    HIP_OK(hipStreamSynchronize(st));
+    float *t64 = (float *)malloc(nt * sizeof(float));
+    HIP_OK(hipMemcpy(t64, d_t, nt * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t nq = (size_t)B * 6;
+    float *q = (float *)malloc(nq * sizeof(float)), *d_q;
+    for (int64_t i = 0; i < B; i++) {
+        q[6 * i + 0] = -4.0f + 0.5f * (float)(i % 17);     /* Nu */
+        q[6 * i + 1] = 0.8f + 0.1f * (float)(i % 7);       /* Alpha */
+        q[6 * i + 2] = 0.3f + 0.1f * (float)(i % 5);       /* Beta */
+        q[6 * i + 3] = 0.15f + 0.05f * (float)(i % 9);     /* Tau */
+        q[6 * i + 4] = 0.25f * (float)(i % 8);             /* Eta */
+        q[6 * i + 5] = 0.8f + 0.1f * (float)(i % 6);       /* Varsigma */
+    }
+    HIP_OK(hipMalloc((void **)&d_q, nq * sizeof(float)));
+    HIP_OK(hipMemcpy(d_q, q, nq * sizeof(float), hipMemcpyHostToDevice));
+    NDDM_CHECK(nddm_simulratcliff(d_q, B, N, seed, 0, flags & NDDM_GAUSS_FAST, 0.0f, 0, d_t, d_s, NULL, (void *)st));
+    HIP_OK(hipStreamSynchronize(st));
+    float *tr = (float *)malloc(nt * sizeof(float)), *sr = (float *)malloc(ns * sizeof(float));
+    HIP_OK(hipMemcpy(tr, d_t, nt * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(sr, d_s, ns * sizeof(float), hipMemcpyDeviceToHost));
+    const int bad_flag_status = nddm_simulratcliff(d_q, B, N, seed, 0, NDDM_BRIDGE, 0.0f, 0, d_t, d_s, NULL, (void *)st);   /* no dt, no bridge */
+    f = fopen(argv[7], "ab");
+    if (!f) { perror(argv[7]); return 1; }
+    fwrite(t64, sizeof(float), nt, f); fwrite(q, sizeof(float), nq, f); fwrite(tr, sizeof(float), nt, f); fwrite(sr, sizeof(float), ns, f);
+    fclose(f);
+    printf("{\"build\": \"%s\", \"ratcliff_bad_flag_status\": %d}\n", nddm_build_info(), bad_flag_status);
+    HIP_OK(hipFree(d_q)); free(t64); free(q); free(tr); free(sr);
+
     printf("{\"sets\": %lld, \"n_trials\": %d, \"seconds\": %.6f, \"trials_per_s\": %.4e, \"first_rt\": %.6f, \"first_choice\": %.0f, "
            "\"bad_shape_status\": %d, \"graph_replay_equal\": %d, \"arena_bytes\": %llu, \"arena_allocations\": %d, "
            "\"arena_released_twice_status\": %d, \"dead_stream_status\": %d}\n", (long long)B, N, t1 - t0, (double)B * N / (t1 - t0), t[0], t[1], rc,

@@ -43,6 +43,9 @@
  *     the choice differed in none of them; a differing trial is a grazed boundary one arithmetic counts as crossed and the
  *     other does not, after which it runs on (largest step-index difference seen: 652)
  *     (oracle/ddm_oracle.c: oracle_philox_simulate_f64; tests/test_oracle_golden.py::test_f32_integrator_against_the_reference_f64_recurrence).
+ *     Since ABI 4 the deviation is an option rather than a given: with NDDM_STATE_F64 (enum nddm_flags) the basic and single-trial
+ *     simulators carry the evidence in float64 exactly as the reference's recurrence does, and their (step, choice) equal that
+ *     function's bit for bit.
  *     Parameters are taken as float32 [B, P]; there is no float64 input form.
  *   - there are no `*_cpu` twins in this library: the CPU restatement of the same stream is test infrastructure
  *     (oracle/ddm_oracle.c) and is never linked into, or reachable from, the product.  Without a ROCm device every entry

@@ -56,6 +56,36 @@ def run(sizes=SIZES, models=range(5), verbose=True, threads=16):
                 if verbose:
                     print(f"model {model} B={B} N={N} bridge={bridge} packed={packed}: {'OK' if ok else 'MISMATCH'}  ({B * N} trials; "
                           f"gpu {t1 - t0:.2f}s oracle {t2 - t1:.2f}s)", flush=True)
+    # the device paths of round 6 at the same scale: NDDM_STATE_F64 (basic, single) against the float64 restatement, nddm_simulratcliff
+    # against section D (hundreds of groups of sets per launch, tiled sets)
+    for model in (m for m in (0, 1) if m in models):
+        for B, N in sizes:
+            p = params_for(model, B)
+            kw = dict(dt=0.001, max_steps=4000, seed=3024 + model, set_offset=987654321)
+            t0 = time.time()
+            g = engine.simulate(model, p, N, fast=False, state_f64=True, **kw)
+            gt, gs = g["trials"].cpu().numpy(), g["summary"].cpu().numpy()
+            t1 = time.time()
+            o = oracle.philox_simulate_f64(model, p, N, threads=threads, want_outputs=True, **kw)
+            ok = (np.array_equal(gt.view(np.uint32), o["trials"].view(np.uint32))
+                  and np.array_equal(np.nan_to_num(gs).view(np.uint32), np.nan_to_num(o["summary"]).view(np.uint32)))
+            if not ok:
+                bad.append((model, B, N, "state_f64"))
+            if verbose:
+                print(f"model {model} B={B} N={N} NDDM_STATE_F64: {'OK' if ok else 'MISMATCH'}  ({B * N} trials; gpu {t1 - t0:.2f}s oracle {time.time() - t1:.2f}s)", flush=True)
+    if 3 in models:
+        for B, N in sizes:
+            p = params_for(3, B)
+            t0 = time.time()
+            g = engine.simulratcliff(p, N, seed=4024, set_offset=55555555555, fast=False, ext_sigma=0.2, ext_mode=0, want_ext=True)
+            got = {k: g[k].cpu().numpy() for k in ("trials", "summary", "ext")}
+            t1 = time.time()
+            o = oracle.philox_ratcliff(p, N, seed=4024, set_offset=55555555555, ext_sigma=0.2, ext_mode=0, want_ext=True, threads=threads)
+            ok = all(np.array_equal(np.nan_to_num(got[k]).view(np.uint32), np.nan_to_num(o[k]).view(np.uint32)) for k in got)
+            if not ok:
+                bad.append((3, B, N, "simulratcliff"))
+            if verbose:
+                print(f"nddm_simulratcliff B={B} N={N}: {'OK' if ok else 'MISMATCH'}  ({B * N} trials; gpu {t1 - t0:.2f}s oracle {time.time() - t1:.2f}s)", flush=True)
     return bad
 
 

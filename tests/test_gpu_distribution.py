@@ -496,6 +496,12 @@ def test_drop_in_api_on_device(kat):
     assert np.array_equal(one.astype(np.float32), allb["sim_data"][3])
     rt, choice = basic_ddm_dc.diffusion_trial(*p[0], seed=1, set_offset=0)
     assert rt > p[0][3] and choice in (-1, 0, 1)
+    # the same call shapes in the reference's float64 state arithmetic (NDDM_STATE_F64): nearly every trial the same (rt, choice)
+    one64 = basic_ddm_dc.simulate_trials(p[3], 120, seed=5, set_offset=3, state_f64=True)
+    all64 = basic_ddm_dc.batch_simulate_trials(p, 120, seed=5, set_offset=0, state_f64=True)
+    assert np.array_equal(one64.astype(np.float32), all64["sim_data"][3]) and (one64 == one).all(axis=1).mean() > 0.97
+    s64 = st.simulate_trials_fine(kat["single_sets"][0], 80, seed=5, set_offset=1, state_f64=True)
+    assert s64.shape == (80, 2) and (np.sign(s64[:, 0]) == np.sign(st.simulate_trials_fine(kat["single_sets"][0], 80, seed=5, set_offset=1)[:, 0])).mean() > 0.97
     # the package-level stream: consecutive calls differ, re-seeding reproduces
     nd.seed(123)
     a1, a2 = basic_ddm_dc.simulate_trials(p[0], 50), basic_ddm_dc.simulate_trials(p[0], 50)
