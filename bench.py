@@ -864,6 +864,22 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "traffic": None,
                         "note": "VALU / transcendental bound (a theta-series rejection test per sphere); no issue model is quoted for this kernel"}}
+    # HBM bytes from the committed rocprofv3 PMC passes of this kernel at this shape (tools/gpu_profile_ratcliff.sh), quoted only if they
+    # were collected from the library that is running
+    from bayesflow_nddms_amd.build import source_hash
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_ratcliff_pmc.json")), key=_round_key, reverse=True):
+        try:
+            d = json.load(open(path))
+            c = next(v["pmc_per_launch"] for k, v in d["kernels"].items() if "ratcliff_kernel<true>" in k)
+            if d["sets"] == B and d["n_trials"] == N and "WRITE_SIZE" in c:
+                if d.get("source_hash") == source_hash():
+                    leg["roofline"].update(traffic=(2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, traffic_source=os.path.basename(path),
+                                           traffic_source_hash=d["source_hash"][:16])
+                else:
+                    leg["roofline"]["traffic_refused"] = [os.path.basename(path)]
+                break
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
     ms_x = timed(False)
     leg["exact_transform"] = {"value": B * N / (ms_x * 1e-3), "unit": "trials/s", "kernel_ms": ms_x,
                               "what": "NDDM_GAUSS_EXACT: every rounding spelled out, bit-equal to oracle/ddm_oracle.c section D "

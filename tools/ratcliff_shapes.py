@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from bayesflow_nddms_amd import engine, priors  # noqa: E402
 
+from bayesflow_nddms_amd import _lib  # noqa: E402
+
+print(f"# library source hash {_lib.lib().nddm_source_hash().decode()}", flush=True)
 TOTAL = 300_000_000
 SHAPES = (300,) if "--one" in sys.argv else (64, 128, 300, 512, 1024, 4096)       # --one: the bench leg's shape only (for the profiler)
 for N in SHAPES:

@@ -28,7 +28,11 @@ for fn in sorted(glob.glob(os.path.join(src, "pmc*", "r_counter_collection.csv")
             pmc[name][k].append(v)
 sys.path.insert(0, ROOT)
 from bayesflow_nddms_amd.build import source_hash  # noqa: E402
-out = {"command": open(os.path.join(src, "command.txt")).read().strip(), "sets": B, "n_trials": N, "source_hash_of_the_tree_at_summary_time": source_hash(), "kernels": {}}
+import re  # noqa: E402
+m_hash = re.search(r"# library source hash ([0-9a-f]{64})", open(os.path.join(src, "run_trace.txt")).read())
+out = {"command": open(os.path.join(src, "command.txt")).read().strip(), "sets": B, "n_trials": N,
+       "source_hash": m_hash.group(1) if m_hash else None,          # of the library that was PROFILED (printed by the profiled program)
+       "source_hash_of_the_tree_at_summary_time": source_hash(), "kernels": {}}
 lines = [f"# rocprofv3 summary `{tag}` -- `{out['command']}` (nddm::ratcliff_kernel, {B} sets x {N} trials per launch)\n",
          "Collected by tools/gpu_profile_ratcliff.sh on one MI355X: pass 1 `--kernel-trace --stats`, then one `--kernel-trace --pmc` pass per counter group.\n",
          open(os.path.join(src, "run_trace.txt")).read().strip() and "bench-side event timing of the traced run:\n\n```\n" + open(os.path.join(src, "run_trace.txt")).read().strip() + "\n```\n"]
