@@ -124,6 +124,9 @@ def parse():
                          "step under each --gather mode (and which of them the plain command and its side legs use), against 288 GB of HBM")
     ap.add_argument("--no-plain-compare", action="store_true",
                     help="--dist at world 1 with a gather: skip the interleaved passes that report the gathered rate over the plain one")
+    ap.add_argument("--compare-plain", action="store_true",
+                    help="with a process group of ANY size and a gather: after the timed region, interleave passes with and without the "
+                         "gather in this same job and report gathered / plain (dist.gathered_over_plain_same_process; default at --dist world 1)")
     ap.add_argument("--train", action="store_true", help="BASELINE config 5: online simulation feeding the amortizer")
     ap.add_argument("--train-iters", type=int, default=150)
     ap.add_argument("--batch", type=int, default=32, help="--train: parameter sets per rank per training step")
@@ -971,7 +974,7 @@ def simulate_bench(a, ctx):
     # ---- everything below is OUTSIDE the headline's timed region
     ident = rank_identity(a, ctx, t_prior, run) if dist_on else None            # (a collective: every rank takes part)
     pass_allocated = run["allocated_bytes"]
-    if a.dist and world == 1 and a.gather != "none" and not a.no_plain_compare:
+    if dist_on and a.gather != "none" and ((a.dist and world == 1 and not a.no_plain_compare) or a.compare_plain):
         # The gathered pass against the plain one IN THIS PROCESS, interleaved (gathered, plain, gathered, plain, ...): the ratio
         # the correctness suite used to take between two separately launched processes -- where one hiccup of the box read as a
         # 27 % gap in round 5 (gpurun_out/r5/gpu_suite1.log) -- reported here as a number, asserted nowhere.
@@ -980,7 +983,7 @@ def simulate_bench(a, ctx):
             for tag, g in (("gathered", a.gather), ("plain", "none")):
                 r = simulate_pass(a, ctx, p_dev, B, g, k, 1, first_step=nxt0, summary_only=a.summary_only and g == "none")
                 nxt0 += k + 1
-                rates[tag].append(B * N * k / r["elapsed"])
+                rates[tag].append(world * B * N * k / r["elapsed"])
                 del r
         med = lambda v: float(np.median(v))
         ident["gathered_over_plain_same_process"] = {"ratio": med(rates["gathered"]) / med(rates["plain"]), "gathered_trials_per_s": rates["gathered"],
