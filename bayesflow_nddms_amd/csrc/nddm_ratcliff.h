@@ -241,15 +241,32 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                     //  rounds exactly as told -+ term does -- the same bits as the checker's integer counter and its two branches)
                     float tnew = 0.0f, told, k = 1.0f, sgn = 1.0f;
                     int uu = 0;
-                    do {
-                        told = tnew;
-                        uu++;
-                        k += 2.0f;
-                        sgn = -sgn;
-                        const float term = k * rat_exp_neg<FAST>(a * (k * k));
-                        tnew = __builtin_fmaf(sgn, term, told);
-                    } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
                     const float ea = rat_exp_neg<FAST>(a);
+                    if constexpr (FAST) {
+                        // the fast mode takes the terms' exponentials by RECURRENCE from the one exponential the test needs anyway:
+                        // e^{-a (k+2)^2} = e^{-a k^2} q_k,  q_k = e^{-4a (k+1)},  q_{k+2} = q_k e^{-8a}  -- two multiplies per term where
+                        // the exact mode (the checker's arithmetic) evaluates an exponential; e^{-8a}, e^{-9a}, e^{-16a} are powers of e^{-a}
+                        const float e2 = ea * ea, e4 = e2 * e2, e8 = e4 * e4;
+                        float ek = e8 * ea, q = e8 * e8;                                 // e^{-9a} (k = 3), e^{-16a}
+                        do {
+                            told = tnew;
+                            uu++;
+                            k += 2.0f;
+                            sgn = -sgn;
+                            tnew = __builtin_fmaf(sgn, k * ek, told);
+                            ek *= q;
+                            q *= e8;
+                        } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
+                    } else {
+                        do {
+                            told = tnew;
+                            uu++;
+                            k += 2.0f;
+                            sgn = -sgn;
+                            const float term = k * rat_exp_neg<FAST>(a * (k * k));
+                            tnew = __builtin_fmaf(sgn, term, told);
+                        } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
+                    }
                     accept = s2 * ea <= ea + tnew;
                 }
                 if (accept) {
