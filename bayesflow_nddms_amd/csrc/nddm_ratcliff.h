@@ -143,7 +143,9 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
         __syncthreads();
 
         // ---- per-lane trial state
-        bool has = false, fresh = false;                 // fresh: handed out in this trip, its first sphere not set up yet
+        bool has = false, need_sphere = false;           // need_sphere: the trial's next sphere -- its first, after the hand-out, or the one
+                                                          // a step away from the boundary leads to -- is set up at the top of the next trip:
+                                                          // ONE site for both (as two inlined sites each ran for a quarter of the lanes)
         int slot = 0;                                     // index of the trial's staged result: tile * n_trials + trial within the tile
         float du = 0.0f, dl = 0.0f, total = 0.0f, lam1 = 0.0f, g1 = 0.0f, x1 = 0.0f, lam = 1.0f, F = 0.0f, c_lam2 = 0.0f;
         bool up = false;
@@ -217,13 +219,13 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                         c_lam2 = __uint_as_float(t[RT_CLAM2]);
                         du = __uint_as_float(t[RT_DU0]); dl = __uint_as_float(t[RT_DL0]); total = 0.0f; sphere = 0;
                         us.init(t[RT_SETLO], t[RT_SETHI], trial);
-                        fresh = true;
+                        has = true; need_sphere = true;
                     }
                 }
                 next = next + n_want < n_slots ? next + n_want : n_slots;
             }
-            if (has || fresh) us.refill(A.k0, A.k1);
-            if (fresh) { has = setup_sphere(); fresh = false; }
+            if (has) us.refill(A.k0, A.k1);
+            if (need_sphere) { has = setup_sphere(); need_sphere = false; }
             if (!__builtin_amdgcn_ballot_w64(has)) {
                 if (next >= n_slots) break;
                 continue;                                 // (every lane that took a trial ended it at once, or met a hole)
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                         const float radius = fminf(du, dl);
                         if (up) { du -= radius; dl += radius; } else { du += radius; dl -= radius; }      // :174-175
                         sphere++;
-                        has = setup_sphere();
+                        need_sphere = true;
                     }
                 }
             }
