@@ -239,27 +239,27 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 att++;
                 if (att >= RATCLIFF_MAX_ATTEMPTS) accept = true;
                 else if (!(a < 0.015625f)) {
-                    // (k = 3, 5, 7, .. and the alternating sign are carried as floats: k + 2 and -sgn are exact, and fma(+-1, term, told)
-                    //  rounds exactly as told -+ term does -- the same bits as the checker's integer counter and its two branches)
-                    float tnew = 0.0f, told, k = 1.0f, sgn = 1.0f;
-                    int uu = 0;
                     const float ea = rat_exp_neg<FAST>(a);
                     if constexpr (FAST) {
-                        // the fast mode takes the terms' exponentials by RECURRENCE from the one exponential the test needs anyway:
-                        // e^{-a (k+2)^2} = e^{-a k^2} q_k,  q_k = e^{-4a (k+1)},  q_{k+2} = q_k e^{-8a}  -- two multiplies per term where
-                        // the exact mode (the checker's arithmetic) evaluates an exponential; e^{-8a}, e^{-9a}, e^{-16a} are powers of e^{-a}
-                        const float e2 = ea * ea, e4 = e2 * e2, e8 = e4 * e4;
-                        float ek = e8 * ea, q = e8 * e8;                                 // e^{-9a} (k = 3), e^{-16a}
-                        do {
-                            told = tnew;
-                            uu++;
-                            k += 2.0f;
-                            sgn = -sgn;
-                            tnew = __builtin_fmaf(sgn, k * ek, told);
-                            ek *= q;
-                            q *= e8;
-                        } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
+                        // The test is s2 e^-a <= theta(a), theta(a) = sum_{k = 1, 3, 5, ..} (-1)^((k-1)/2) k e^{-a k^2} = eta(4 a i / pi)^3.
+                        // The reference's series needs up to 18 terms when a is small -- and a wave waits for its smallest a.  The
+                        // modular transformation of eta (Jacobi's imaginary transformation) states the same function as
+                        //   theta(a) = (pi / 4a)^{3/2} theta(pi^2 / 16a),
+                        // a series in e^{-pi^2 k^2 / 16a} that converges the faster the smaller a is; the two meet at a = pi / 4, where the
+                        // fourth term of either is 7 e^{-49 pi / 4} ~ 1e-16 of the first: THREE terms of whichever series a calls for
+                        // are theta(a) to float32, with no loop and the same instructions for every lane.
+                        const bool dual = a < 0.785398163f;
+                        const float rs = __builtin_amdgcn_rsqf(a), ra = rs * rs;
+                        const float E = dual ? rat_exp_neg<FAST>(0.616850275f * ra) : ea;          // e^{-c}, c = pi^2 / 16a or a
+                        const float E2 = E * E, E4 = E2 * E2, E8 = E4 * E4;
+                        const float P = __builtin_fmaf(E8, __builtin_fmaf(5.0f * E8, E8, -3.0f), 1.0f);    // 1 - 3 e^{-8c} + 5 e^{-24c}
+                        // dual: s2 e^-a <= (pi/4)^{3/2} a^{-3/2} e^{-c} P;  else: s2 e^-a <= e^-a P
+                        accept = dual ? (s2 * ea <= (0.696040999f * (rs * ra)) * (E * P)) : (s2 <= P);
                     } else {
+                        // (k = 3, 5, 7, .. and the alternating sign are carried as floats: k + 2 and -sgn are exact, and fma(+-1, term, told)
+                        //  rounds exactly as told -+ term does -- the same bits as the checker's integer counter and its two branches)
+                        float tnew = 0.0f, told, k = 1.0f, sgn = 1.0f;
+                        int uu = 0;
                         do {
                             told = tnew;
                             uu++;
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                             const float term = k * rat_exp_neg<FAST>(a * (k * k));
                             tnew = __builtin_fmaf(sgn, term, told);
                         } while (tnew != told && uu < RATCLIFF_MAX_TERMS);
+                        accept = s2 * ea <= ea + tnew;
                     }
-                    accept = s2 * ea <= ea + tnew;
                 }
                 if (accept) {
                     total += rat_div<FAST>(nl, lam);                                     // :161-163
