@@ -13,7 +13,9 @@
 //   s2 e^-a <= e^-a + sum_{k = 3, 5, ..} (-+) k e^{-a k^2},  a = -F ln s1  (the reference's s2 <= 1 + s1^-F * series, without a positive
 //   exponent); the series stops when a term no longer changes the float32 sum (<= 64 terms); a < 2^-6 is rejected without it (the bound
 //   is below 2^-33, the smallest uniform); the sphere's time is -ln(s1) / lambda.  Caps that make every loop finite: 4096 attempts
-//   (then accepted), 4096 spheres (then ended on the nearer boundary).  Laid out for 64-lane waves:
+//   (then accepted), 4096 spheres (then ended on the nearer boundary).  The FAST mode evaluates the same acceptance function without
+//   the loop: three terms of the series or of its Jacobi-dual form, whichever converges (see the attempt below).  Laid out for
+//   64-lane waves:
 //   * a single-wave workgroup works on a GROUP of consecutive tiles (a tile = one parameter set of <= 512 trials; ~1000 trials per
 //     group) with PERSISTENT LANES: the trial loop, the sphere loop and the rejection loop of the reference are flattened into ONE
 //     loop whose trip is one rejection attempt, and a lane whose trial ended takes the group's next trial at the top of the next trip
@@ -26,7 +28,8 @@
 //     the way the simulator draws its per-trial latents), the uniforms are stream 3 of the trial, consumed in order;
 //   * results are staged in LDS as one float per trial (the decision time with the response as its sign bit) and flushed as whole
 //     float2 (y, acc) lines with the fused summary reduction (integer sums of the decision time in 2^-16 s: bit-reproducible).
-// The path is VALU / transcendental bound (two exp per series term); 8 B are written per trial.
+// The path is VALU-issue bound (per trial ~2.6 attempts, ~1.8 spheres, ~3.2 Philox blocks; rocprofv3: 12 wave-instructions per trial at an
+// exec-mask utilisation of 0.70, profiles/r6_ratcliff_summary.md); 8 B are written per trial.
 #pragma once
 #include "nddm_sim.h"
 
@@ -100,6 +103,13 @@ struct UnifStream {
         return uniform01(w);
     }
 };
+
+// sum of a 64-bit value < 2^60 over the 64 lanes: three DPP reductions of 20-bit pieces (each total < 2^26); lane 63 holds the total
+__device__ __forceinline__ unsigned long long wave_sum_dpp64(unsigned long long v)
+{
+    const uint32_t s0 = wave_sum_dpp((uint32_t)v & 0xfffffu), s1 = wave_sum_dpp((uint32_t)(v >> 20) & 0xfffffu), s2 = wave_sum_dpp((uint32_t)(v >> 40));
+    return (unsigned long long)s0 + ((unsigned long long)s1 << 20) + ((unsigned long long)s2 << 40);
+}
 
 // per-tile constants in LDS (RT_WORDS dwords per tile of the group), written by lane l for tile l when a group opens
 enum { RT_NU = 0, RT_ETA, RT_INVD, RT_CLAM2, RT_DU0, RT_DL0, RT_TAU, RT_ALPHA, RT_SETLO, RT_SETHI, RT_NHERE, RT_T0, RT_WORDS };
@@ -311,9 +321,11 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
             }
             if (A.out_summary) {
-                n_up = wave_sum(n_up);
-                sk = wave_sum(sk); sk2 = wave_sum(sk2); sk_up = wave_sum(sk_up); sk2_up = wave_sum(sk2_up);
-                if (lane == 0) {
+                // (DPP reductions, totals in lane 63: as shuffles the five sums are 54 ds_bpermute round trips per tile, ~5000 cycles
+                //  in which this wave issues nothing else)
+                n_up = (int)wave_sum_dpp((uint32_t)n_up);
+                sk = wave_sum_dpp64(sk); sk2 = wave_sum_dpp64(sk2); sk_up = wave_sum_dpp64(sk_up); sk2_up = wave_sum_dpp64(sk2_up);
+                if (lane == WAVE - 1) {
                     if (A.partials) {
                         unsigned long long *q = A.partials + vset * 5;
                         q[0] = (unsigned long long)n_up | ((unsigned long long)(n_here - n_up) << 21);

@@ -866,7 +866,9 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
            "mean_rt_s": mean_rt, "p_missing": 0.0,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "traffic": None,
-                        "note": "VALU / transcendental bound (a theta-series rejection test per sphere); no issue model is quoted for this kernel"}}
+                        "note": "VALU-issue bound (a rejection sampler: ~2.6 attempts, ~1.8 spheres and ~3.2 Philox blocks per trial); `valu` below "
+                                "states the measured instruction stream of this build (rocprofv3 PMC) instead of an ISA issue model: the loop's "
+                                "trip counts are data-dependent"}}
     # HBM bytes from the committed rocprofv3 PMC passes of this kernel at this shape (tools/gpu_profile_ratcliff.sh), quoted only if they
     # were collected from the library that is running
     from bayesflow_nddms_amd.build import source_hash
@@ -878,6 +880,15 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
                 if d.get("source_hash") == source_hash():
                     leg["roofline"].update(traffic=(2.0 * c.get("FETCH_SIZE", 0.0) + c["WRITE_SIZE"]) * 1024.0, traffic_source=os.path.basename(path),
                                            traffic_source_hash=d["source_hash"][:16])
+                    if all(k in c for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")):
+                        # the profiled launches' own instruction stream: wave-instructions per trial, the share of their 64 lanes that
+                        # was switched on (the flattened loop's lane efficiency), and how often a SIMD issued one (XCD-summed GUI cycles / 8
+                        # = the launch's cycles; 1024 SIMDs)
+                        leg["roofline"]["valu"] = {
+                            "wave_insts_per_trial": c["SQ_INSTS_VALU"] / (B * N),
+                            "exec_mask_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+                            "simd_cycles_per_valu_inst": 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) / c["SQ_INSTS_VALU"],
+                            "source": os.path.basename(path)}
                 else:
                     leg["roofline"]["traffic_refused"] = [os.path.basename(path)]
                 break
