@@ -992,7 +992,7 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
     // whatever its size, and the group's staged results (4 B per trial) decide how many workgroups a CU holds (~1000 trials: 6.4 KB of
     // LDS with the rings and the FIFO, six workgroups per SIMD; profiles/r6_ratcliff_shapes.txt).  <= 64 tiles (one lane
     // states one tile's constants).  NDDM_RATCLIFF_GROUP_TRIALS: developer override of the target (A/B runs).
-    static const int group_target = [] { const char *e = getenv("NDDM_RATCLIFF_GROUP_TRIALS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 8192 ? v : 1024; }();      // (measured at 300 trials per set: 600 / 900 / 1200 / 1600 / 2048 / 3000 -> 9.7 / 9.2 / 9.4 / 10.0 / 10.5 / 13.5 ms)
+    static const int group_target = [] { const char *e = getenv("NDDM_RATCLIFF_GROUP_TRIALS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 8192 ? v : 1024; }();      // (measured at 300 trials per set: 512 / 1024 / 2048 / 4096 -> 6.3 / 5.4 / 5.8 / 8.5 ms)
     int group = group_target / tile_n;
     group = group < 1 ? 1 : (group > 64 ? 64 : group);
     if ((long long)group > vB) group = (int)vB;

@@ -224,8 +224,10 @@ int nddm_alpha_not_scaled_simulate(const float *params, int64_t B, int32_t n_tri
  * coefficient Varsigma (Tuerlinckx et al. 2001: random walk on spheres with rejection) -- the generator config 3's reference actually
  * runs.  No step size: nothing to discretise, no KS caveat.  (ABI 4)
  *   params       device f32 [B, 6] = Nu, Alpha, Beta, Tau, Eta, Varsigma (Nu is clipped to +-5 as :102-103 does)
- *   flags        NDDM_GAUSS_EXACT (every rounding spelled out: equal bit for bit to oracle/ddm_oracle.c section D) or NDDM_GAUSS_FAST
- *                (v_log_f32 / v_exp_f32); nothing else
+ *   flags        NDDM_GAUSS_EXACT (every rounding spelled out, the reference's series term by term: equal bit for bit to
+ *                oracle/ddm_oracle.c section D) or NDDM_GAUSS_FAST (v_log_f32 / v_exp_f32 / v_rcp_f32, and the SAME acceptance function
+ *                from three terms of its series or of the series' Jacobi-dual form, whichever converges: no loop; on 6e6 trials no
+ *                response differs from the exact mode's and no response time by more than 1e-6 s); nothing else
  *   out_trials   [B, n_trials, 2] = (y, acc): y = +-(Tau + decision time) signed by the response, acc = (sign + 1) / 2  (:98-102)
  *   out_summary  [B, NDDM_SUMMARY_K] from integer sums of the decision time in 2^-16 s (n_missing is 0: the sampler has no timeout)
  *   out_extdata  [B]: (ext_mode == 0 ? Alpha[b] : 1) + ext_sigma * N(0,1)  (alpha_not_scaled.py:103-106), as nddm_alpha_not_scaled_simulate
