@@ -186,11 +186,13 @@ def test_simulratcliff_bit_parity(N):
         assert np.array_equal(big[:, :300], g["trials"].cpu().numpy())
         sub = engine.simulratcliff(p[10:20], 300, seed=2026, set_offset=so + 10, fast=False, want_summary=False)["trials"].cpu().numpy()
         assert np.array_equal(sub, g["trials"].cpu().numpy()[10:20])
-        # the fast transform (v_log_f32 / v_exp_f32): the same stream, nearly every trial ends on the same boundary at nearly the same time
+        # the fast mode (v_log_f32 / v_exp_f32 / v_rcp_f32; the acceptance function from three terms of its series or of the series'
+        # Jacobi-dual form instead of the reference's loop): the same stream, and the same function to float32 -- a trial differs only
+        # when an attempt's (s2, s1) lands within rounding of the acceptance bound (0 of 6e6 trials in profiles/r6_ratcliff_agreement.txt)
         f = engine.simulratcliff(p, N, seed=2026, set_offset=so, fast=True, want_summary=False)["trials"].cpu().numpy()
         gt = g["trials"].cpu().numpy()
         same = np.sign(f[..., 0]) == np.sign(gt[..., 0])
-        assert same.mean() > 0.995 and np.median(np.abs(f[..., 0] - gt[..., 0])[same]) < 1e-5
+        assert same.mean() > 0.9999 and np.abs(f[..., 0] - gt[..., 0])[same].max() < 1e-5
         # the per-trial drift is the draw the Euler-Maruyama form of the model uses: with Eta = 0 and a strong drift both agree on the response
     with pytest.raises(ValueError, match="GAUSS"):
         from bayesflow_nddms_amd import _lib
