@@ -998,8 +998,8 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
     if ((long long)group > vB) group = (int)vB;
     A.group = group;
     A.tile_magic = (uint32_t)((0x100000000ull + (unsigned long long)tile_n - 1ull) / (unsigned long long)tile_n);
-    // uniform rings | drift FIFO | table | staged results
-    const size_t lds = ((size_t)WAVE * 8 + RATCLIFF_FIFO + (size_t)group * RT_WORDS + (size_t)group * (size_t)tile_n) * sizeof(float);
+    // uniform rings | drift FIFO | round keys | table | staged results
+    const size_t lds = ((size_t)WAVE * 8 + RATCLIFF_FIFO + RATCLIFF_KEYS + (size_t)group * RT_WORDS + (size_t)group * (size_t)tile_n) * sizeof(float);
     const long long n_groups = (vB + group - 1) / group;
     const dim3 grid((unsigned)n_groups), block(WAVE);
     if (flags & NDDM_GAUSS_FAST) hipLaunchKernelGGL(ratcliff_kernel<true>, grid, block, lds, st, A);

@@ -37,6 +37,7 @@ namespace nddm {
 
 constexpr int RATCLIFF_MAX_TERMS = 64, RATCLIFF_MAX_ATTEMPTS = 4096, RATCLIFF_MAX_SPHERES = 4096;
 constexpr int RATCLIFF_FIFO = 128;          // entries of the drift-normal FIFO (a power of two >= 2 * WAVE)
+constexpr int RATCLIFF_KEYS = 20;           // dwords of the Philox round-key table in LDS
 
 struct RatArgs {
     const float *params;            // [B, 6]: Nu, Alpha, Beta, Tau, Eta, Varsigma
@@ -88,10 +89,14 @@ struct UnifStream {
     {
         set_lo = set_lo_; trial = trial_; c2 = set_hi28 | 0x30000000u; q = 0u; gen = 0u;
     }
-    __device__ __forceinline__ void refill(uint32_t k0, uint32_t k1)
+    // KEYS: AllKeys (round keys in 20 VGPRs) or the LDS byte address of the key table -- see the kernel
+    template <typename KEYS>
+    __device__ __forceinline__ void refill(const KEYS &K)
     {
         if (4u * gen - q < 4u) {                         // (block gen goes where block gen - 2 was: q > 4 (gen - 1), so that one is consumed)
-            const u32x4 x = philox4x32_10(set_lo, trial, c2, gen, k0, k1);
+            u32x4 x;
+            if constexpr (sizeof(KEYS) == sizeof(uint32_t)) x = philox4x32_10_lds(set_lo, trial, c2, gen, K);
+            else x = philox4x32_10_vkeys(set_lo, trial, c2, gen, K);
             *reinterpret_cast<uint4 *>(ring + (gen & 1u) * 4u) = make_uint4(x.x, x.y, x.z, x.w);
             gen++;
         }
@@ -120,7 +125,22 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
     extern __shared__ uint32_t lds_raw[];
     const int G = A.group;                                             // tiles per workgroup pass (<= 64)
     float *const zfifo = reinterpret_cast<float *>(lds_raw + WAVE * 8);            // [RATCLIFF_FIFO]: the drift normals of the next slots, drawn 64 at a time
-    uint32_t *const tbl = lds_raw + WAVE * 8 + RATCLIFF_FIFO;          // [G][RT_WORDS]  (behind the rings and the FIFO: 16-byte aligned)
+    uint32_t *const keys = lds_raw + WAVE * 8 + RATCLIFF_FIFO;         // [RATCLIFF_KEYS]: the ten Philox round-key pairs
+    uint32_t *const tbl = keys + RATCLIFF_KEYS;                        // [G][RT_WORDS]  (16-byte aligned)
+    // The round keys are wave-uniform, but an SGPR operand costs VALU issue time on gfx950 (v_xor_b32 with one: 4.1 cycles against 2.4;
+    // the pipe is what bounds this kernel): as in the simulator's step loop they are read from LDS as broadcasts, one round ahead, and
+    // folded in by v_bitop3_b32 (philox4x32_10_lds) -- 20 three-input XORs per block instead of 20 + 20 two-input ones, half of them
+    // with an SGPR: 82 issue cycles per block less.  kbase: the table's LDS byte address in a VGPR (opaque: one register + immediates).
+    if (threadIdx.x < 10) { keys[2 * threadIdx.x] = A.k0 + threadIdx.x * PHILOX_W0; keys[2 * threadIdx.x + 1] = A.k1 + threadIdx.x * PHILOX_W1; }
+    uint32_t kbase;
+    {
+        const uint32_t off = (uint32_t)(size_t)keys;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kbase) : "s"(off));
+    }
+    // ... and the loop's own block (the uniforms) takes them from 20 VGPRs in the fast mode (56 -> 76 VGPRs: six waves per SIMD either
+    // way, the SGPRs' bound; 5.06 -> 4.91 ms), from LDS in the exact mode (62 -> 82 VGPRs would cost its sixth wave: 10.35 vs 10.69 ms)
+    [[maybe_unused]] AllKeys VK;
+    if constexpr (FAST) VK.init(A.k0, A.k1);
     float *const staged = reinterpret_cast<float *>(tbl + G * RT_WORDS);          // [G][n_trials]: copysign(decision time, response)
     const int lane = threadIdx.x;
     const long long n_groups = (A.n_vsets + G - 1) / G;
@@ -172,11 +192,12 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
         // the sphere that starts at the current position: its constants and its direction (one uniform) -- or the end of the
         // trial, when the position lies on a boundary (Beta = 0 or 1) or the safety cap is reached; returns "the trial goes on"
         auto setup_sphere = [&]() -> bool {
+            // (straight-line but for the store: every level of nested divergence costs the loop ~10 scalar instructions of exec-mask
+            //  bookkeeping, and the scalar unit is as busy as the vector pipe here -- tools/ratcliff_isa_mix.py; a trial that ends
+            //  computes a sphere nobody uses)
             const float radius = fminf(du, dl);
-            if (!(radius > 0.0f) || sphere >= RATCLIFF_MAX_SPHERES) {
-                staged[slot] = copysignf(total, du <= dl ? 1.0f : -1.0f);
-                return false;
-            }
+            const bool dead = !(radius > 0.0f) | (sphere >= RATCLIFF_MAX_SPHERES);
+            if (dead) staged[slot] = copysignf(total, du <= dl ? 1.0f : -1.0f);
             lam = lam1 + rat_div<FAST>(c_lam2, radius * radius);                         // :138
             const float Gr = radius * g1;
             F = rat_div<FAST>(1.0f, __builtin_fmaf(Gr, Gr, 1.0f));                       // :140-141, F0^2 / (1 + F0^2) with F0 = 1 / G
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
             const float p_up = rat_div<FAST>((x >= 0.0f) ? 1.0f : e, 1.0f + e);          // :143-144: 1 / (1 + e) or e / (1 + e)
             up = us.next() < p_up;                                                       // :145
             att = 0;
-            return true;
+            return !dead;
         };
 
         while (true) {
@@ -204,9 +225,9 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                         const int tr = ds - tile * A.n_trials;
                         float z0 = 0.0f;
                         if (tr < (int)t[RT_NHERE]) {
-                            float z[4];
-                            normals4<FAST>(t[RT_SETLO], t[RT_T0] + (uint32_t)tr, t[RT_SETHI] | 0x10000000u, 0u, A.k0, A.k1, z);
-                            z0 = z[0];
+                            float z1_unused;
+                            AuxStream<FAST> aux(kbase, t[RT_SETLO], t[RT_SETHI], t[RT_T0] + (uint32_t)tr);
+                            aux.first_pair(z0, z1_unused);
                         }
                         zfifo[ds & (RATCLIFF_FIFO - 1)] = z0;
                     }
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
                 next = next + n_want < n_slots ? next + n_want : n_slots;
             }
-            if (has) us.refill(A.k0, A.k1);
+            if (has) { if constexpr (FAST) us.refill(VK); else us.refill(kbase); }
             if (need_sphere) { has = setup_sphere(); need_sphere = false; }
             if (!__builtin_amdgcn_ballot_w64(has)) {
                 if (next >= n_slots) break;
@@ -247,25 +268,29 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 const float a = F * nl;
                 bool accept = false;
                 att++;
-                if (att >= RATCLIFF_MAX_ATTEMPTS) accept = true;
-                else if (!(a < 0.015625f)) {
+                if constexpr (FAST) {
                     const float ea = rat_exp_neg<FAST>(a);
-                    if constexpr (FAST) {
-                        // The test is s2 e^-a <= theta(a), theta(a) = sum_{k = 1, 3, 5, ..} (-1)^((k-1)/2) k e^{-a k^2} = eta(4 a i / pi)^3.
-                        // The reference's series needs up to 18 terms when a is small -- and a wave waits for its smallest a.  The
-                        // modular transformation of eta (Jacobi's imaginary transformation) states the same function as
-                        //   theta(a) = (pi / 4a)^{3/2} theta(pi^2 / 16a),
-                        // a series in e^{-pi^2 k^2 / 16a} that converges the faster the smaller a is; the two meet at a = pi / 4, where the
-                        // fourth term of either is 7 e^{-49 pi / 4} ~ 1e-16 of the first: THREE terms of whichever series a calls for
-                        // are theta(a) to float32, with no loop and the same instructions for every lane.
-                        const bool dual = a < 0.785398163f;
-                        const float rs = __builtin_amdgcn_rsqf(a), ra = rs * rs;
-                        const float E = dual ? rat_exp_neg<FAST>(0.616850275f * ra) : ea;          // e^{-c}, c = pi^2 / 16a or a
-                        const float E2 = E * E, E4 = E2 * E2, E8 = E4 * E4;
-                        const float P = __builtin_fmaf(E8, __builtin_fmaf(5.0f * E8, E8, -3.0f), 1.0f);    // 1 - 3 e^{-8c} + 5 e^{-24c}
-                        // dual: s2 e^-a <= (pi/4)^{3/2} a^{-3/2} e^{-c} P;  else: s2 e^-a <= e^-a P
-                        accept = dual ? (s2 * ea <= (0.696040999f * (rs * ra)) * (E * P)) : (s2 <= P);
-                    } else {
+                    // The test is s2 e^-a <= theta(a), theta(a) = sum_{k = 1, 3, 5, ..} (-1)^((k-1)/2) k e^{-a k^2} = eta(4 a i / pi)^3.
+                    // The reference's series needs up to 18 terms when a is small -- and a wave waits for its smallest a.  The
+                    // modular transformation of eta (Jacobi's imaginary transformation) states the same function as
+                    //   theta(a) = (pi / 4a)^{3/2} theta(pi^2 / 16a),
+                    // a series in e^{-pi^2 k^2 / 16a} that converges the faster the smaller a is; the two meet at a = pi / 4, where the
+                    // fourth term of either is 7 e^{-49 pi / 4} ~ 1e-16 of the first: THREE terms of whichever series a calls for
+                    // are theta(a) to float32, with no loop and the same instructions for every lane.
+                    const bool dual = a < 0.785398163f;
+                    const float rs = __builtin_amdgcn_rsqf(a), ra = rs * rs;
+                    const float E = dual ? rat_exp_neg<FAST>(0.616850275f * ra) : ea;          // e^{-c}, c = pi^2 / 16a or a
+                    const float E2 = E * E, E4 = E2 * E2, E8 = E4 * E4;
+                    const float P = __builtin_fmaf(E8, __builtin_fmaf(5.0f * E8, E8, -3.0f), 1.0f);    // 1 - 3 e^{-8c} + 5 e^{-24c}
+                    // dual: s2 e^-a <= (pi/4)^{3/2} a^{-3/2} e^{-c} P;  else: s2 e^-a <= e^-a P  (selects, not branches; an a below
+                    // 2^-6 -- a = 0 gives NaNs here -- is rejected by the last line, as the exact mode rejects it before its series)
+                    const float lhs = s2 * (dual ? ea : 1.0f);
+                    const float rhs = P * (dual ? (0.696040999f * (rs * ra)) * E : 1.0f);
+                    accept = (att >= RATCLIFF_MAX_ATTEMPTS) | (!(a < 0.015625f) & (lhs <= rhs));
+                } else {
+                    if (att >= RATCLIFF_MAX_ATTEMPTS) accept = true;
+                    else if (!(a < 0.015625f)) {
+                        const float ea = rat_exp_neg<FAST>(a);
                         // (k = 3, 5, 7, .. and the alternating sign are carried as floats: k + 2 and -sgn are exact, and fma(+-1, term, told)
                         //  rounds exactly as told -+ term does -- the same bits as the checker's integer counter and its two branches)
                         float tnew = 0.0f, told, k = 1.0f, sgn = 1.0f;
@@ -283,15 +308,14 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
                 if (accept) {
                     total += rat_div<FAST>(nl, lam);                                     // :161-163
-                    if (up ? (du <= dl) : (dl <= du)) {                                  // the nearer boundary is reached (:165-172)
-                        staged[slot] = copysignf(total, up ? 1.0f : -1.0f);
-                        has = false;
-                    } else {
-                        const float radius = fminf(du, dl);
-                        if (up) { du -= radius; dl += radius; } else { du += radius; dl -= radius; }      // :174-175
-                        sphere++;
-                        need_sphere = true;
-                    }
+                    const bool hit = up ? (du <= dl) : (dl <= du);                       // the nearer boundary is reached (:165-172)
+                    if (hit) staged[slot] = copysignf(total, up ? 1.0f : -1.0f);
+                    // else the position moves by the radius (:174-175); a trial that ended moves too, unobserved
+                    const float radius = fminf(du, dl);
+                    const float d = up ? radius : -radius;
+                    du -= d; dl += d;
+                    sphere++;
+                    has = !hit; need_sphere = !hit;
                 }
             }
         }
@@ -337,9 +361,10 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
             }
             if (A.out_ext && lane == 0 && t0 == 0) {
-                float z[4];
-                normals4<FAST>(t[RT_SETLO], 0xffffffffu, t[RT_SETHI] | 0x10000000u, 0u, A.k0, A.k1, z);     // the set's external datum (alpha_not_scaled.py:103-106)
-                A.out_ext[set] = __builtin_fmaf(A.ext_sigma, z[0], (A.ext_mode == 0) ? __uint_as_float(t[RT_ALPHA]) : 1.0f);
+                float z0, z1_unused;
+                AuxStream<FAST> aux(kbase, t[RT_SETLO], t[RT_SETHI], 0xffffffffu);                      // the set's external datum (alpha_not_scaled.py:103-106)
+                aux.first_pair(z0, z1_unused);
+                A.out_ext[set] = __builtin_fmaf(A.ext_sigma, z0, (A.ext_mode == 0) ? __uint_as_float(t[RT_ALPHA]) : 1.0f);
             }
         }
     }

@@ -193,6 +193,32 @@ __device__ __forceinline__ u32x4 philox4x32_10_lds(uint32_t c0, uint32_t c1, uin
     return {c0, c1, c2, c3};
 }
 
+// General counter, all ten key pairs held in VGPRs for the whole kernel (20 registers): the three-input XORs of the LDS form without
+// its ten LDS round trips per block -- for a kernel whose residency is bounded by something else anyway (the exact sampler: SGPRs)
+struct AllKeys {
+    uint32_t a[10], b[10];
+    __device__ __forceinline__ void init(uint32_t k0, uint32_t k1)
+    {
+        auto v = [](uint32_t s) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s)); return r; };   // opaque: stays a VGPR
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { a[r] = v(k0 + (uint32_t)r * PHILOX_W0); b[r] = v(k1 + (uint32_t)r * PHILOX_W1); }
+    }
+};
+__device__ __forceinline__ u32x4 philox4x32_10_vkeys(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const AllKeys &K)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, K.a[r]);
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, K.b[r]);
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    return {c0, c1, c2, c3};
+}
+
 // ---------------------------------------------------------------- exact transform
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, every rounding spelled out.
 __device__ __forceinline__ float exact_logf(float u)

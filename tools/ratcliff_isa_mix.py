@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""The flattened loop of nddm::ratcliff_kernel<fast> in the SHIPPED library, priced like the simulator's step loop (tools/isa_mix.py:
+the code object's disassembly x the per-instruction issue costs of tools/ubench_valu): VALU instructions of one trip, their mean issue
+cost, and -- against the measured SIMD-cycles per VALU instruction of profiles/<tag>_ratcliff_pmc.json -- how busy the VALU pipe is.
+The trip counts are data-dependent, so this is a statement about the instruction stream, not a time model.  CPU only.
+usage: python tools/ratcliff_isa_mix.py [--ubench profiles/r6_ubench_valu.txt] [--pmc profiles/r6_ratcliff_pmc.json]"""
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_mix  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SALU_CYCLES = 4.23          # SIMD-cycles per SALU instruction at 8 waves per SIMD, tools/ubench_salu.hip (profiles/r2_ubench_salu.txt)
+
+
+def _tree_hash():
+    sys.path.insert(0, ROOT)
+    from bayesflow_nddms_amd.build import source_hash
+    return source_hash()
+
+
+def loop_of(txt, sym_re):
+    lines = txt.splitlines()
+    start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <" + sym_re + r">:", l))
+    insts = []
+    for l in lines[start + 1:]:
+        if re.match(r"^[0-9a-f]+ <", l):
+            break
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*// ([0-9A-F]+):", l)
+        if not m:
+            continue
+        tgt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", l)
+        insts.append((int(m.group(3), 16), m.group(1), m.group(2), None if not tgt else int(tgt.group(1), 16)))
+    base = insts[0][0]
+    insts = [(a - base, op, args, t) for a, op, args, t in insts]
+    # the flattened loop: the backward branch whose region holds both Philox bodies (drift FIFO + uniform refill = 32 v_mad_u64_u32)
+    best = None
+    for a, op, _, t in insts:
+        if op.startswith(("s_cbranch", "s_branch")) and t is not None and t < a:
+            body = [x for x in insts if t <= x[0] <= a]
+            n_mad = sum(1 for x in body if x[1].startswith("v_mad_u64_u32"))
+            if n_mad >= 32 and (best is None or len(body) < len(best)):
+                best = body
+    return best
+
+
+def main():
+    args = sys.argv[1:]
+    ub = os.path.join(ROOT, "profiles", "r6_ubench_valu.txt")
+    pmc = os.path.join(ROOT, "profiles", "r6_ratcliff_pmc.json")
+    if "--ubench" in args:
+        ub = args[args.index("--ubench") + 1]
+    if "--pmc" in args:
+        pmc = args[args.index("--pmc") + 1]
+    cost, sgpr, src = isa_mix.load_ubench(ub)
+    txt, digest = isa_mix.disassemble()
+    body = loop_of(txt, r"_ZN4nddm15ratcliff_kernelILb1EEEvNS_7RatArgsE")
+    t = isa_mix.tally(body, cost, sgpr)
+    # the drift FIFO's section (the first Philox body + its Box-Muller pair) runs once per 64 hand-outs, not once per trip
+    print(f"# nddm::ratcliff_kernel<fast>, code object {digest}; issue costs from {src}")
+    print(f"flattened loop, static: {t['valu']} VALU / {t['salu']} SALU / {t['lds']} LDS instructions; "
+          f"sum of VALU issue costs {t['cycles_per_block']:.0f} SIMD-cycles = {t['cycles_per_block'] / t['valu']:.2f} per VALU instruction")
+    print("  (every section of a trip -- hand-out, uniform refill, sphere set-up, attempt, acceptance -- runs once per trip; the drift FIFO's "
+          "78 instructions once per 64 hand-outs)")
+    for r in t["mix"][:12]:
+        print(f"  {r['op']:28s} x{r['n']:3d}  {r['cycles_each']:.2f} cycles each{'' if r['costed'] else '  (default cost)'}")
+    if os.path.exists(pmc):
+        d = json.load(open(pmc))
+        c = next(v["pmc_per_launch"] for k, v in d["kernels"].items() if "ratcliff_kernel<true>" in k)
+        meas = 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) / c["SQ_INSTS_VALU"]
+        mean = t["cycles_per_block"] / t["valu"]
+        stale = "" if d.get("code_object", digest) == digest and d.get("source_hash") == _tree_hash() else "  [PMC file is from another build]"
+        print(f"measured ({os.path.basename(pmc)}){stale}: one VALU instruction per {meas:.2f} SIMD-cycles = {meas * t['valu']:.0f} SIMD-cycles per trip "
+              f"-> the VALU pipe is {mean / meas:.2f} busy with this mix; exec-mask utilisation "
+              f"{c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU']):.3f} -> "
+              f"{mean / meas * c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU']):.2f} of the pipe's lane-cycles do the sampler's arithmetic")
+        print(f"the trip's {t['salu']} SALU instructions (exec-mask bookkeeping of the nested divergence) at {SALU_CYCLES} SIMD-cycles each "
+              f"(profiles/r2_ubench_salu.txt: a CU's scalar unit serves its four SIMDs in turn) = {t['salu'] * SALU_CYCLES:.0f} SIMD-cycles: the "
+              f"scalar unit is {t['salu'] * SALU_CYCLES / (meas * t['valu']):.2f} busy -- the two issue limits are about equal")
+
+
+if __name__ == "__main__":
+    main()
