@@ -403,7 +403,7 @@ def pmc_traffic(model_name, B, N, dt=0.001, gauss="fast"):
     return {"bytes": None, "refused": stale[:3]} if stale else None
 
 
-def issue_model(model_name, gauss, f64=False):
+def issue_model(model_name, gauss, f64=False, key=None):
     """ISA-level ceiling of the shipped library's step loop (tools/isa_mix.py), if the committed file matches the .so."""
     from bayesflow_nddms_amd.build import SO_PATH
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -412,13 +412,13 @@ def issue_model(model_name, gauss, f64=False):
         digest = isa_mix.code_object(SO_PATH)[1]                # hash of the library's gfx950 code object
     except Exception:                                           # noqa: BLE001 -- reported as "does not match"
         digest = None
-    key = model_name + {"fast": "", "exact": "_exact", "packed": "_packed"}[gauss] + ("_f64" if f64 else "")
+    key = key or model_name + {"fast": "", "exact": "_exact", "packed": "_packed"}[gauss] + ("_f64" if f64 else "")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), key=_round_key, reverse=True):
         try:
             d = json.load(open(path))
             k = d["kernels"][key]
             same = digest is not None and d.get("library_sha256_16") == digest
-            return {"cycles_per_block": k["cycles_per_block"], "valu_per_block": k["valu"], "steps_per_block": k.get("steps_per_block", 4),
+            return {"cycles_per_block": k.get("cycles_per_block", k.get("cycles_per_trip")), "valu_per_block": k["valu"], "steps_per_block": k.get("steps_per_block", 4),
                     "source": os.path.basename(path),
                     "issue_costs_from": d.get("issue_costs_from"), "library_matches": same}
         except (OSError, KeyError, ValueError):
@@ -884,11 +884,25 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
                         # the profiled launches' own instruction stream: wave-instructions per trial, the share of their 64 lanes that
                         # was switched on (the flattened loop's lane efficiency), and how often a SIMD issued one (XCD-summed GUI cycles / 8
                         # = the launch's cycles; 1024 SIMDs)
-                        leg["roofline"]["valu"] = {
-                            "wave_insts_per_trial": c["SQ_INSTS_VALU"] / (B * N),
-                            "exec_mask_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
-                            "simd_cycles_per_valu_inst": 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) / c["SQ_INSTS_VALU"],
-                            "source": os.path.basename(path)}
+                        v = {"wave_insts_per_trial": c["SQ_INSTS_VALU"] / (B * N),
+                             "exec_mask_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+                             "simd_cycles_per_valu_inst": 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) / c["SQ_INSTS_VALU"],
+                             "source": os.path.basename(path)}
+                        leg["roofline"]["valu"] = v
+                        # ... against the loop's ISA mix priced with the measured per-instruction issue costs (tools/ratcliff_isa_mix.py, in
+                        # the tracked issue-model file while it is of the running code object): how busy the VALU pipe is, and -- with the
+                        # exec mask -- what share of the pipe's lane-cycles is the sampler's arithmetic
+                        im = issue_model("ratcliff", "fast", key="ratcliff_fast")
+                        if im and im["library_matches"]:
+                            mean = im["cycles_per_block"] / im["valu_per_block"]
+                            busy = mean / v["simd_cycles_per_valu_inst"]
+                            leg["roofline_valu"] = {"bound": "valu_issue", "mean_issue_cycles_per_valu_inst": mean, "valu_pipe_busy": busy,
+                                                    "exec_mask_utilisation": v["exec_mask_utilisation"],
+                                                    "frac": min(1.0, busy) * v["exec_mask_utilisation"],
+                                                    "what": "frac = (VALU pipe busy, capped at 1) x (exec-mask utilisation): the share of the vector "
+                                                            "pipe's lane-cycles spent on lanes that hold a trial; the instruction stream itself "
+                                                            "(trip counts of a rejection sampler) is data-dependent, so there is no lockstep run to compare with",
+                                                    "issue_model": {k: im[k] for k in ("source", "issue_costs_from", "library_matches")}}
                 else:
                     leg["roofline"]["traffic_refused"] = [os.path.basename(path)]
                 break

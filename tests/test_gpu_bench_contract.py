@@ -75,6 +75,11 @@ def _check_legs(d):
     ex = legs["alpha_ns_exact_sampler"]
     assert ex["unit"] == "trials/s" and ex["value"] > 1e8 and ex["ks_vs_ref"]["max"] < ex["ks_vs_ref"]["bar"] == 0.01
     assert 0 < ex["exact_transform"]["value"] <= 1.05 * ex["value"] and 0.2 < ex["mean_rt_s"] < 2.0
+    # its VALU statement: the measured instruction stream (PMC file of THIS library, else absent) against the ISA mix of its loop
+    if "valu" in ex["roofline"]:
+        rv = ex["roofline_valu"]
+        assert rv["issue_model"]["library_matches"] is True and 0.3 < rv["exec_mask_utilisation"] <= 1.0 and 0.5 < rv["valu_pipe_busy"] < 1.2
+        assert abs(rv["frac"] - min(1.0, rv["valu_pipe_busy"]) * rv["exec_mask_utilisation"]) < 1e-9
     so = legs["single"]["summary_only"]
     assert so["value"] > 0 and so["kernel_ms"] > 0                                         # (no 8 B per trial: its rate is in the line, not asserted)
     tr = legs["train"]

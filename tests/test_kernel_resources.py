@@ -91,6 +91,8 @@ def test_issue_model_reads_the_shipped_library():
     newest = max(glob.glob(os.path.join(ROOT, "profiles", "*_issue_model.json")), key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
     d = json.load(open(newest))
     assert d["library_sha256_16"] == digest, (newest, "stale: run tools/refresh_issue_model.sh")
+    rf = d["kernels"]["ratcliff_fast"]                                     # the exact sampler's loop (tools/ratcliff_isa_mix.py), same file
+    assert 150 <= rf["valu"] <= 300 and rf["vmem"] == 0 and sum(m["n"] for m in rf["mix"] if m["op"].startswith("v_mad_u64_u32")) >= 32
     assert {"basic", "single", "alpha_ns_bridge", "basic_exact", "basic_exact_f64", "basic_f64"} <= set(d["kernels"])
 
 

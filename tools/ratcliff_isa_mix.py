@@ -3,7 +3,9 @@
 the code object's disassembly x the per-instruction issue costs of tools/ubench_valu): VALU instructions of one trip, their mean issue
 cost, and -- against the measured SIMD-cycles per VALU instruction of profiles/<tag>_ratcliff_pmc.json -- how busy the VALU pipe is.
 The trip counts are data-dependent, so this is a statement about the instruction stream, not a time model.  CPU only.
-usage: python tools/ratcliff_isa_mix.py [--ubench profiles/r6_ubench_valu.txt] [--pmc profiles/r6_ratcliff_pmc.json]"""
+usage: python tools/ratcliff_isa_mix.py [--ubench profiles/r6_ubench_valu.txt] [--pmc profiles/r6_ratcliff_pmc.json]
+                                         [--json-into profiles/r6_issue_model.json]   (adds kernels.ratcliff_fast to the tracked model file
+                                          bench.py reads, if that file is of the same code object; tools/refresh_issue_model.sh does)"""
 import json
 import os
 import re
@@ -65,6 +67,18 @@ def main():
           f"sum of VALU issue costs {t['cycles_per_block']:.0f} SIMD-cycles = {t['cycles_per_block'] / t['valu']:.2f} per VALU instruction")
     print("  (every section of a trip -- hand-out, uniform refill, sphere set-up, attempt, acceptance -- runs once per trip; the drift FIFO's "
           "78 instructions once per 64 hand-outs)")
+    if "--json-into" in args:
+        path = args[args.index("--json-into") + 1]
+        d = json.load(open(path))
+        if d.get("library_sha256_16") != digest:
+            sys.exit(f"{path} is of code object {d.get('library_sha256_16')}, the library is {digest}: run tools/refresh_issue_model.sh")
+        d["kernels"]["ratcliff_fast"] = {"valu": t["valu"], "salu": t["salu"], "lds": t["lds"], "vmem": t["vmem"],
+                                         "cycles_per_trip": t["cycles_per_block"], "salu_cycles_per_trip": t["salu"] * SALU_CYCLES,
+                                         "unit_note": "one trip of the flattened loop (one rejection attempt of every lane that holds a trial), static; "
+                                                      "the drift FIFO's instructions included although they run once per 64 hand-outs",
+                                         "mix": t["mix"]}
+        json.dump(d, open(path, "w"), indent=1)
+        print("added kernels.ratcliff_fast to", path)
     for r in t["mix"][:12]:
         print(f"  {r['op']:28s} x{r['n']:3d}  {r['cycles_each']:.2f} cycles each{'' if r['costed'] else '  (default cost)'}")
     if os.path.exists(pmc):
@@ -79,7 +93,7 @@ def main():
               f"{mean / meas * c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU']):.2f} of the pipe's lane-cycles do the sampler's arithmetic")
         print(f"the trip's {t['salu']} SALU instructions (exec-mask bookkeeping of the nested divergence) at {SALU_CYCLES} SIMD-cycles each "
               f"(profiles/r2_ubench_salu.txt: a CU's scalar unit serves its four SIMDs in turn) = {t['salu'] * SALU_CYCLES:.0f} SIMD-cycles: the "
-              f"scalar unit is {t['salu'] * SALU_CYCLES / (meas * t['valu']):.2f} busy -- the two issue limits are about equal")
+              f"scalar unit is {t['salu'] * SALU_CYCLES / (meas * t['valu']):.2f} busy")
 
 
 if __name__ == "__main__":

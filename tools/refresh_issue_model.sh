@@ -8,3 +8,4 @@ cd "$(dirname "$0")/.."
 python3 tools/isa_mix.py basic single single_alt alpha_ns alpha_ns_bridge explicit basic_exact single_exact alpha_ns_exact \
     alpha_ns_bridge_exact basic_packed single_packed alpha_ns_packed basic_vkeys basic_f64 single_f64 basic_exact_f64 single_exact_f64 \
     --json profiles/${TAG}_issue_model.json | grep -v "^  "
+python3 tools/ratcliff_isa_mix.py --json-into profiles/${TAG}_issue_model.json | grep "^added\|^flattened"
