@@ -221,8 +221,8 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                     const int ds = drawn + lane;
                     if (ds < n_slots) {
                         const int tile = slot_tile(ds);
-                        const uint32_t *t = tbl + tile * RT_WORDS;
-                        const int tr = ds - tile * A.n_trials;
+                        const uint32_t *t = tbl + __mul24(tile, RT_WORDS);
+                        const int tr = ds - __mul24(tile, A.n_trials);
                         float z0 = 0.0f;
                         if (tr < (int)t[RT_NHERE]) {
                             float z1_unused;
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 const int idx = next + (int)lane_rank(want);
                 if (!has && idx < n_slots) {
                     const int tile = slot_tile(idx);
-                    const int tr = idx - tile * A.n_trials;
-                    const uint32_t *t = tbl + tile * RT_WORDS;
+                    const int tr = idx - __mul24(tile, A.n_trials);
+                    const uint32_t *t = tbl + __mul24(tile, RT_WORDS);
                     if (tr < (int)t[RT_NHERE]) {
                         slot = idx;
                         const uint32_t trial = t[RT_T0] + (uint32_t)tr;
@@ -308,10 +308,13 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
                 if (accept) {
                     total += rat_div<FAST>(nl, lam);                                     // :161-163
-                    const bool hit = up ? (du <= dl) : (dl <= du);                       // the nearer boundary is reached (:165-172)
+                    // the distances ahead of and behind the step: the nearer boundary is reached when the one ahead is the smaller
+                    // (:165-172: du <= dl going up, dl <= du going down) -- and then it is the radius, else the one behind is
+                    const float ahead = up ? du : dl, behind = up ? dl : du;
+                    const bool hit = ahead <= behind;
                     if (hit) staged[slot] = copysignf(total, up ? 1.0f : -1.0f);
                     // else the position moves by the radius (:174-175); a trial that ended moves too, unobserved
-                    const float radius = fminf(du, dl);
+                    const float radius = hit ? ahead : behind;                           // = min(du, dl)
                     const float d = up ? radius : -radius;
                     du -= d; dl += d;
                     sphere++;
