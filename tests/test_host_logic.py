@@ -532,3 +532,40 @@ def test_host_shim_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_shim_battery.py")], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.stdout.strip().splitlines()[-1] == f"SHIM {want} ({n_checks} checks)"
+
+
+def test_three_term_acceptance_function_of_the_exact_samplers_fast_mode():
+    """nddm_simulratcliff's fast mode accepts an attempt when s2 e^-a <= theta(a), theta(a) = sum_{k odd} (-1)^((k-1)/2) k e^{-a k^2}, and
+    evaluates theta from THREE terms of that series (a >= pi/4) or of its Jacobi-dual form (pi/4a)^{3/2} theta(pi^2/16a) (a < pi/4) --
+    csrc/nddm_ratcliff.h.  The same float32 arithmetic in NumPy, with the kernel's constants, against 400 terms of the series in
+    float64 over the whole range the kernel evaluates (a >= 2^-6): the acceptance probability theta(a) e^a equal to 5e-7 (the reference
+    sums the series until a term no longer changes its sum; pyhddmjagsutils.py:147-159)."""
+    f = np.float32
+    a = np.exp(np.linspace(np.log(2.0 ** -6), np.log(60.0), 40001)).astype(np.float32)
+    ea = np.exp(-a.astype(np.float64)).astype(np.float32)
+    dual = a < f(0.785398163)
+    rs = (1.0 / np.sqrt(a.astype(np.float64))).astype(np.float32)
+    ra = rs * rs
+    E = np.where(dual, np.exp(-(f(0.616850275) * ra).astype(np.float64)).astype(np.float32), ea)
+    E2 = E * E; E4 = E2 * E2; E8 = E4 * E4
+    P = E8 * (f(5.0) * E8 * E8 + f(-3.0)) + f(1.0)
+    theta3 = np.where(dual, (f(0.696040999) * (rs * ra)) * (E * P), ea * P).astype(np.float64)
+    k = np.arange(1, 801, 2, dtype=np.float64)
+    sgn = np.where(((k - 1) // 2) % 2 == 0, 1.0, -1.0)
+    a64 = a.astype(np.float64)
+    small = a64 < 0.3                                        # the alternating float64 sum cancels below ~0.3: its exact value is the dual's
+    ref = np.empty_like(a64)
+    ref[~small] = (sgn * k * np.exp(-a64[~small, None] * k * k)).sum(1)
+    b = (np.pi ** 2 / 16.0) / a64[small]
+    ref[small] = (np.pi / (4.0 * a64[small])) ** 1.5 * (sgn[:8] * k[:8] * np.exp(-b[:, None] * k[:8] * k[:8])).sum(1)
+    # what the test decides is P(accept) = theta(a) e^a: equal to 5e-7 absolute everywhere (one float32 ulp of a probability); theta
+    # itself to 1e-5 relative (at a = 2^-6, where theta ~ 1e-15, the float32 rounding of the exponent pi^2/16a ~ 38 is what is left)
+    p_err = np.abs(theta3 - ref) * np.exp(a64)
+    rel = np.abs(theta3 - ref) / ref
+    assert p_err.max() < 5e-7 and rel.max() < 1e-5, (p_err.max(), a[p_err.argmax()], rel.max(), a[rel.argmax()])
+    # ... and where both float64 forms are accurate (0.3 <= a <= 2) they are the same function: the identity itself
+    mid = (a64 >= 0.3) & (a64 <= 2.0)
+    bm = (np.pi ** 2 / 16.0) / a64[mid]
+    dual64 = (np.pi / (4.0 * a64[mid])) ** 1.5 * (sgn[:12] * k[:12] * np.exp(-bm[:, None] * k[:12] * k[:12])).sum(1)
+    ser64 = (sgn * k * np.exp(-a64[mid, None] * k * k)).sum(1)
+    assert np.abs(dual64 / ser64 - 1.0).max() < 1e-12
