@@ -974,7 +974,10 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
     RatArgs A;
     memset(&A, 0, sizeof A);
     A.params = params; A.out_trials = out_trials; A.out_summary = out_summary; A.out_ext = out_extdata;
-    A.n_vsets = vB; A.n_trials = tile_n; A.n_total = n_trials; A.tiles_per_set = tiles;
+    // slots per tile: a tile's trials, but at least 2 -- slot -> tile is a multiply-high by ceil(2^32 / slots), which does not exist for 1;
+    // a set of ONE trial is a tile of two slots whose second is a hole (the mechanism of a split set's short last tile)
+    const int tile_slots = tile_n < 2 ? 2 : tile_n;
+    A.n_vsets = vB; A.n_trials = tile_slots; A.n_total = n_trials; A.tiles_per_set = tiles;
     A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32); A.set_offset = set_offset;
     A.ext_sigma = ext_sigma; A.ext_mode = ext_mode;
     // sets of more than 512 trials are split into tiles whose integer partial sums combine_partials_kernel adds up (stream-ordered
@@ -993,13 +996,13 @@ int nddm_simulratcliff(const float *params, int64_t B, int32_t n_trials, uint64_
     // LDS with the rings and the FIFO, six workgroups per SIMD; profiles/r6_ratcliff_shapes.txt).  <= 64 tiles (one lane
     // states one tile's constants).  NDDM_RATCLIFF_GROUP_TRIALS: developer override of the target (A/B runs).
     static const int group_target = [] { const char *e = getenv("NDDM_RATCLIFF_GROUP_TRIALS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 8192 ? v : 1024; }();      // (measured at 300 trials per set: 512 / 1024 / 2048 / 4096 -> 6.3 / 5.4 / 5.8 / 8.5 ms)
-    int group = group_target / tile_n;
+    int group = group_target / tile_slots;
     group = group < 1 ? 1 : (group > 64 ? 64 : group);
     if ((long long)group > vB) group = (int)vB;
     A.group = group;
-    A.tile_magic = (uint32_t)((0x100000000ull + (unsigned long long)tile_n - 1ull) / (unsigned long long)tile_n);
+    A.tile_magic = (uint32_t)((0x100000000ull + (unsigned long long)tile_slots - 1ull) / (unsigned long long)tile_slots);
     // uniform rings | drift FIFO | round keys | table | staged results
-    const size_t lds = ((size_t)WAVE * 8 + RATCLIFF_FIFO + RATCLIFF_KEYS + (size_t)group * RT_WORDS + (size_t)group * (size_t)tile_n) * sizeof(float);
+    const size_t lds = ((size_t)WAVE * 8 + RATCLIFF_FIFO + RATCLIFF_KEYS + (size_t)group * RT_WORDS + (size_t)group * (size_t)tile_slots) * sizeof(float);
     const long long n_groups = (vB + group - 1) / group;
     const dim3 grid((unsigned)n_groups), block(WAVE);
     if (flags & NDDM_GAUSS_FAST) hipLaunchKernelGGL(ratcliff_kernel<true>, grid, block, lds, st, A);

@@ -28,8 +28,8 @@
 //     the way the simulator draws its per-trial latents), the uniforms are stream 3 of the trial, consumed in order;
 //   * results are staged in LDS as one float per trial (the decision time with the response as its sign bit) and flushed as whole
 //     float2 (y, acc) lines with the fused summary reduction (integer sums of the decision time in 2^-16 s: bit-reproducible).
-// The path is VALU-issue bound (per trial ~2.6 attempts, ~1.8 spheres, ~3.2 Philox blocks; rocprofv3: 12 wave-instructions per trial at an
-// exec-mask utilisation of 0.70, profiles/r6_ratcliff_summary.md); 8 B are written per trial.
+// The path is VALU-issue bound (per trial ~2.6 attempts, ~1.8 spheres, ~3.2 Philox blocks; the vector pipe is saturated at an exec-mask
+// utilisation of 0.70: profiles/r6_ratcliff_summary.md, tools/ratcliff_isa_mix.py); 8 B are written per trial.
 #pragma once
 #include "nddm_sim.h"
 
@@ -46,7 +46,7 @@ struct RatArgs {
     float *out_ext;                 // [B] or null
     unsigned long long *partials;   // [B * tiles_per_set, 5] or null
     long long n_vsets;              // B * tiles_per_set
-    int n_trials;                   // trials per tile
+    int n_trials;                   // SLOTS per tile: its trials, at least 2 (a one-trial set has a hole)
     int n_total;                    // trials per set
     int tiles_per_set;
     uint32_t k0, k1;
@@ -124,9 +124,12 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
 {
     extern __shared__ uint32_t lds_raw[];
     const int G = A.group;                                             // tiles per workgroup pass (<= 64)
-    float *const zfifo = reinterpret_cast<float *>(lds_raw + WAVE * 8);            // [RATCLIFF_FIFO]: the drift normals of the next slots, drawn 64 at a time
-    uint32_t *const keys = lds_raw + WAVE * 8 + RATCLIFF_FIFO;         // [RATCLIFF_KEYS]: the ten Philox round-key pairs
-    uint32_t *const tbl = keys + RATCLIFF_KEYS;                        // [G][RT_WORDS]  (16-byte aligned)
+    // LDS: table | uniform rings | drift FIFO | round keys | staged results.  The table comes FIRST: a field of tile i is then at
+    // 48 i + a constant that fits the LDS instructions' offset field (behind the rings it took an address add per read)
+    uint32_t *const tbl = lds_raw;                                     // [G][RT_WORDS]
+    uint32_t *const rings = tbl + G * RT_WORDS;                        // [WAVE][8]  (16-byte aligned: RT_WORDS is a multiple of 4)
+    float *const zfifo = reinterpret_cast<float *>(rings + WAVE * 8);  // [RATCLIFF_FIFO]: the drift normals of the next slots, drawn 64 at a time
+    uint32_t *const keys = rings + WAVE * 8 + RATCLIFF_FIFO;           // [RATCLIFF_KEYS]: the ten Philox round-key pairs
     // The round keys are wave-uniform, but an SGPR operand costs VALU issue time on gfx950 (v_xor_b32 with one: 4.1 cycles against 2.4;
     // the pipe is what bounds this kernel): as in the simulator's step loop they are read from LDS as broadcasts, one round ahead, and
     // folded in by v_bitop3_b32 (philox4x32_10_lds) -- 20 three-input XORs per block instead of 20 + 20 two-input ones, half of them
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
     // way, the SGPRs' bound; 5.06 -> 4.91 ms), from LDS in the exact mode (62 -> 82 VGPRs would cost its sixth wave: 10.35 vs 10.69 ms)
     [[maybe_unused]] AllKeys VK;
     if constexpr (FAST) VK.init(A.k0, A.k1);
-    float *const staged = reinterpret_cast<float *>(tbl + G * RT_WORDS);          // [G][n_trials]: copysign(decision time, response)
+    float *const staged = reinterpret_cast<float *>(keys + RATCLIFF_KEYS);        // [G][n_trials]: copysign(decision time, response)
     const int lane = threadIdx.x;
     const long long n_groups = (A.n_vsets + G - 1) / G;
     for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -182,20 +185,21 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
         int sphere = 0, att = 0;
         UnifStream us;
         us.init(0u, 0u, 0u);
-        us.ring = lds_raw + lane * 8;
+        us.ring = rings + lane * 8;
         int next = 0;                                     // wave-uniform: the group's next unassigned slot
         int drawn = 0;                                    // wave-uniform: slots [next, drawn) have their drift normal in the FIFO
         const int n_slots = g_here * A.n_trials;
         // slot -> (tile, trial within the tile); a slot beyond its tile's n_here is a hole
-        auto slot_tile = [&](int idx) { return A.n_trials == 1 ? idx : (int)(((unsigned long long)(uint32_t)idx * A.tile_magic) >> 32); };
+        auto slot_tile = [&](int idx) { return (int)__umulhi((uint32_t)idx, A.tile_magic); };      // (n_trials >= 2: see the launch)
 
         // the sphere that starts at the current position: its constants and its direction (one uniform) -- or the end of the
         // trial, when the position lies on a boundary (Beta = 0 or 1) or the safety cap is reached; returns "the trial goes on"
         auto setup_sphere = [&]() -> bool {
             // (straight-line but for the store: every level of nested divergence costs the loop ~10 scalar instructions of exec-mask
-            //  bookkeeping, and the scalar unit is as busy as the vector pipe here -- tools/ratcliff_isa_mix.py; a trial that ends
-            //  computes a sphere nobody uses)
-            const float radius = fminf(du, dl);
+            //  bookkeeping and copies of the loop-carried state at its edges -- tools/ratcliff_isa_mix.py; a trial that ends computes a
+            //  sphere nobody uses)
+            float radius;                                 // min(du, dl): ONE v_min_f32 (fminf() quiets its operands first: two more instructions)
+            asm("v_min_f32 %0, %1, %2" : "=v"(radius) : "v"(du), "v"(dl));
             const bool dead = !(radius > 0.0f) | (sphere >= RATCLIFF_MAX_SPHERES);
             if (dead) staged[slot] = copysignf(total, du <= dl ? 1.0f : -1.0f);
             lam = lam1 + rat_div<FAST>(c_lam2, radius * radius);                         // :138
@@ -218,28 +222,28 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 if (next + n_want > drawn && drawn < n_slots) {
                     // the drift normals of the next 64 slots, by ALL lanes (auxiliary normal 0 of each slot's trial: one Philox block
                     // and one Box-Muller pair per trial, ~95 instructions whatever the number of lanes a hand-out serves)
-                    const int ds = drawn + lane;
-                    if (ds < n_slots) {
-                        const int tile = slot_tile(ds);
-                        const uint32_t *t = tbl + __mul24(tile, RT_WORDS);
-                        const int tr = ds - __mul24(tile, A.n_trials);
-                        float z0 = 0.0f;
-                        if (tr < (int)t[RT_NHERE]) {
-                            float z1_unused;
-                            AuxStream<FAST> aux(kbase, t[RT_SETLO], t[RT_SETHI], t[RT_T0] + (uint32_t)tr);
-                            aux.first_pair(z0, z1_unused);
-                        }
-                        zfifo[ds & (RATCLIFF_FIFO - 1)] = z0;
-                    }
+                    // (straight-line: a lane beyond the group's last slot redoes that slot -- the same value to the same entry -- and a
+                    //  hole's normal is drawn and never read; nested conditions cost scalar bookkeeping and save nothing here)
+                    const int ds = drawn + lane < n_slots ? drawn + lane : n_slots - 1;
+                    const int tile = slot_tile(ds);
+                    const uint32_t *t = tbl + __mul24(tile, RT_WORDS);
+                    const int tr = ds - __mul24(tile, A.n_trials);
+                    float z0, z1_unused;
+                    AuxStream<FAST> aux(kbase, t[RT_SETLO], t[RT_SETHI], t[RT_T0] + (uint32_t)tr);
+                    aux.first_pair(z0, z1_unused);
+                    zfifo[ds & (RATCLIFF_FIFO - 1)] = z0;
                     drawn = drawn + WAVE < n_slots ? drawn + WAVE : n_slots;
                     __builtin_amdgcn_wave_barrier();          // (the hand-out below reads other lanes' entries: a wave's LDS operations complete in order)
                 }
                 const int idx = next + (int)lane_rank(want);
-                if (!has && idx < n_slots) {
-                    const int tile = slot_tile(idx);
-                    const int tr = idx - __mul24(tile, A.n_trials);
+                {
+                    // (one condition, evaluated by every lane on a clamped slot: the tile's trial count is read before it is known
+                    //  whether this lane takes a trial)
+                    const int idc = idx < n_slots ? idx : n_slots - 1;
+                    const int tile = slot_tile(idc);
+                    const int tr = idc - __mul24(tile, A.n_trials);
                     const uint32_t *t = tbl + __mul24(tile, RT_WORDS);
-                    if (tr < (int)t[RT_NHERE]) {
+                    if (!has & (idx < n_slots) & (tr < (int)t[RT_NHERE])) {
                         slot = idx;
                         const uint32_t trial = t[RT_T0] + (uint32_t)tr;
                         const float inv_D = __uint_as_float(t[RT_INVD]);
@@ -259,10 +263,13 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
             if (need_sphere) { has = setup_sphere(); need_sphere = false; }
             if (!__builtin_amdgcn_ballot_w64(has)) {
                 if (next >= n_slots) break;
-                continue;                                 // (every lane that took a trial ended it at once, or met a hole)
-            }
-            // ---- one rejection attempt of every lane that holds a trial (:147-159)
-            if (has) {
+                if constexpr (!FAST) continue;            // (every lane that took a trial ended it at once, or met a hole; the fast mode's
+            }                                             //  attempt runs for idle lanes anyway)
+            // ---- one rejection attempt of every lane that holds a trial (:147-159).  In the fast mode the lanes that hold none run
+            // along (no region, no copies of the loop-carried state at its edges): what they compute is never observed -- their state
+            // is set when they are handed a trial -- and `accept` is false for them.  The exact mode's series loop must not see their
+            // garbage (it could run to its cap), so there the region stays.
+            if (FAST || has) {
                 const float s2 = us.next(), s1 = us.next();
                 const float nl = rat_neg_log<FAST>(s1);
                 const float a = F * nl;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                     // 2^-6 -- a = 0 gives NaNs here -- is rejected by the last line, as the exact mode rejects it before its series)
                     const float lhs = s2 * (dual ? ea : 1.0f);
                     const float rhs = P * (dual ? (0.696040999f * (rs * ra)) * E : 1.0f);
-                    accept = (att >= RATCLIFF_MAX_ATTEMPTS) | (!(a < 0.015625f) & (lhs <= rhs));
+                    accept = has & ((att >= RATCLIFF_MAX_ATTEMPTS) | (!(a < 0.015625f) & (lhs <= rhs)));
                 } else {
                     if (att >= RATCLIFF_MAX_ATTEMPTS) accept = true;
                     else if (!(a < 0.015625f)) {

@@ -38,15 +38,19 @@ def loop_of(txt, sym_re):
         insts.append((int(m.group(3), 16), m.group(1), m.group(2), None if not tgt else int(tgt.group(1), 16)))
     base = insts[0][0]
     insts = [(a - base, op, args, t) for a, op, args, t in insts]
-    # the flattened loop: the backward branch whose region holds both Philox bodies (drift FIFO + uniform refill = 32 v_mad_u64_u32)
-    best = None
+    # the flattened loop: the backward branches whose region holds both Philox bodies (drift FIFO + uniform refill: >= 32 v_mad_u64_u32)
+    # and no more of them than the smallest such region -- the loop has several latches (its `continue`s and the compiler's block
+    # placement), the group loop around it holds further blocks (the set's external datum) -- from the first header to the last latch
+    cands = []
     for a, op, _, t in insts:
         if op.startswith(("s_cbranch", "s_branch")) and t is not None and t < a:
-            body = [x for x in insts if t <= x[0] <= a]
-            n_mad = sum(1 for x in body if x[1].startswith("v_mad_u64_u32"))
-            if n_mad >= 32 and (best is None or len(body) < len(best)):
-                best = body
-    return best
+            n_mad = sum(1 for x in insts if t <= x[0] <= a and x[1].startswith("v_mad_u64_u32"))
+            if n_mad >= 32:
+                cands.append((n_mad, t, a))
+    n_min = min(c[0] for c in cands)
+    lo = min(t for n, t, a in cands if n == n_min)
+    hi = max(a for n, t, a in cands if n == n_min)
+    return [x for x in insts if lo <= x[0] <= hi]
 
 
 def main():
