@@ -900,8 +900,10 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
                                                     "exec_mask_utilisation": v["exec_mask_utilisation"],
                                                     "frac": min(1.0, busy) * v["exec_mask_utilisation"],
                                                     "what": "frac = (VALU pipe busy, capped at 1) x (exec-mask utilisation): the share of the vector "
-                                                            "pipe's lane-cycles spent on lanes that hold a trial; the instruction stream itself "
-                                                            "(trip counts of a rejection sampler) is data-dependent, so there is no lockstep run to compare with",
+                                                            "pipe's lane-cycles spent on switched-on lanes -- lanes that hold a trial, plus (~0.015) "
+                                                            "idle lanes that run the fast mode's attempt along because a region around it would "
+                                                            "cost more; the instruction stream itself (trip counts of a rejection sampler) is "
+                                                            "data-dependent, so there is no lockstep run to compare with",
                                                     "issue_model": {k: im[k] for k in ("source", "issue_costs_from", "library_matches")}}
                 else:
                     leg["roofline"]["traffic_refused"] = [os.path.basename(path)]
