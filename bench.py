@@ -141,6 +141,26 @@ def free_port():
         return s.getsockname()[1]
 
 
+def init_own_group(dist, backend, dev, tries=5):
+    """init_process_group for a world of ONE that this process rendezvouses with itself: on a port that was free a moment ago
+    (free_port() closes its probe socket before the store binds: another socket of this host can take the port in between -- seen once
+    as EADDRINUSE on the GPU box), so a failed bind is retried on a fresh port."""
+    last = None
+    for _ in range(tries):
+        os.environ["MASTER_PORT"] = str(free_port())
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=0, world_size=1)
+            return
+        except Exception as e:                                   # noqa: BLE001 -- DistNetworkError / RuntimeError, by version
+            last = e
+            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e).lower():
+                raise
+    raise last
+
+
 def visible_gpus():
     """Number of GPUs a worker would see, asked of a THROWAWAY child process: the launcher itself never loads the HIP runtime
     (its children must be fresh processes, and a process that has touched the GPU must not be re-executed)."""
@@ -540,7 +560,9 @@ def worker(a):
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")      # the process group's own streams: high priority as well
-        if a.backend == "nccl":
+        if world == 1 and os.environ.get("NDDM_BENCH_OWN_LAUNCHER") == "1":
+            init_own_group(dist, a.backend, dev)                 # (main() made this process its own launcher: the port is ours to choose)
+        elif a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -780,13 +802,22 @@ def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False
                                         want_trials=want_trials, bridge=bridge, state_f64=state_f64)
         run(0)
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
-        for i, (e0, e1) in enumerate(ev):
-            e0.record(); run(1 + i); e1.record()
-        torch.cuda.synchronize()
-        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        times, done = [], 0
+        for n_more in (L, 3 * L):                        # a launch of a few ms is sampled 4 L times: a short sample is at the mercy of one hiccup
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_more)]
+            for i, (e0, e1) in enumerate(ev):
+                e0.record(); run(1 + done + i); e1.record()
+            torch.cuda.synchronize()
+            times += [e0.elapsed_time(e1) for e0, e1 in ev]
+            done += n_more
+            if np.mean(times) >= 15.0:
+                break
+        launch_ms[:] = [round(t, 3) for t in times]
+        return float(np.mean(times))
 
+    launch_ms = []
     ms = timed(True)
+    launch_ms_trials = list(launch_ms)
     geometry = engine.last_launch()
     em_steps = em_steps_of(out_summary, p_dev[:, tau_i], dt, max_k, bridge)          # of the last launch
     alg_bytes = B * N * 8 + B * (p_host.shape[1] * 4 + engine.SUMMARY_K * 4)
@@ -794,7 +825,8 @@ def simulator_leg(a, ctx, name, out_trials, out_summary, with_summary_only=False
     nm = "single_trial_alpha_not_scaled" if name == "single" else ("basic_ddm_dc" if name == "basic" else name)
     variant = gauss + (", state_f64" if state_f64 else "")
     leg = {"metric": f"simulated DDM trials/sec at n_trials={N} dt={dt:g} ({nm}, max_steps={max_steps:g})",
-           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": KERNEL_NAME[name] % variant,
+           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": len(launch_ms_trials), "launch_ms": launch_ms_trials,
+           "kernel": KERNEL_NAME[name] % variant,
            "workload": f"{nm} HIP simulator, {B} parameter sets x {N} trials per launch, dt={dt}, max_steps={max_steps:g}, params ~ its "
                        f"reference prior (default_rng 2023); trials f32[B,N,2] + fused summaries f32[B,10]",
            "gauss": gauss, "state_f64": bool(state_f64), "dt": dt, "max_steps": max_steps,
@@ -849,18 +881,28 @@ def ratcliff_leg(a, ctx, out_trials, out_summary):
         run = lambda i: engine.simulratcliff(p_dev, N, seed=2023, set_offset=i * B, fast=fast, out_trials=out_trials, out_summary=out_summary)
         run(0)
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
-        for i, (e0, e1) in enumerate(ev):
-            e0.record(); run(1 + i); e1.record()
-        torch.cuda.synchronize()
-        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        times, done = [], 0
+        for n_more in (L, 3 * L):                        # (a few ms per launch: 4 L launches, as simulator_leg samples its short kernels)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_more)]
+            for i, (e0, e1) in enumerate(ev):
+                e0.record(); run(1 + done + i); e1.record()
+            torch.cuda.synchronize()
+            times += [e0.elapsed_time(e1) for e0, e1 in ev]
+            done += n_more
+            if np.mean(times) >= 15.0:
+                break
+        launch_ms[:] = [round(t, 3) for t in times]
+        return float(np.mean(times))
 
+    launch_ms = []
     ms = timed(True)
+    launch_ms_fast = list(launch_ms)
     mean_rt = float(out_summary[:, 3].double().mean().item())
     alg_bytes = B * N * 8 + B * (6 * 4 + engine.SUMMARY_K * 4)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     leg = {"metric": f"simulated DDM trials/sec at n_trials={N}, exact first-passage sampler (alpha_not_scaled's own generator, simulratcliff; no dt)",
-           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": L, "kernel": "nddm::ratcliff_kernel<fast>",
+           "value": B * N / (ms * 1e-3), "unit": "trials/s", "kernel_ms": ms, "launches": len(launch_ms_fast), "launch_ms": launch_ms_fast,
+           "kernel": "nddm::ratcliff_kernel<fast>",
            "workload": f"simulratcliff on the device, {B} parameter sets x {N} trials per launch, params ~ alpha_not_scaled.py:66-72 (default_rng 2023); "
                        f"(y, acc) f32[B,N,2] + fused summaries f32[B,10]",
            "mean_rt_s": mean_rt, "p_missing": 0.0,
@@ -940,8 +982,7 @@ def training_leg(a, ctx, gather_rccl):
     own_group = False
     if gather_rccl and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ["MASTER_PORT"] = str(free_port())
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        init_own_group(dist, "nccl", dev)
         own_group = True
     iters, warm, out = max(1, a.leg_train_iters), 10, {}
     try:
@@ -1451,7 +1492,8 @@ def main():
                          f"(--share-device --backend gloo rehearses the multi-rank path on one GPU)")
         launch_ranks(a.gpus)                         # does not return
     if "WORLD_SIZE" not in os.environ and a.dist:    # one rank, distributed code path: be our own launcher
-        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                          NDDM_BENCH_OWN_LAUNCHER="1")
     worker(a)
 
 
