@@ -101,7 +101,8 @@ def parse():
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the side legs of the default line: at N = 1 the other BASELINE configs (single-trial + fused summaries, "
                          "alpha_not_scaled with the bridge, the config-5 training loop), at N > 1 the all-gather and strong-scaling legs")
-    ap.add_argument("--leg-launches", type=int, default=4, help="timed launches per simulator side leg")
+    ap.add_argument("--leg-launches", type=int, default=4, help="timed launches per simulator side leg (a leg whose launch is under 15 ms times four times as many: the first launches of a short "
+                         "sample run while the clocks settle; every launch's time is in the leg's launch_ms)")
     ap.add_argument("--leg-train-iters", type=int, default=150, help="timed iterations per training side leg")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --share-device rehearse the multi-process path on a one-GPU box")
