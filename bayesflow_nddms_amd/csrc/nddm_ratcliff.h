@@ -330,7 +330,10 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
             }
         }
         __syncthreads();
-        // ---- flush, tile by tile: whole float2 lines + the fused summary (integer sums, decision time in 2^-16 s)
+        // ---- flush, tile by tile: whole float2 lines + the fused summary's integer sums (decision time in 2^-16 s), reduced over the
+        // wave by DPP (as shuffles the five sums are 54 ds_bpermute round trips per tile; as LDS atomics on one address 200 cycles of
+        // the CU's LDS pipe each: 11.5 ms instead of 4.3) and parked in LDS -- lane `tile`'s uniform ring: nobody draws any more --
+        // for the group's epilogue.  [0] sum k + (n_upper << 40)  [1] sum k^2  [2] sum k (upper)  [3] sum k^2 (upper);  k < 2^26
         for (int tile = 0; tile < g_here; ++tile) {
             const uint32_t *t = tbl + tile * RT_WORDS;
             const long long vset = v0 + tile;
@@ -355,22 +358,38 @@ __global__ __launch_bounds__(WAVE) void ratcliff_kernel(const RatArgs A)
                 }
             }
             if (A.out_summary) {
-                // (DPP reductions, totals in lane 63: as shuffles the five sums are 54 ds_bpermute round trips per tile, ~5000 cycles
-                //  in which this wave issues nothing else)
                 n_up = (int)wave_sum_dpp((uint32_t)n_up);
                 sk = wave_sum_dpp64(sk); sk2 = wave_sum_dpp64(sk2); sk_up = wave_sum_dpp64(sk_up); sk2_up = wave_sum_dpp64(sk2_up);
-                if (lane == WAVE - 1) {
-                    if (A.partials) {
-                        unsigned long long *q = A.partials + vset * 5;
-                        q[0] = (unsigned long long)n_up | ((unsigned long long)(n_here - n_up) << 21);
-                        q[1] = sk; q[2] = sk2; q[3] = sk_up; q[4] = sk2_up;
-                    } else {
-                        finalize_summary(A.out_summary + set * NDDM_SUMMARY_K, n_up, n_here - n_up, 0, sk, sk2, sk_up, sk2_up, 0, 0, A.n_total,
-                                         1.52587890625e-05f, Tau);
-                    }
+                if (lane == WAVE - 1) {                                // (the DPP reductions leave the totals in the last lane)
+                    unsigned long long *q = reinterpret_cast<unsigned long long *>(rings + tile * 8);
+                    q[0] = sk | ((unsigned long long)n_up << 40);                                  // (sk < 2^36, n_up <= 512)
+                    q[1] = sk2; q[2] = sk_up; q[3] = sk2_up;
                 }
             }
-            if (A.out_ext && lane == 0 && t0 == 0) {
+        }
+        // ---- the per-set epilogue of the whole group at once, lane l for tile l: the summary row from the tile's integer sums (seven
+        // float64 divisions, ~300 instructions -- by ONE lane after every tile they were a tenth of the kernel's instructions at 300
+        // trials per set and a third at 100) and the set's external datum
+        __builtin_amdgcn_wave_barrier();
+        if (lane < g_here) {
+            const uint32_t *t = tbl + lane * RT_WORDS;
+            const long long vset = v0 + lane;
+            const long long set = TPS == 1 ? vset : vset / TPS;
+            const int n_here = (int)t[RT_NHERE];
+            if (A.out_summary) {
+                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(rings + lane * 8);
+                const int n_up = (int)(q[0] >> 40);
+                const unsigned long long sk = q[0] & ((1ull << 40) - 1ull);
+                if (A.partials) {                                      // a tile of a split set: combine_partials_kernel adds the tiles up
+                    unsigned long long *w = A.partials + vset * 5;
+                    w[0] = (unsigned long long)n_up | ((unsigned long long)(n_here - n_up) << 21);
+                    w[1] = sk; w[2] = q[1]; w[3] = q[2]; w[4] = q[3];
+                } else {
+                    finalize_summary(A.out_summary + set * NDDM_SUMMARY_K, n_up, n_here - n_up, 0, sk, q[1], q[2], q[3], 0, 0, A.n_total,
+                                     1.52587890625e-05f, __uint_as_float(t[RT_TAU]));
+                }
+            }
+            if (A.out_ext && t[RT_T0] == 0u) {
                 float z0, z1_unused;
                 AuxStream<FAST> aux(kbase, t[RT_SETLO], t[RT_SETHI], 0xffffffffu);                      // the set's external datum (alpha_not_scaled.py:103-106)
                 aux.first_pair(z0, z1_unused);
